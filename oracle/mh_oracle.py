@@ -1,0 +1,152 @@
+"""ctypes face of the CPU oracle (oracle/mh_oracle.c) — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product package (markov-huffman-coding_amd/) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libmh_oracle.so")
+REF_BIN = os.path.join(_HERE, "_ref", "markovhuffman")
+
+_u8p = C.POINTER(C.c_uint8)
+_u64p = C.POINTER(C.c_uint64)
+
+
+def build(force=False):
+    """Compile libmh_oracle.so (and oracle/_ref when /root/reference is present)."""
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "mh_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB
+
+
+def _load():
+    build()
+    lib = C.CDLL(_LIB)
+    lib.mho_histogram_o1.argtypes = [C.c_void_p, C.c_size_t, C.c_uint8, C.c_void_p]
+    lib.mho_histogram_o0.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.mho_model_from_counts.argtypes = [C.c_void_p, C.c_int]
+    lib.mho_model_from_counts.restype = C.c_void_p
+    lib.mho_model_from_table.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]
+    lib.mho_model_from_table.restype = C.c_void_p
+    lib.mho_model_free.argtypes = [C.c_void_p]
+    lib.mho_model_type.argtypes = [C.c_void_p]
+    lib.mho_model_write_table.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.mho_model_write_table.restype = C.c_size_t
+    lib.mho_export_codes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.mho_get_lut.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 4
+    lib.mho_compress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _u64p]
+    lib.mho_compress.restype = C.c_size_t
+    lib.mho_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    lib.mho_decompress.restype = C.c_int64
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _load()
+    return _lib
+
+
+def _as_u8(data):
+    a = np.frombuffer(data, dtype=np.uint8) if isinstance(data, (bytes, bytearray, memoryview)) else np.ascontiguousarray(data, dtype=np.uint8)
+    return a
+
+
+def histogram_o1(data, prev0=0x20):
+    a = _as_u8(data)
+    out = np.zeros(65536, dtype=np.uint64)
+    lib().mho_histogram_o1(a.ctypes.data, a.size, prev0, out.ctypes.data)
+    return out
+
+
+def histogram_o0(data):
+    a = _as_u8(data)
+    out = np.zeros(256, dtype=np.uint64)
+    lib().mho_histogram_o0(a.ctypes.data, a.size, out.ctypes.data)
+    return out
+
+
+class Model:
+    """Owns an mho_model*."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise ValueError("oracle: bad table")
+        self._h = handle
+
+    @classmethod
+    def from_counts(cls, counts, order):
+        c = np.ascontiguousarray(counts, dtype=np.uint64)
+        assert c.size == (65536 if order else 256)
+        return cls(lib().mho_model_from_counts(c.ctypes.data, order))
+
+    @classmethod
+    def from_data(cls, data, order=1):
+        return cls.from_counts(histogram_o1(data) if order else histogram_o0(data), order)
+
+    @classmethod
+    def from_table(cls, table_bytes):
+        a = _as_u8(table_bytes)
+        err = C.c_int(0)
+        h = lib().mho_model_from_table(a.ctypes.data, a.size, C.byref(err))
+        if not h:
+            raise ValueError("oracle: bad table (%d)" % err.value)
+        return cls(h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().mho_model_free(self._h)
+            self._h = None
+
+    @property
+    def type(self):
+        return lib().mho_model_type(self._h)
+
+    def table_bytes(self):
+        n = lib().mho_model_write_table(self._h, None, 0)
+        out = np.zeros(max(n, 1), dtype=np.uint8)
+        lib().mho_model_write_table(self._h, out.ctypes.data, n)
+        return out[:n].tobytes()
+
+    def codes(self):
+        """(len8[65536], code64[65536]) indexed prev*256+sym; code right-aligned."""
+        l = np.zeros(65536, dtype=np.uint8)
+        c = np.zeros(65536, dtype=np.uint64)
+        lib().mho_export_codes(self._h, l.ctypes.data, c.ctypes.data)
+        return l, c
+
+    def lut(self, prev, w):
+        p, i, v, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        lib().mho_get_lut(self._h, prev, w, C.byref(p), C.byref(i), C.byref(v), C.byref(d))
+        return bool(p.value), bool(i.value), v.value, d.value
+
+    def compress(self, data):
+        """Returns (file_bytes incl. header, payload_bits)."""
+        a = _as_u8(data)
+        nb = C.c_uint64(0)
+        need = lib().mho_compress(self._h, a.ctypes.data, a.size, None, 0, C.byref(nb))
+        out = np.zeros(need, dtype=np.uint8)
+        lib().mho_compress(self._h, a.ctypes.data, a.size, out.ctypes.data, need, C.byref(nb))
+        return out.tobytes(), nb.value
+
+    def decompress(self, blob, cap=None):
+        a = _as_u8(blob)
+        if cap is None:
+            n = lib().mho_decompress(self._h, a.ctypes.data, a.size, None, 0)
+            if n < 0:
+                raise ValueError("oracle: decompress error %d" % n)
+            cap = n
+        out = np.zeros(max(cap, 1), dtype=np.uint8)
+        n = lib().mho_decompress(self._h, a.ctypes.data, a.size, out.ctypes.data, cap)
+        if n < 0:
+            raise ValueError("oracle: decompress error %d" % n)
+        return out[:n].tobytes()
