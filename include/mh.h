@@ -1,0 +1,188 @@
+/*
+ * mh.h — C ABI of the MI355X-native Markov-Huffman codec (libmhc.so).
+ *
+ * This is the drop-in boundary for the reference's hot path.  The reference
+ * (jeremy-rifkin/Markov-Huffman-Coding) has no FFI of its own: its seam is the
+ * C++ class i_coding_provider (src/coding.h:18-35) built in main()
+ * (src/main.cpp:136-184) from a histogram made by construct_table()
+ * (src/main.cpp:29-39).  Each entry point below names the reference interface
+ * it replaces; INTEGRATION.md shows the binding a maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every function returns an int status
+ *     (MH_OK == 0, negative = error).  The reference's convention is
+ *     eprintf + exit(1) (src/utils.cpp:62-65, src/coding.cpp:103-110); the
+ *     C++ face in markov-huffman-coding_amd/host/ turns a non-zero status into
+ *     exactly that.
+ *   - the caller owns every buffer.  "mh_*" functions take HOST pointers and
+ *     stage through HBM internally; "mh_dev_*" functions take DEVICE pointers
+ *     plus a hipStream_t (as void*), never allocate, and never synchronise
+ *     unless stated.
+ *   - all compute runs in hand-written HIP kernels for gfx950.  There is no
+ *     CPU fallback: without a usable GPU every compute call returns
+ *     MH_ERR_NO_DEVICE.
+ *   - an mh_model is immutable after construction and may be shared by threads.
+ *   - bit order everywhere: MSB first inside a byte (src/bitbuffer.cpp:12).
+ */
+#ifndef MH_H
+#define MH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MH_VERSION 100
+
+enum {
+    MH_OK = 0,
+    MH_ERR_ARG = -1,           /* null/misaligned pointer, bad size or option            */
+    MH_ERR_NO_DEVICE = -2,     /* no usable gfx950 device / HIP runtime                  */
+    MH_ERR_HIP = -3,           /* a HIP call failed (mh_last_hip_error() has the code)   */
+    MH_ERR_CORRUPT = -4,       /* stream not decodable (src/coding.cpp:103-106)          */
+    MH_ERR_TYPE = -5,          /* stream/table type mismatch (src/coding.cpp:107-110)    */
+    MH_ERR_BADTABLE = -6,      /* table file not parseable (src/huffman.cpp:166-172)     */
+    MH_ERR_CODE_TOO_LONG = -7, /* a codeword exceeds 64 bits (not reachable < 2^44 B)    */
+    MH_ERR_CAPACITY = -8,      /* output buffer or workspace too small                   */
+    MH_ERR_TIMEOUT = -9,       /* bounded device-side wait expired (should not happen)   */
+    MH_ERR_NOMEM = -10,
+};
+
+/* Initial context of every stream: the space character (src/main.cpp:32, src/coding.cpp:67,118). */
+#define MH_PREV0 0x20
+
+const char *mh_strerror(int status);
+int mh_last_hip_error(void);
+/* Number of usable devices; 0 when there is none (never an error). */
+int mh_device_count(void);
+/* Device used by the calling thread's subsequent mh_* / mh_dev_* calls (hipSetDevice). */
+int mh_set_device(int ordinal);
+
+/* ------------------------------------------------------------------ model */
+
+typedef struct mh_model mh_model;
+
+/* Replaces huffman_table(int*) (src/huffman.h:14, src/huffman.cpp:18-20,131-164; order 0, 256 counts)
+ * and markov_huffman_table(int*) (src/markov_huffman.h:12, src/markov_huffman.cpp:9-13; order 1,
+ * counts[256*prev+sym], 65536 counts).  Tie-breaking reproduces min_pq (src/min_pq.tpp:4-52) and the
+ * height swap (src/huffman.cpp:147-149) exactly; counts are 64-bit (reference: int).
+ * Builds the code tables and decode LUTs (src/huffman.cpp:91-123) and uploads them to the current
+ * device.  Host pointer in. */
+int mh_model_from_counts(const uint64_t *counts, int order, mh_model **out);
+
+/* Same, counts resident in HBM (e.g. straight out of mh_dev_histogram_o1 or an RCCL all-reduce).
+ * Per-context tree build, code derivation and LUT fill run in a HIP kernel on `stream`; the call
+ * synchronises the stream once to pick up the (small) host mirror of the tables. */
+int mh_dev_model_from_counts(const uint64_t *d_counts, int order, void *stream, mh_model **out);
+
+/* Replaces the table-file constructors huffman_table(bitbuffer&) / markov_huffman_table(bitbuffer&)
+ * (src/huffman.cpp:22-25,166-172; src/markov_huffman.cpp:15-25) and main()'s type sniffing on the
+ * first bit (src/main.cpp:147-161).  `bytes` = whole table file. */
+int mh_model_from_table_bits(const uint8_t *bytes, size_t n, mh_model **out);
+
+/* Replaces write_coding_tree (src/markov_huffman.cpp:80-88, src/huffman.cpp:83-85,174-188) plus the
+ * bitbuffer flush that pads to a byte (src/bitbuffer.cpp:170-180).  *nbytes = size needed/written. */
+int mh_model_write_table(const mh_model *m, uint8_t *out, size_t cap, size_t *nbytes);
+
+/* get_type() (src/coding.h:29-32): 0 simple Huffman, 1 Markov-Huffman. */
+int mh_model_type(const mh_model *m);
+/* Longest codeword in bits (0 for an all-empty model). */
+int mh_model_max_code_len(const mh_model *m);
+/* get_encoding(prev, c) (src/markov_huffman.cpp:52-54 -> src/huffman.cpp:71-73): *len bits,
+ * *code right-aligned (valid when *len <= 64).  *len == 0: symbol has no code in this context. */
+int mh_model_get_code(const mh_model *m, int prev, int sym, int *len, uint64_t *code);
+/* decoding_lookup(prev, w) (src/markov_huffman.cpp:56-58 -> src/huffman.cpp:87-89): the 8-bit-window
+ * LUT entry.  *present == 0 for a null entry (empty context). */
+int mh_model_get_lut(const mh_model *m, int prev, int w, int *present, int *is_internal, int *value, int *depth);
+void mh_model_free(mh_model *m);
+
+/* ------------------------------------------------------------- chunk index */
+/*
+ * The reference's stream has no index (src/coding.cpp:35-59), and a decoder's state is
+ * (bit position, previous byte), so parallel decode needs an out-of-band index: one uint64 per chunk
+ * of `chunk_symbols` input bytes,
+ *        entry = (context byte at the chunk start << 56) | payload bit offset of the chunk start.
+ * mh_encode / mh_dev_encode produce it; it never changes the payload bytes.  chunk_symbols must be a
+ * power of two in [MH_CHUNK_MIN, MH_CHUNK_MAX].
+ */
+#define MH_CHUNK_MIN 256u
+#define MH_CHUNK_MAX 8192u
+#define MH_CHUNK_DEFAULT 1024u
+#define MH_INDEX_BIT_MASK 0x00FFFFFFFFFFFFFFull
+static inline uint64_t mh_index_entries(uint64_t n_symbols, uint32_t chunk_symbols) {
+    return (n_symbols + chunk_symbols - 1) / chunk_symbols;
+}
+
+/* ------------------------------------------------------- host-buffer calls */
+
+/* Replaces construct_table + the order-1 lambda (src/main.cpp:29-39,173-181): counts[256*prev+c]++,
+ * prev starting at prev0.  counts: 65536 entries, overwritten. */
+int mh_histogram_o1(const uint8_t *data, size_t n, uint8_t prev0, uint64_t *counts);
+/* Replaces construct_table + the order-0 lambda (src/main.cpp:164-171).  counts: 256 entries. */
+int mh_histogram_o0(const uint8_t *data, size_t n, uint64_t *counts);
+
+/* Replaces the body of i_coding_provider::compress (src/coding.cpp:61-94) between the header
+ * placeholder and the header rewrite: payload bits only.  *nbits = payload length in bits; payload
+ * bytes written = ceil(*nbits / 8), zero padded (src/bitbuffer.cpp:175).  cap must be >=
+ * mh_encode_bound(n).  index/chunk_symbols optional (index == NULL: none). */
+int mh_encode(const mh_model *m, const uint8_t *data, size_t n, uint8_t prev0,
+              uint8_t *out_payload, size_t cap, uint64_t *nbits,
+              uint64_t *index, uint32_t chunk_symbols);
+/* Worst-case payload bytes for n input bytes under model m (n * max_code_len bits, rounded up, + slack). */
+size_t mh_encode_bound(const mh_model *m, size_t n);
+/* The header byte of src/coding.cpp:88: 0x30 | (~type & 1) << 3 | (8 - nbits % 8) % 8. */
+uint8_t mh_stream_header(const mh_model *m, uint64_t nbits);
+/* Validates a header byte as src/coding.cpp:100-116 does and returns the payload length in bits for a
+ * file of file_bytes bytes: MH_ERR_CORRUPT on bad magic, MH_ERR_TYPE on a table/stream mismatch. */
+int mh_stream_parse_header(const mh_model *m, uint8_t header, uint64_t file_bytes, uint64_t *nbits);
+
+/* Replaces the loop of i_coding_provider::decompress (src/coding.cpp:118-157): decode exactly `nbits`
+ * payload bits.  With an index (from mh_encode) chunks decode in parallel and n_symbols must be the
+ * original length; with index == NULL (a stream produced by the reference) a device-side
+ * index-building pass runs first and n_symbols is ignored.  *nbytes = decoded size (written if cap
+ * suffices, else MH_ERR_CAPACITY with *nbytes set). */
+int mh_decode(const mh_model *m, const uint8_t *payload, uint64_t nbits, uint8_t prev0,
+              uint8_t *out, size_t cap, size_t *nbytes,
+              const uint64_t *index, uint32_t chunk_symbols, uint64_t n_symbols);
+
+/* ------------------------------------------------------------ device calls */
+/* Device pointers, stream-ordered, no allocation, no synchronisation.  d_data / d_payload / d_out must
+ * be 16-byte aligned.  Workspaces: query the size, allocate once, reuse. */
+
+size_t mh_dev_histogram_workspace(size_t n);
+/* d_counts (65536 or 256 x uint64) is overwritten. */
+int mh_dev_histogram_o1(const uint8_t *d_data, size_t n, uint8_t prev0, uint64_t *d_counts,
+                        void *d_ws, size_t ws_bytes, void *stream);
+int mh_dev_histogram_o0(const uint8_t *d_data, size_t n, uint64_t *d_counts,
+                        void *d_ws, size_t ws_bytes, void *stream);
+
+size_t mh_dev_encode_workspace(size_t n);
+/* d_nbits: one uint64 (payload bits).  d_index: mh_index_entries(n, chunk_symbols) entries or NULL.
+ * d_status: one int32, set non-zero by the device on a bounded-wait expiry (check after sync). */
+int mh_dev_encode(const mh_model *m, const uint8_t *d_data, size_t n, uint8_t prev0,
+                  uint8_t *d_payload, size_t cap, uint64_t *d_nbits,
+                  uint64_t *d_index, uint32_t chunk_symbols,
+                  void *d_ws, size_t ws_bytes, void *stream);
+
+size_t mh_dev_decode_workspace(uint64_t nbits, uint64_t n_symbols, uint32_t chunk_symbols);
+/* Parallel decode with an index.  Errors found on the device (null LUT entry, walk past the end)
+ * are reported through the int32 at the start of the workspace: mh_dev_status() reads it. */
+int mh_dev_decode(const mh_model *m, const uint8_t *d_payload, uint64_t nbits,
+                  uint8_t *d_out, uint64_t n_symbols,
+                  const uint64_t *d_index, uint32_t chunk_symbols,
+                  void *d_ws, size_t ws_bytes, void *stream);
+/* Index-building pass for a stream without one (sequential on the device): fills d_index (capacity
+ * index_cap entries) and *d_n_symbols.  chunk_symbols as above. */
+int mh_dev_build_index(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, uint8_t prev0,
+                       uint64_t *d_index, uint64_t index_cap, uint32_t chunk_symbols,
+                       uint64_t *d_n_symbols, void *d_ws, size_t ws_bytes, void *stream);
+/* Synchronises `stream` and returns the device-side status word of a workspace (MH_OK, MH_ERR_CORRUPT,
+ * MH_ERR_TIMEOUT, MH_ERR_CAPACITY). */
+int mh_dev_status(const void *d_ws, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

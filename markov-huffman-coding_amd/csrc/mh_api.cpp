@@ -1,0 +1,413 @@
+// mh_api.cpp — the C ABI of include/mh.h on top of the HIP kernels.  No CPU compute fallback: every
+// compute entry point needs a device and returns MH_ERR_NO_DEVICE without one.
+#include "../../include/mh.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "mh_kernels.h"
+#include "mh_model.hpp"
+
+struct mh_model {
+    mh::Model host;
+    mh::Model::Packed packed;
+    int device = -1;
+    // device images (owned)
+    uint16_t *d_enc16 = nullptr;
+    uint8_t *d_len8 = nullptr;
+    uint64_t *d_code64 = nullptr;
+    uint16_t *d_dec16 = nullptr;
+    uint32_t *d_tree = nullptr;
+};
+
+namespace {
+
+thread_local int g_last_hip = 0;
+
+int hip_fail(hipError_t e) {
+    g_last_hip = int(e);
+    return (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver) ? MH_ERR_NO_DEVICE : MH_ERR_HIP;
+}
+
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t _e = (expr);                         \
+        if (_e != hipSuccess) return hip_fail(_e);      \
+    } while (0)
+
+bool have_device() {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess && n > 0;
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int chunk_shift_of(uint32_t chunk_symbols) {
+    if (chunk_symbols < MH_CHUNK_MIN || chunk_symbols > MH_CHUNK_MAX) return -1;
+    if (chunk_symbols & (chunk_symbols - 1)) return -1;
+    int s = 0;
+    while ((1u << s) != chunk_symbols) ++s;
+    return s;
+}
+
+int status_from_device(int s) {
+    switch (s) {
+        case mhk::MHK_STATUS_OK: return MH_OK;
+        case mhk::MHK_STATUS_TIMEOUT: return MH_ERR_TIMEOUT;
+        case mhk::MHK_STATUS_CAPACITY: return MH_ERR_CAPACITY;
+        default: return MH_ERR_CORRUPT;
+    }
+}
+
+// RAII device buffer for the host-buffer convenience calls
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    template <typename T> T *as() { return static_cast<T *>(p); }
+};
+
+// Host tables are always built; the device images are uploaded when a device exists.  Without one the
+// model still answers table queries (mh_model_write_table, mh_model_get_code, ...) but every
+// compute call on it returns MH_ERR_NO_DEVICE.
+int upload_model(mh_model *m) {
+    m->packed = m->host.pack();
+    if (!have_device()) return MH_OK;
+    if (m->packed.max_len > mh::MAX_CODE_BITS) return MH_OK;   // compute calls report MH_ERR_CODE_TOO_LONG
+    HIP_TRY(hipGetDevice(&m->device));
+    const mh::Model::Packed &pk = m->packed;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_enc16), 65536 * 2));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_len8), 65536));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_code64), 65536 * 8));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_dec16), 65536 * 2));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_tree), 256 * mh::TREE_STRIDE * 4));
+    HIP_TRY(hipMemcpy(m->d_enc16, pk.enc16.data(), 65536 * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(m->d_len8, pk.len8.data(), 65536, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(m->d_code64, pk.code64.data(), 65536 * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(m->d_dec16, pk.dec16.data(), 65536 * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(m->d_tree, pk.tree.data(), 256 * mh::TREE_STRIDE * 4, hipMemcpyHostToDevice));
+    return MH_OK;
+}
+
+int finish_model(mh_model *m, mh_model **out) {
+    int rc = upload_model(m);
+    if (rc != MH_OK) { mh_model_free(m); return rc; }
+    *out = m;
+    return MH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mh_strerror(int status) {
+    switch (status) {
+        case MH_OK: return "ok";
+        case MH_ERR_ARG: return "invalid argument";
+        case MH_ERR_NO_DEVICE: return "no usable HIP device (the codec has no CPU fallback)";
+        case MH_ERR_HIP: return "HIP runtime error";
+        case MH_ERR_CORRUPT: return "Input appears corrupt";
+        case MH_ERR_TYPE: return "File encoding method does not match provided encoding table";
+        case MH_ERR_BADTABLE: return "encoding table not parseable";
+        case MH_ERR_CODE_TOO_LONG: return "codeword longer than 64 bits";
+        case MH_ERR_CAPACITY: return "output buffer or workspace too small";
+        case MH_ERR_TIMEOUT: return "device-side wait expired";
+        case MH_ERR_NOMEM: return "out of memory";
+        default: return "unknown error";
+    }
+}
+
+int mh_last_hip_error(void) { return g_last_hip; }
+
+int mh_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int mh_set_device(int ordinal) {
+    HIP_TRY(hipSetDevice(ordinal));
+    return MH_OK;
+}
+
+/* ---------------------------------------------------------------- model */
+
+int mh_model_from_counts(const uint64_t *counts, int order, mh_model **out) {
+    if (!counts || !out || (order != 0 && order != 1)) return MH_ERR_ARG;
+    mh_model *m = new (std::nothrow) mh_model;
+    if (!m) return MH_ERR_NOMEM;
+    m->host.build_from_counts(counts, order);
+    return finish_model(m, out);
+}
+
+int mh_dev_model_from_counts(const uint64_t *d_counts, int order, void *stream, mh_model **out) {
+    if (!d_counts || !out || (order != 0 && order != 1)) return MH_ERR_ARG;
+    if (!have_device()) return MH_ERR_NO_DEVICE;
+    size_t ncount = order ? 65536 : 256;
+    std::vector<uint64_t> counts(ncount);
+    HIP_TRY(hipMemcpyAsync(counts.data(), d_counts, ncount * 8, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return mh_model_from_counts(counts.data(), order, out);
+}
+
+int mh_model_from_table_bits(const uint8_t *bytes, size_t n, mh_model **out) {
+    if ((!bytes && n) || !out) return MH_ERR_ARG;
+    mh_model *m = new (std::nothrow) mh_model;
+    if (!m) return MH_ERR_NOMEM;
+    if (!m->host.load_table(bytes, n)) { delete m; return MH_ERR_BADTABLE; }
+    return finish_model(m, out);
+}
+
+int mh_model_write_table(const mh_model *m, uint8_t *out, size_t cap, size_t *nbytes) {
+    if (!m || !nbytes) return MH_ERR_ARG;
+    std::vector<uint8_t> t = m->host.save_table();
+    *nbytes = t.size();
+    if (!out) return MH_OK;
+    if (cap < t.size()) return MH_ERR_CAPACITY;
+    if (!t.empty()) std::memcpy(out, t.data(), t.size());
+    return MH_OK;
+}
+
+int mh_model_type(const mh_model *m) { return m ? m->host.type : MH_ERR_ARG; }
+
+int mh_model_max_code_len(const mh_model *m) { return m ? m->packed.max_len : MH_ERR_ARG; }
+
+int mh_model_get_code(const mh_model *m, int prev, int sym, int *len, uint64_t *code) {
+    if (!m || !len || !code) return MH_ERR_ARG;
+    const mh::Code &c = m->host.context(prev).code(sym);
+    *len = c.len;
+    *code = c.len <= 64 ? c.right_aligned() : 0;
+    return MH_OK;
+}
+
+int mh_model_get_lut(const mh_model *m, int prev, int w, int *present, int *is_internal, int *value, int *depth) {
+    if (!m || !present || !is_internal || !value || !depth) return MH_ERR_ARG;
+    const mh::ContextCoder &c = m->host.context(prev);
+    int n = c.lut(w);
+    *present = n >= 0;
+    *is_internal = *value = *depth = 0;
+    if (n >= 0) {
+        *is_internal = !c.node(n).leaf;
+        *value = c.node(n).sym;
+        *depth = c.node(n).depth;
+    }
+    return MH_OK;
+}
+
+void mh_model_free(mh_model *m) {
+    if (!m) return;
+    if (m->d_enc16) (void)hipFree(m->d_enc16);
+    if (m->d_len8) (void)hipFree(m->d_len8);
+    if (m->d_code64) (void)hipFree(m->d_code64);
+    if (m->d_dec16) (void)hipFree(m->d_dec16);
+    if (m->d_tree) (void)hipFree(m->d_tree);
+    delete m;
+}
+
+/* ------------------------------------------------------------ device calls */
+
+size_t mh_dev_histogram_workspace(size_t) { return 64; }
+
+int mh_dev_histogram_o1(const uint8_t *d_data, size_t n, uint8_t prev0, uint64_t *d_counts, void *, size_t, void *stream) {
+    if ((!d_data && n) || !d_counts || !aligned16(d_data)) return MH_ERR_ARG;
+    HIP_TRY(mhk::launch_hist_o1(d_data, n, prev0, reinterpret_cast<unsigned long long *>(d_counts), static_cast<hipStream_t>(stream)));
+    return MH_OK;
+}
+
+int mh_dev_histogram_o0(const uint8_t *d_data, size_t n, uint64_t *d_counts, void *, size_t, void *stream) {
+    if ((!d_data && n) || !d_counts || !aligned16(d_data)) return MH_ERR_ARG;
+    HIP_TRY(mhk::launch_hist_o0(d_data, n, reinterpret_cast<unsigned long long *>(d_counts), static_cast<hipStream_t>(stream)));
+    return MH_OK;
+}
+
+size_t mh_dev_encode_workspace(size_t n) { return mhk::encode_workspace_bytes(n); }
+
+int mh_dev_encode(const mh_model *m, const uint8_t *d_data, size_t n, uint8_t prev0, uint8_t *d_payload, size_t cap,
+                  uint64_t *d_nbits, uint64_t *d_index, uint32_t chunk_symbols, void *d_ws, size_t ws_bytes, void *stream) {
+    if (!m || (!d_data && n) || !d_payload || !d_nbits || !d_ws) return MH_ERR_ARG;
+    if (!aligned16(d_data) || !aligned16(d_payload) || !aligned16(d_ws)) return MH_ERR_ARG;
+    int shift = chunk_shift_of(d_index ? chunk_symbols : MH_CHUNK_DEFAULT);
+    if (shift < 0) return MH_ERR_ARG;
+    if (ws_bytes < mhk::encode_workspace_bytes(n)) return MH_ERR_CAPACITY;
+    if (m->packed.max_len > mh::MAX_CODE_BITS) return MH_ERR_CODE_TOO_LONG;
+    if (!m->d_enc16) return MH_ERR_NO_DEVICE;
+    mhk::EncParams p{};
+    p.data = d_data; p.n = n; p.prev0 = prev0; p.chunk_shift = uint32_t(shift);
+    p.out = d_payload; p.cap = cap;
+    p.enc16 = m->d_enc16; p.len8 = m->d_len8; p.code64 = m->d_code64;
+    p.nbits = reinterpret_cast<unsigned long long *>(d_nbits);
+    p.index = reinterpret_cast<unsigned long long *>(d_index);
+    p.seed = 0;
+    HIP_TRY(mhk::launch_encode(p, d_ws, static_cast<hipStream_t>(stream)));
+    return MH_OK;
+}
+
+size_t mh_dev_decode_workspace(uint64_t, uint64_t, uint32_t) { return 64; }
+
+int mh_dev_decode(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, uint8_t *d_out, uint64_t n_symbols,
+                  const uint64_t *d_index, uint32_t chunk_symbols, void *d_ws, size_t ws_bytes, void *stream) {
+    if (!m || !d_ws || ws_bytes < 64) return MH_ERR_ARG;
+    if (n_symbols && (!d_payload || !d_out || !d_index)) return MH_ERR_ARG;
+    if (!aligned16(d_payload) || !aligned16(d_out)) return MH_ERR_ARG;
+    int shift = chunk_shift_of(chunk_symbols);
+    if (shift < 0) return MH_ERR_ARG;
+    if (m->packed.max_len > mh::MAX_CODE_BITS) return MH_ERR_CODE_TOO_LONG;
+    if (!m->d_dec16) return MH_ERR_NO_DEVICE;
+    mhk::DecParams p{};
+    p.payload = d_payload; p.payload_bytes = (nbits + 7) / 8; p.nbits = nbits;
+    p.out = d_out; p.n = n_symbols;
+    p.index = reinterpret_cast<const unsigned long long *>(d_index);
+    p.nchunks = mh_index_entries(n_symbols, chunk_symbols);
+    p.chunk_shift = uint32_t(shift);
+    p.dec16 = m->d_dec16; p.tree = m->d_tree;
+    HIP_TRY(mhk::launch_decode(p, d_ws, static_cast<hipStream_t>(stream)));
+    return MH_OK;
+}
+
+int mh_dev_build_index(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, uint8_t prev0, uint64_t *d_index,
+                       uint64_t index_cap, uint32_t chunk_symbols, uint64_t *d_n_symbols, void *d_ws, size_t ws_bytes, void *stream) {
+    if (!m || !d_index || !d_n_symbols || !d_ws || ws_bytes < 64 || (!d_payload && nbits)) return MH_ERR_ARG;
+    int shift = chunk_shift_of(chunk_symbols);
+    if (shift < 0 || !aligned16(d_payload)) return MH_ERR_ARG;
+    if (m->packed.max_len > mh::MAX_CODE_BITS) return MH_ERR_CODE_TOO_LONG;
+    if (!m->d_dec16) return MH_ERR_NO_DEVICE;
+    mhk::IdxParams p{};
+    p.payload = d_payload; p.payload_bytes = (nbits + 7) / 8; p.nbits = nbits;
+    p.prev0 = prev0; p.chunk_shift = uint32_t(shift);
+    p.index = reinterpret_cast<unsigned long long *>(d_index); p.index_cap = index_cap;
+    p.n_symbols = reinterpret_cast<unsigned long long *>(d_n_symbols);
+    p.dec16 = m->d_dec16; p.tree = m->d_tree;
+    HIP_TRY(mhk::launch_build_index(p, d_ws, static_cast<hipStream_t>(stream)));
+    return MH_OK;
+}
+
+int mh_dev_status(const void *d_ws, void *stream) {
+    if (!d_ws) return MH_ERR_ARG;
+    int s = 0;
+    HIP_TRY(hipMemcpyAsync(&s, d_ws, sizeof s, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return status_from_device(s);
+}
+
+/* ------------------------------------------------------- host-buffer calls */
+
+static int histogram_host(const uint8_t *data, size_t n, uint8_t prev0, uint64_t *counts, int order) {
+    if ((!data && n) || !counts) return MH_ERR_ARG;
+    if (!have_device()) return MH_ERR_NO_DEVICE;
+    size_t nc = order ? 65536 : 256;
+    DevBuf d_data, d_counts;
+    HIP_TRY(d_data.alloc(n));
+    HIP_TRY(d_counts.alloc(nc * 8));
+    if (n) HIP_TRY(hipMemcpy(d_data.p, data, n, hipMemcpyHostToDevice));
+    int rc = order ? mh_dev_histogram_o1(d_data.as<uint8_t>(), n, prev0, d_counts.as<uint64_t>(), nullptr, 0, nullptr)
+                   : mh_dev_histogram_o0(d_data.as<uint8_t>(), n, d_counts.as<uint64_t>(), nullptr, 0, nullptr);
+    if (rc != MH_OK) return rc;
+    HIP_TRY(hipMemcpy(counts, d_counts.p, nc * 8, hipMemcpyDeviceToHost));
+    return MH_OK;
+}
+
+int mh_histogram_o1(const uint8_t *data, size_t n, uint8_t prev0, uint64_t *counts) {
+    return histogram_host(data, n, prev0, counts, 1);
+}
+
+int mh_histogram_o0(const uint8_t *data, size_t n, uint64_t *counts) { return histogram_host(data, n, 0, counts, 0); }
+
+size_t mh_encode_bound(const mh_model *m, size_t n) {
+    size_t maxlen = m ? size_t(m->packed.max_len) : 64;
+    if (maxlen < 1) maxlen = 1;
+    return (n * maxlen + 7) / 8 + 16;
+}
+
+uint8_t mh_stream_header(const mh_model *m, uint64_t nbits) {
+    int type = m ? m->host.type : 1;
+    int bi = int(nbits & 7u);
+    return uint8_t(0x30 | ((~type & 1) << 3) | ((8 - bi) % 8));   // src/coding.cpp:88
+}
+
+int mh_stream_parse_header(const mh_model *m, uint8_t header, uint64_t file_bytes, uint64_t *nbits) {
+    if (!m || !nbits || file_bytes < 1) return MH_ERR_ARG;
+    if ((header & 0xF0) != 0x30) return MH_ERR_CORRUPT;                         // src/coding.cpp:103-106
+    if (((~(header & (1 << 3)) >> 3) & 1) != m->host.type) return MH_ERR_TYPE;  // src/coding.cpp:107-110
+    uint64_t total = (file_bytes - 1) * 8;
+    uint64_t rem = header & 7u;                                                 // src/coding.cpp:111-115
+    if (rem > total) return MH_ERR_CORRUPT;
+    *nbits = total - rem;
+    return MH_OK;
+}
+
+int mh_encode(const mh_model *m, const uint8_t *data, size_t n, uint8_t prev0, uint8_t *out_payload, size_t cap,
+              uint64_t *nbits, uint64_t *index, uint32_t chunk_symbols) {
+    if (!m || (!data && n) || !nbits || (!out_payload && cap)) return MH_ERR_ARG;
+    if (index && chunk_shift_of(chunk_symbols) < 0) return MH_ERR_ARG;
+    if (!have_device()) return MH_ERR_NO_DEVICE;
+    if (m->packed.max_len > mh::MAX_CODE_BITS) return MH_ERR_CODE_TOO_LONG;
+    hipStream_t st = nullptr;
+    size_t dcap = mh_encode_bound(m, n);
+    size_t nidx = index ? size_t(mh_index_entries(n, chunk_symbols)) : 0;
+    size_t wsb = mh_dev_encode_workspace(n);
+    DevBuf d_data, d_out, d_nbits, d_index, d_ws;
+    HIP_TRY(d_data.alloc(n));
+    HIP_TRY(d_out.alloc(dcap));
+    HIP_TRY(d_nbits.alloc(8));
+    HIP_TRY(d_index.alloc(nidx * 8));
+    HIP_TRY(d_ws.alloc(wsb));
+    if (n) HIP_TRY(hipMemcpy(d_data.p, data, n, hipMemcpyHostToDevice));
+    int rc = mh_dev_encode(m, d_data.as<uint8_t>(), n, prev0, d_out.as<uint8_t>(), dcap, d_nbits.as<uint64_t>(),
+                           index ? d_index.as<uint64_t>() : nullptr, chunk_symbols, d_ws.p, wsb, st);
+    if (rc != MH_OK) return rc;
+    rc = mh_dev_status(d_ws.p, st);
+    if (rc != MH_OK) return rc;
+    HIP_TRY(hipMemcpy(nbits, d_nbits.p, 8, hipMemcpyDeviceToHost));
+    size_t nbytes = size_t((*nbits + 7) / 8);
+    if (nbytes > cap) return MH_ERR_CAPACITY;
+    if (nbytes) HIP_TRY(hipMemcpy(out_payload, d_out.p, nbytes, hipMemcpyDeviceToHost));
+    if (nidx) HIP_TRY(hipMemcpy(index, d_index.p, nidx * 8, hipMemcpyDeviceToHost));
+    return MH_OK;
+}
+
+int mh_decode(const mh_model *m, const uint8_t *payload, uint64_t nbits, uint8_t prev0, uint8_t *out, size_t cap,
+              size_t *nbytes, const uint64_t *index, uint32_t chunk_symbols, uint64_t n_symbols) {
+    if (!m || (!payload && nbits) || !nbytes || (!out && cap)) return MH_ERR_ARG;
+    if (!have_device()) return MH_ERR_NO_DEVICE;
+    if (!index) chunk_symbols = MH_CHUNK_DEFAULT;
+    if (chunk_shift_of(chunk_symbols) < 0) return MH_ERR_ARG;
+    hipStream_t st = nullptr;
+    size_t pbytes = size_t((nbits + 7) / 8);
+    DevBuf d_payload, d_index, d_ws, d_nsym, d_out;
+    HIP_TRY(d_payload.alloc(pbytes));
+    HIP_TRY(d_ws.alloc(64));
+    if (pbytes) HIP_TRY(hipMemcpy(d_payload.p, payload, pbytes, hipMemcpyHostToDevice));
+    size_t nidx;
+    if (index) {
+        nidx = size_t(mh_index_entries(n_symbols, chunk_symbols));
+        HIP_TRY(d_index.alloc(nidx * 8));
+        if (nidx) HIP_TRY(hipMemcpy(d_index.p, index, nidx * 8, hipMemcpyHostToDevice));
+    } else {
+        // every code is at least one bit: the stream holds at most nbits symbols
+        uint64_t idx_cap = nbits / chunk_symbols + 2;
+        HIP_TRY(d_index.alloc(size_t(idx_cap) * 8));
+        HIP_TRY(d_nsym.alloc(8));
+        int rc = mh_dev_build_index(m, d_payload.as<uint8_t>(), nbits, prev0, d_index.as<uint64_t>(), idx_cap, chunk_symbols,
+                                    d_nsym.as<uint64_t>(), d_ws.p, 64, st);
+        if (rc != MH_OK) return rc;
+        rc = mh_dev_status(d_ws.p, st);
+        if (rc != MH_OK) return rc;
+        HIP_TRY(hipMemcpy(&n_symbols, d_nsym.p, 8, hipMemcpyDeviceToHost));
+    }
+    *nbytes = size_t(n_symbols);
+    if (n_symbols > cap) return MH_ERR_CAPACITY;
+    HIP_TRY(d_out.alloc(size_t(n_symbols)));
+    int rc = mh_dev_decode(m, d_payload.as<uint8_t>(), nbits, d_out.as<uint8_t>(), n_symbols, d_index.as<uint64_t>(),
+                           chunk_symbols, d_ws.p, 64, st);
+    if (rc != MH_OK) return rc;
+    rc = mh_dev_status(d_ws.p, st);
+    if (rc != MH_OK) return rc;
+    if (n_symbols) HIP_TRY(hipMemcpy(out, d_out.p, size_t(n_symbols), hipMemcpyDeviceToHost));
+    return MH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,309 @@
+// mh_model.cpp — see mh_model.hpp.  Host-side, integer-only, deterministic.
+#include "mh_model.hpp"
+
+#include <algorithm>
+#include <utility>
+
+namespace mh {
+
+namespace {
+
+// Array binary min-heap keyed on weight ONLY, with the reference's comparison directions
+// (src/min_pq.tpp:29-52): swim while parent > child (strict), sink towards the right child only when
+// it is strictly smaller than the left, and stop when the chosen child is not strictly smaller.
+// These rules fix every tie and therefore every codeword.
+class TieExactHeap {
+public:
+    void push(int64_t key, int item) {
+        slots_.push_back({key, item});
+        size_t i = slots_.size() - 1;
+        while (i != 0) {
+            size_t parent = (i - 1) / 2;
+            if (!(slots_[parent].first > slots_[i].first)) break;
+            std::swap(slots_[parent], slots_[i]);
+            i = parent;
+        }
+    }
+    int pop() {
+        int top = slots_.front().second;
+        slots_.front() = slots_.back();
+        slots_.pop_back();
+        size_t i = 0, n = slots_.size();
+        for (;;) {
+            size_t l = 2 * i + 1, r = l + 1;
+            size_t pick = (r < n && slots_[r].first < slots_[l].first) ? r : l;
+            if (pick < n && slots_[pick].first < slots_[i].first) {
+                std::swap(slots_[pick], slots_[i]);
+                i = pick;
+            } else {
+                break;
+            }
+        }
+        return top;
+    }
+    size_t size() const { return slots_.size(); }
+
+private:
+    std::vector<std::pair<int64_t, int>> slots_;
+};
+
+inline void code_set_bit(Code &c, int pos, int v) {
+    uint64_t mask = 1ull << (63 - (pos & 63));
+    if (v) c.bits[pos >> 6] |= mask; else c.bits[pos >> 6] &= ~mask;
+}
+
+}  // namespace
+
+void ContextCoder::clear() {
+    nodes_.clear();
+    root_ = -1;
+    codes_.fill(Code{});
+    lut_.fill(-1);
+    max_len_ = 0;
+}
+
+int ContextCoder::add_leaf(uint8_t sym, int64_t w) {
+    Node n;
+    n.sym = sym; n.leaf = true; n.weight = w; n.height = 0;
+    nodes_.push_back(n);
+    return int(nodes_.size()) - 1;
+}
+
+int ContextCoder::add_inner(int l, int r) {
+    Node n;
+    n.child[0] = int16_t(l); n.child[1] = int16_t(r); n.leaf = false;
+    n.weight = nodes_[l].weight + nodes_[r].weight;                    // src/tree.h:20
+    n.height = std::max(nodes_[l].height, nodes_[r].height) + 1;       // src/tree.h:21
+    nodes_.push_back(n);
+    return int(nodes_.size()) - 1;
+}
+
+void ContextCoder::build_from_counts(const uint64_t *counts) {
+    clear();
+    TieExactHeap heap;
+    for (int s = 0; s < 256; ++s)                                      // src/huffman.cpp:134-138
+        if (counts[s]) heap.push(int64_t(counts[s]), add_leaf(uint8_t(s), int64_t(counts[s])));
+    if (heap.size() == 0) return;                                      // :140-142 empty context
+    while (heap.size() > 1) {                                          // :143-151
+        int a = heap.pop();
+        int b = heap.pop();
+        if (nodes_[a].height > nodes_[b].height) std::swap(a, b);      // :147-149
+        int merged = add_inner(a, b);
+        heap.push(nodes_[merged].weight, merged);
+    }
+    root_ = heap.pop();
+    if (nodes_[root_].leaf) {                                          // :154-162 one-symbol context
+        uint8_t s = nodes_[root_].sym;
+        int64_t w = nodes_[root_].weight;
+        int l = add_leaf(s, w), r = add_leaf(s, w);
+        Node &rt = nodes_[root_];
+        rt.child[0] = int16_t(l); rt.child[1] = int16_t(r);
+        rt.leaf = false; rt.height = 1;
+    }
+    derive_tables();
+}
+
+// Iterative DFS, left (bit 0) before right (bit 1) — src/huffman.cpp:97-123.  A later leaf with the
+// same symbol overwrites the earlier code (:115), which is what makes the one-symbol code "1".
+void ContextCoder::derive_tables() {
+    codes_.fill(Code{});
+    lut_.fill(-1);
+    max_len_ = 0;
+    if (root_ < 0) return;
+    struct Frame { int node; int depth; Code path; };
+    std::vector<Frame> stack;
+    stack.push_back({root_, 0, Code{}});
+    while (!stack.empty()) {
+        Frame f = stack.back();
+        stack.pop_back();
+        Node &n = nodes_[f.node];
+        n.depth = f.depth;
+        if (!n.leaf) {
+            if (f.depth == 8) lut_[int(f.path.bits[0] >> 56)] = f.node;          // :111-113
+            if (f.depth >= 255) continue;
+            Frame right{n.child[1], f.depth + 1, f.path};
+            code_set_bit(right.path, f.depth, 1);
+            Frame left{n.child[0], f.depth + 1, f.path};
+            stack.push_back(right);   // popped second
+            stack.push_back(left);    // popped first: left subtree is visited before right
+        } else {
+            Code c = f.path;
+            c.len = f.depth;
+            codes_[n.sym] = c;
+            max_len_ = std::max(max_len_, f.depth);
+            if (f.depth >= 1 && f.depth <= 8) {                                   // :116-121
+                int base = int(f.path.bits[0] >> 56);
+                for (int i = 0; i < (1 << (8 - f.depth)); ++i) lut_[base + i] = f.node;
+            }
+        }
+    }
+    // max_len_ must reflect surviving codes only (a duplicate symbol may have been overwritten)
+    max_len_ = 0;
+    for (const Code &c : codes_) max_len_ = std::max(max_len_, c.len);
+}
+
+// Pre-order: inner -> 0, leaf -> 1 + 8-bit symbol (src/huffman.cpp:174-188).
+void ContextCoder::save(BitWriter &out) const {
+    if (root_ < 0) return;
+    std::vector<int> stack{root_};
+    while (!stack.empty()) {
+        int i = stack.back();
+        stack.pop_back();
+        const Node &n = nodes_[i];
+        if (n.leaf) {
+            out.bit(1);
+            out.byte(n.sym);
+        } else {
+            out.bit(0);
+            stack.push_back(n.child[1]);
+            stack.push_back(n.child[0]);
+        }
+    }
+}
+
+// src/huffman.cpp:166-172.  The first subtree in the stream is the LEFT child (the reference leaves
+// this to the compiler's argument evaluation order; g++ and clang agree — SURVEY §8c).
+bool ContextCoder::load(BitReader &in) {
+    clear();
+    // Iterative reconstruction: `open` holds inner nodes still waiting for children.
+    struct Open { int node; int filled; };
+    std::vector<Open> open;
+    int leaves = 0;
+    for (;;) {
+        if (in.failed()) { clear(); return false; }
+        int made;
+        if (in.bit()) {
+            int s = in.byte();
+            if (in.failed() || ++leaves > 257) { clear(); return false; }
+            made = add_leaf(uint8_t(s), 0);
+        } else {
+            Node n;
+            n.leaf = false;
+            nodes_.push_back(n);
+            made = int(nodes_.size()) - 1;
+            if (open.size() > 256) { clear(); return false; }
+        }
+        if (root_ < 0) root_ = made;
+        if (!open.empty()) {
+            Open &o = open.back();
+            nodes_[o.node].child[o.filled++] = int16_t(made);
+        }
+        if (!nodes_[made].leaf) open.push_back({made, 0});
+        while (!open.empty() && open.back().filled == 2) {
+            Node &n = nodes_[open.back().node];
+            n.height = std::max(nodes_[n.child[0]].height, nodes_[n.child[1]].height) + 1;
+            open.pop_back();
+        }
+        if (open.empty()) break;
+    }
+    if (in.failed() || nodes_[root_].leaf) { clear(); return false; }  // writer never emits a bare leaf
+    int inner = 0;
+    for (const Node &n : nodes_) inner += !n.leaf;
+    if (inner > TREE_STRIDE) { clear(); return false; }
+    derive_tables();
+    return true;
+}
+
+void ContextCoder::pack_decode(uint16_t *dec, uint32_t *tree) const {
+    for (int i = 0; i < 256; ++i) dec[i] = 0;
+    for (int i = 0; i < TREE_STRIDE; ++i) tree[i] = 0;
+    if (root_ < 0) return;
+    // number inner nodes in visiting order, root = 0
+    std::vector<int> id(nodes_.size(), -1);
+    int next = 0;
+    for (size_t i = 0; i < nodes_.size(); ++i)
+        if (!nodes_[i].leaf) id[i] = (int(i) == root_) ? 0 : -2;
+    next = 1;
+    for (size_t i = 0; i < nodes_.size(); ++i)
+        if (id[i] == -2) id[i] = next++;
+    auto enc_child = [&](int c) -> uint32_t {
+        return nodes_[c].leaf ? (TREE_LEAF | nodes_[c].sym) : uint32_t(id[c]);
+    };
+    for (size_t i = 0; i < nodes_.size(); ++i)
+        if (!nodes_[i].leaf)
+            tree[id[i]] = (enc_child(nodes_[i].child[1]) << 16) | enc_child(nodes_[i].child[0]);
+    for (int w = 0; w < 256; ++w) {
+        int n = lut_[w];
+        if (n < 0) continue;
+        dec[w] = nodes_[n].leaf ? uint16_t((nodes_[n].depth << 8) | nodes_[n].sym)
+                                : uint16_t(DEC16_INNER | id[n]);
+    }
+}
+
+int Model::max_code_len() const {
+    int m = 0;
+    for (const ContextCoder &c : ctx) m = std::max(m, c.max_len());
+    return m;
+}
+
+void Model::build_from_counts(const uint64_t *counts, int order) {
+    type = order ? 1 : 0;
+    ctx.assign(order ? 256 : 1, ContextCoder{});
+    for (size_t i = 0; i < ctx.size(); ++i) ctx[i].build_from_counts(counts + 256 * i);  // src/markov_huffman.cpp:10-12
+}
+
+bool Model::load_table(const uint8_t *bytes, size_t n) {
+    BitReader in(bytes, n);
+    // src/main.cpp:147-161: a Huffman tree file starts with 0 (its root), a Markov file with 1.
+    int first = n ? ((bytes[0] >> 7) & 1) : 0;
+    if (!first) {
+        type = 0;
+        ctx.assign(1, ContextCoder{});
+        return n > 0 && ctx[0].load(in);
+    }
+    type = 1;
+    ctx.assign(256, ContextCoder{});
+    in.bit();                                                       // src/markov_huffman.cpp:17
+    for (int p = 0; p < 256; ++p) {                                 // :19-24
+        if (in.bit()) {
+            if (!ctx[p].load(in)) return false;
+        }
+        if (in.failed()) return false;
+    }
+    return true;
+}
+
+std::vector<uint8_t> Model::save_table() const {
+    BitWriter out;
+    if (type == 0) {
+        ctx[0].save(out);                                           // src/huffman.cpp:83-85
+    } else {
+        out.bit(1);                                                 // src/markov_huffman.cpp:81
+        for (int p = 0; p < 256; ++p) {                             // :82-87
+            out.bit(!ctx[p].empty());
+            ctx[p].save(out);
+        }
+    }
+    return out.bytes();
+}
+
+Model::Packed Model::pack() const {
+    Packed pk;
+    pk.enc16.assign(65536, 0);
+    pk.len8.assign(65536, 0);
+    pk.code64.assign(65536, 0);
+    pk.dec16.assign(65536, 0);
+    pk.tree.assign(256 * TREE_STRIDE, 0);
+    pk.max_len = max_code_len();
+    for (int prev = 0; prev < 256; ++prev) {
+        const ContextCoder &c = context(prev);
+        c.pack_decode(&pk.dec16[prev * 256], &pk.tree[prev * TREE_STRIDE]);
+        for (int sym = 0; sym < 256; ++sym) {
+            const Code &cd = c.code(sym);
+            uint32_t window = uint32_t(sym) << 8 | uint32_t(prev);
+            uint16_t e = 0;
+            if (cd.len > ENC16_MAX_LEN) {
+                e = ENC16_ESCAPE;
+                pk.any_escape = true;
+            } else if (cd.len > 0) {
+                e = uint16_t((cd.len << 12) | uint32_t(cd.right_aligned()));
+            }
+            pk.enc16[enc_slot(window)] = e;
+            pk.len8[prev * 256 + sym] = uint8_t(std::min(cd.len, 255));
+            pk.code64[prev * 256 + sym] = cd.len <= 64 ? cd.right_aligned() : 0;
+        }
+    }
+    return pk;
+}
+
+}  // namespace mh

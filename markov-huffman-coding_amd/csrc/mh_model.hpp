@@ -1,0 +1,143 @@
+// mh_model.hpp — host-side model of the Markov-Huffman codec: per-context Huffman trees with the
+// reference's exact tie-breaking, code tables, decode LUTs, table-file (de)serialisation, and the
+// packed images the HIP kernels consume.  Product code (no dependency on oracle/).
+//
+// Reference behaviour restated here (file:line into jeremy-rifkin/Markov-Huffman-Coding):
+//   tree build        src/huffman.cpp:131-164, src/min_pq.tpp:4-52, src/tree.h:19-23
+//   codes + LUT       src/huffman.cpp:91-123
+//   table file        src/huffman.cpp:166-188, src/markov_huffman.cpp:15-25,80-88
+#pragma once
+
+#include <array>
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+namespace mh {
+
+// ---- device table formats (shared with mh_kernels.hip) ------------------------------------------
+
+// Encode table, LDS-resident: 65536 x u16, entry = len(4) << 12 | code(12) for len <= 12,
+// 0 = "no code" (symbol skipped, src/coding.cpp:72 under NDEBUG), ENC16_ESCAPE = look the
+// codeword up in the full (len8, code64) tables in HBM/L2.
+// Index = enc_slot(window) where window = sym << 8 | prev is the raw little-endian 16-bit field
+// read straight out of the byte stream; the XOR folds the symbol into the bank-selecting low bits.
+constexpr uint16_t ENC16_ESCAPE = 0xFFFF;
+constexpr int ENC16_MAX_LEN = 12;
+constexpr uint32_t enc_slot(uint32_t window) { return (window ^ (window >> 8)) & 0xFFFFu; }
+
+// Decode LUT, LDS-resident: 65536 x u16 indexed prev << 8 | next-8-stream-bits.
+//   0                      null (empty context)
+//   leaf   : len(1..8) << 8 | symbol
+//   inner  : 0x8000 | internal-node id (node stored at depth 8, src/huffman.cpp:111-113)
+constexpr uint16_t DEC16_INNER = 0x8000;
+// Fallback tree in HBM/L2: per context 256 x u32 = right << 16 | left; a child is
+// 0x8000 | symbol for a leaf, else the internal-node id (0 = root).
+constexpr uint32_t TREE_LEAF = 0x8000;
+constexpr int TREE_STRIDE = 256;
+
+constexpr int MAX_CODE_BITS = 64;  // device path limit (MH_ERR_CODE_TOO_LONG beyond)
+
+struct Code {
+    int len = 0;                       // bits; 0 = no code
+    std::array<uint64_t, 4> bits{};    // MSB-first: bit i of the code is bit (63 - i % 64) of bits[i / 64]
+    uint64_t right_aligned() const {   // valid for len <= 64
+        return len == 0 ? 0 : (len >= 64 ? bits[0] : bits[0] >> (64 - len));
+    }
+};
+
+struct Node {
+    int16_t child[2] = {-1, -1};  // -1 on a leaf
+    uint8_t sym = 0;
+    bool leaf = true;
+    int64_t weight = 0;
+    int height = 0;
+    int depth = -1;
+};
+
+class BitReader;
+class BitWriter;
+
+// One context = one Huffman table (huffman_table in the reference).
+class ContextCoder {
+public:
+    void clear();
+    bool empty() const { return root_ < 0; }
+    void build_from_counts(const uint64_t *counts256);
+    bool load(BitReader &in);          // reads one serialized tree; false on a malformed stream
+    void save(BitWriter &out) const;
+    const Code &code(int sym) const { return codes_[sym & 255]; }
+    int lut(int w) const { return lut_[w & 255]; }   // node index or -1
+    const Node &node(int i) const { return nodes_[i]; }
+    int root() const { return root_; }
+    int max_len() const { return max_len_; }
+    // packed device images for this context
+    void pack_decode(uint16_t *dec256, uint32_t *tree256) const;
+
+private:
+    void derive_tables();
+    int add_leaf(uint8_t sym, int64_t w);
+    int add_inner(int l, int r);
+    std::vector<Node> nodes_;
+    int root_ = -1;
+    std::array<Code, 256> codes_{};
+    std::array<int, 256> lut_{};
+    int max_len_ = 0;
+};
+
+class BitReader {
+public:
+    BitReader(const uint8_t *p, size_t nbytes) : p_(p), nbits_(nbytes * 8) {}
+    int bit() {
+        if (pos_ >= nbits_) { fail_ = true; return 0; }
+        int v = (p_[pos_ >> 3] >> (7 - (pos_ & 7))) & 1;
+        ++pos_;
+        return v;
+    }
+    int byte() { int v = 0; for (int i = 0; i < 8; ++i) v = (v << 1) | bit(); return v; }
+    bool failed() const { return fail_; }
+private:
+    const uint8_t *p_;
+    size_t nbits_, pos_ = 0;
+    bool fail_ = false;
+};
+
+class BitWriter {
+public:
+    void bit(int v) {
+        if ((nbits_ & 7) == 0) buf_.push_back(0);
+        if (v) buf_.back() |= uint8_t(1u << (7 - (nbits_ & 7)));
+        ++nbits_;
+    }
+    void byte(int v) { for (int i = 7; i >= 0; --i) bit((v >> i) & 1); }
+    const std::vector<uint8_t> &bytes() const { return buf_; }  // zero padded to a byte
+private:
+    std::vector<uint8_t> buf_;
+    size_t nbits_ = 0;
+};
+
+// Whole model: 1 context (simple Huffman, type 0) or 256 (Markov-Huffman, type 1).
+class Model {
+public:
+    int type = 1;
+    std::vector<ContextCoder> ctx;      // size 1 or 256
+    const ContextCoder &context(int prev) const { return type ? ctx[prev & 255] : ctx[0]; }
+    int max_code_len() const;
+    void build_from_counts(const uint64_t *counts, int order);
+    bool load_table(const uint8_t *bytes, size_t n);
+    std::vector<uint8_t> save_table() const;
+
+    // Packed images (always 256 contexts; a type-0 model replicates its single table).
+    struct Packed {
+        std::vector<uint16_t> enc16;     // 65536, slot order (enc_slot)
+        std::vector<uint8_t> len8;       // 65536, prev*256+sym
+        std::vector<uint64_t> code64;    // 65536, prev*256+sym, right aligned
+        std::vector<uint16_t> dec16;     // 65536, prev*256+w
+        std::vector<uint32_t> tree;      // 256*TREE_STRIDE
+        int max_len = 0;
+        bool any_escape = false;
+    };
+    Packed pack() const;
+};
+
+}  // namespace mh

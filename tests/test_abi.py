@@ -1,0 +1,129 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol include/mh.h
+declares, and its host logic (tree build with the reference's tie-breaks, code/LUT derivation, table
+files, stream header) agrees with the oracle and the golden vectors.  No compute call is made here
+unless it is to check that it refuses to run without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as entry
+from conftest import ROOT, check_against_golden, golden, golden_names
+
+
+@pytest.fixture(scope="module")
+def mhc():
+    entry.build()
+    return entry.load_package()
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "mh.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mh_[a-z0-9_]+)\s*\(", text)) - {"mh_index_entries"})
+
+
+def test_library_exports_every_declared_symbol(mhc):
+    lib = ctypes.CDLL(mhc.LIB_PATH)
+    declared = _declared_functions()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), "libmhc.so does not export %s" % name
+    assert sorted(mhc.EXPORTS) == declared
+
+
+def test_strerror_and_device_count(mhc):
+    assert mhc.lib().mh_strerror(0) == b"ok"
+    assert b"corrupt" in mhc.lib().mh_strerror(mhc.MH_ERR_CORRUPT)
+    assert mhc.device_count() >= 0
+
+
+@pytest.mark.parametrize("name", golden_names())
+@pytest.mark.parametrize("order", [0, 1])
+def test_host_model_matches_reference_tables(mhc, oracle, name, order):
+    """Tree build + table file: counts from the oracle's histogram, model from the product's host code."""
+    data = golden()[name]["data"]
+    counts = oracle.histogram_o1(data) if order else oracle.histogram_o0(data)
+    m = mhc.Model.from_counts(counts, order)
+    check_against_golden(name, "e" if order else "eh", m.table_bytes())
+    assert m.type == order
+
+
+@pytest.mark.parametrize("name", ["input_ipsum.txt", "input_wiki_cpp.html", "kat3", "kat4", "one_Z", "empty"])
+def test_host_codes_and_lut_match_oracle(mhc, oracle, name):
+    data = golden()[name]["data"]
+    counts = oracle.histogram_o1(data)
+    m = mhc.Model.from_counts(counts, 1)
+    o = oracle.Model.from_counts(counts, 1)
+    lm, cm = m.codes()
+    lo, co = o.codes()
+    assert np.array_equal(lm, lo)
+    assert np.array_equal(cm, co)
+    assert m.max_code_len == int(lo.max())
+    for prev in (0, 0x20, ord("e"), 255):
+        for w in range(0, 256, 3):
+            assert m.lut(prev, w) == o.lut(prev, w)
+
+
+@pytest.mark.parametrize("name", ["input_a.txt", "input_wiki_cpp.txt", "kat2", "nine_Z"])
+@pytest.mark.parametrize("order", [0, 1])
+def test_table_file_round_trip(mhc, oracle, name, order):
+    data = golden()[name]["data"]
+    counts = oracle.histogram_o1(data) if order else oracle.histogram_o0(data)
+    built = mhc.Model.from_counts(counts, order)
+    loaded = mhc.Model.from_table(built.table_bytes())
+    assert loaded.type == order
+    assert loaded.table_bytes() == built.table_bytes()
+    lb, cb = built.codes()
+    ll, cl = loaded.codes()
+    assert np.array_equal(lb, ll) and np.array_equal(cb, cl)
+
+
+def test_bad_table_is_rejected(mhc):
+    with pytest.raises(mhc.MhError) as e:
+        mhc.Model.from_table(b"\xff\xff\xff")          # Markov marker, then a truncated tree
+    assert e.value.status == mhc.MH_ERR_BADTABLE
+    with pytest.raises(mhc.MhError):
+        mhc.Model.from_table(b"")                      # no tree at all
+
+
+def test_stream_header_helpers(mhc, oracle):
+    """Header byte of src/coding.cpp:88 and its validation (src/coding.cpp:100-116)."""
+    data = golden()["input_b.txt"]["data"]
+    m1 = mhc.Model.from_counts(oracle.histogram_o1(data), 1)
+    m0 = mhc.Model.from_counts(oracle.histogram_o0(data), 0)
+    lib = mhc.lib()
+    assert lib.mh_stream_header(m1.handle, 10) == 0x36      # "36 f3 80": 10 payload bits, Markov
+    assert lib.mh_stream_header(m0.handle, 19) == 0x3D      # "3d 0a fb c0": 19 bits, Huffman
+    assert lib.mh_stream_header(m1.handle, 16) == 0x30
+    nb = ctypes.c_uint64()
+    assert lib.mh_stream_parse_header(m1.handle, 0x36, 3, ctypes.byref(nb)) == 0 and nb.value == 10
+    assert lib.mh_stream_parse_header(m1.handle, 0x3D, 4, ctypes.byref(nb)) == mhc.MH_ERR_TYPE
+    assert lib.mh_stream_parse_header(m0.handle, 0x3D, 4, ctypes.byref(nb)) == 0 and nb.value == 19
+    assert lib.mh_stream_parse_header(m1.handle, 0x80, 4, ctypes.byref(nb)) == mhc.MH_ERR_CORRUPT
+
+
+def test_argument_errors(mhc):
+    lib = mhc.lib()
+    h = ctypes.c_void_p()
+    assert lib.mh_model_from_counts(None, 1, ctypes.byref(h)) == mhc.MH_ERR_ARG
+    counts = np.zeros(65536, dtype=np.uint64)
+    assert lib.mh_model_from_counts(counts.ctypes.data, 2, ctypes.byref(h)) == mhc.MH_ERR_ARG
+
+
+def test_compute_refuses_without_gpu(mhc):
+    """No CPU fallback: without a device every compute call reports MH_ERR_NO_DEVICE."""
+    if mhc.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(mhc.MhError) as e:
+        mhc.histogram_o1(b"hello world")
+    assert e.value.status == mhc.MH_ERR_NO_DEVICE
+    m = mhc.Model.from_counts(np.ones(65536, dtype=np.uint64), 1)
+    with pytest.raises(mhc.MhError) as e:
+        m.encode(b"hello")
+    assert e.value.status == mhc.MH_ERR_NO_DEVICE
+    with pytest.raises(mhc.MhError) as e:
+        m.decode(b"\x00", 8)
+    assert e.value.status == mhc.MH_ERR_NO_DEVICE

@@ -1,0 +1,240 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against the
+CPU oracle on the same inputs and against the golden vectors made with the genuine reference.
+Integer/byte work: the bar is bit-exact everywhere."""
+import numpy as np
+import pytest
+
+import __graft_entry__ as entry
+from conftest import check_against_golden, golden, golden_names
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mhc():
+    mod = entry.load_package()
+    mod.lib()
+    assert mod.device_count() >= 1, "GPU tests need a device; the codec has no CPU fallback"
+    return mod
+
+
+def zipf_bytes(n, seed, s=1.1):
+    rng = np.random.default_rng(seed)
+    w = 1.0 / np.arange(1, 257) ** s
+    return rng.choice(256, size=n, p=w / w.sum()).astype(np.uint8).tobytes()
+
+
+def text_like(n, seed):
+    rng = np.random.default_rng(seed)
+    words = [b"lorem", b"ipsum", b"dolor", b"sit", b"amet", b"consectetur", b"adipiscing", b"elit", b"sed", b"do",
+             b"eiusmod", b"tempor", b"incididunt", b"ut", b"labore", b"et", b"dolore", b"magna", b"aliqua"]
+    out = bytearray()
+    while len(out) < n:
+        out += words[int(rng.integers(len(words)))] + (b". " if rng.random() < 0.1 else b" ")
+    return bytes(out[:n])
+
+
+# ------------------------------------------------------------------ histogram
+
+@pytest.mark.parametrize("name", golden_names())
+def test_histogram_matches_oracle_on_golden_inputs(mhc, oracle, name):
+    data = golden()[name]["data"]
+    assert np.array_equal(mhc.histogram_o1(data), oracle.histogram_o1(data))
+    assert np.array_equal(mhc.histogram_o0(data), oracle.histogram_o0(data))
+
+
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 31, 4095, 4096, 65537, 1 << 20, (1 << 22) + 5])
+def test_histogram_ragged_sizes(mhc, oracle, n):
+    data = zipf_bytes(n, n)
+    assert np.array_equal(mhc.histogram_o1(data), oracle.histogram_o1(data))
+    assert np.array_equal(mhc.histogram_o0(data), oracle.histogram_o0(data))
+
+
+def test_histogram_counter_overflow_path(mhc, oracle):
+    """One pair count far above 32768 exercises the packed 15-bit LDS counters' guard-bit fix-up."""
+    data = (b"\x00" * (3 << 20)) + zipf_bytes(1 << 20, 5) + (b"ab" * (1 << 20))
+    h = mhc.histogram_o1(data)
+    assert np.array_equal(h, oracle.histogram_o1(data))
+    assert h[0] > (3 << 20) - 2
+    assert np.array_equal(mhc.histogram_o0(data), oracle.histogram_o0(data))
+
+
+def test_histogram_prev0(mhc, oracle):
+    data = zipf_bytes(100000, 9)
+    for prev0 in (0, 0x20, 0xFF):
+        assert np.array_equal(mhc.histogram_o1(data, prev0), oracle.histogram_o1(data, prev0))
+
+
+# ------------------------------------------------------------------ encode
+
+@pytest.mark.parametrize("name", golden_names())
+def test_markov_stream_matches_reference_golden(mhc, name):
+    data = golden()[name]["data"]
+    m = mhc.Model.from_data(data, order=1)
+    blob, nbits, _ = m.compress(data)
+    check_against_golden(name, "cm", blob)
+    check_against_golden(name, "e", m.table_bytes())
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_huffman_stream_matches_reference_golden(mhc, name):
+    data = golden()[name]["data"]
+    m = mhc.Model.from_data(data, order=0)
+    blob, nbits, _ = m.compress(data)
+    check_against_golden(name, "ch", blob)
+    check_against_golden(name, "eh", m.table_bytes())
+
+
+@pytest.mark.parametrize("n", [1, 7, 8, 9, 63, 64, 511, 512, 8191, 8192, 8193, 16384, 100003, 8192 * 300 + 17])
+@pytest.mark.parametrize("kind", ["zipf", "text", "uniform"])
+def test_encode_matches_oracle_ragged(mhc, oracle, n, kind):
+    if kind == "zipf":
+        data = zipf_bytes(n, n + 1)
+    elif kind == "text":
+        data = text_like(n, n + 2)
+    else:
+        data = np.random.default_rng(n).integers(0, 256, n, dtype=np.uint8).tobytes()
+    m = mhc.Model.from_data(data, 1)
+    o = oracle.Model.from_data(data, 1)
+    assert m.table_bytes() == o.table_bytes()
+    blob, nbits, _ = m.compress(data)
+    ref, ref_bits = o.compress(data)
+    assert nbits == ref_bits
+    assert blob == ref
+
+
+def test_encode_with_loaded_table_and_missing_symbols(mhc, oracle):
+    """`-e table` path (src/main.cpp:137-161): symbols absent from the table are silently skipped
+    (src/coding.cpp:72 under NDEBUG); contexts absent from it too."""
+    train = text_like(50000, 1)
+    table = oracle.Model.from_data(train, 1).table_bytes()
+    data = text_like(30000, 2) + b"XYZ\x00\x01" * 50 + text_like(1000, 3)
+    m = mhc.Model.from_table(table)
+    o = oracle.Model.from_table(table)
+    blob, nbits, _ = m.compress(data)
+    ref, ref_bits = o.compress(data)
+    assert (nbits, blob) == (ref_bits, ref)
+
+
+def _skewed(n, seed, p=0.5):
+    """Geometric symbol distribution: Huffman codes grow to ~25 bits, far beyond the 12-bit LDS table."""
+    rng = np.random.default_rng(seed)
+    return np.minimum(rng.geometric(p, n) - 1, 255).astype(np.uint8).tobytes()
+
+
+def test_encode_long_codes_escape_path(mhc, oracle):
+    data = _skewed(1 << 20, 3)
+    m = mhc.Model.from_data(data, 1)
+    assert m.max_code_len > 12
+    o = oracle.Model.from_data(data, 1)
+    assert m.compress(data)[0] == o.compress(data)[0]
+    m0 = mhc.Model.from_data(data, 0)
+    assert m0.max_code_len > 12
+    assert m0.compress(data)[0] == oracle.Model.from_data(data, 0).compress(data)[0]
+
+
+def test_encode_multi_round_tiles(mhc, oracle):
+    """A table trained on skewed data, applied to data made of its RAREST symbols: almost every code is
+    an escape and tiles carry more bits than the LDS staging image holds (several rounds per tile)."""
+    train = _skewed(1 << 21, 11)
+    table = oracle.Model.from_data(train, 0).table_bytes()
+    o = oracle.Model.from_table(table)
+    lens, _ = o.codes()
+    present = [s for s in range(256) if lens[s] >= 14]
+    assert len(present) >= 4
+    rng = np.random.default_rng(4)
+    data = np.array(present, dtype=np.uint8)[rng.integers(0, len(present), 70000)].tobytes()
+    data = data + train[:5000] + data[:8192 * 2 + 3]
+    m = mhc.Model.from_table(table)
+    blob, nbits, idx = m.compress(data, chunk_symbols=256)
+    ref, ref_bits = o.compress(data)
+    assert nbits == ref_bits and nbits > 12 * len(data)
+    assert blob == ref
+    assert m.decompress(blob, index=idx, chunk_symbols=256, n_symbols=len(data)) == data
+
+
+# ------------------------------------------------------------------ decode
+
+@pytest.mark.parametrize("name", golden_names())
+@pytest.mark.parametrize("order", [0, 1])
+def test_round_trip_golden_inputs_with_index(mhc, name, order):
+    data = golden()[name]["data"]
+    if order == 0 and not data:
+        pytest.skip("empty -h table cannot be decoded (reference crashes, SURVEY §8c)")
+    m = mhc.Model.from_data(data, order)
+    blob, nbits, idx = m.compress(data, chunk_symbols=256)
+    assert m.decompress(blob, index=idx, chunk_symbols=256, n_symbols=len(data)) == data
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names() if n != "kat4"])
+@pytest.mark.parametrize("order", [0, 1])
+def test_decode_reference_stream_without_index(mhc, oracle, name, order):
+    """Drop-in case: the stream was produced by the reference (here: the oracle, pinned to it) and has
+    no index.  Table loaded from the reference's table file."""
+    data = golden()[name]["data"]
+    if order == 0 and not data:
+        pytest.skip("empty -h table")
+    o = oracle.Model.from_data(data, order)
+    blob, _ = o.compress(data)
+    m = mhc.Model.from_table(o.table_bytes())
+    assert m.decompress(blob) == data
+
+
+@pytest.mark.parametrize("chunk", [256, 1024, 8192])
+@pytest.mark.parametrize("n", [1, 255, 256, 257, 8192, 8193, 1 << 20, (1 << 21) + 77])
+def test_round_trip_chunk_sizes(mhc, oracle, n, chunk):
+    data = zipf_bytes(n, n + chunk)
+    m = mhc.Model.from_data(data, 1)
+    blob, nbits, idx = m.compress(data, chunk_symbols=chunk)
+    assert len(idx) == (n + chunk - 1) // chunk
+    assert m.decompress(blob, index=idx, chunk_symbols=chunk, n_symbols=n) == data
+    # the GPU stream also decodes on the oracle, and the index points at real code boundaries
+    assert oracle.Model.from_data(data, 1).decompress(blob) == data
+    assert int(idx[0]) == (0x20 << 56)
+
+
+def test_index_entries_are_exact(mhc, oracle):
+    """Each entry = (previous byte << 56) | bit offset of that chunk's first codeword."""
+    data = text_like(40000, 6)
+    chunk = 256
+    m = mhc.Model.from_data(data, 1)
+    _, nbits, idx = m.compress(data, chunk_symbols=chunk)
+    lens, _ = oracle.Model.from_data(data, 1).codes()
+    arr = np.frombuffer(data, dtype=np.uint8).astype(np.int64)
+    prev = np.concatenate([[0x20], arr[:-1]])
+    bitpos = np.concatenate([[0], np.cumsum(lens[prev * 256 + arr].astype(np.int64))])
+    assert bitpos[-1] == nbits
+    for c, e in enumerate(idx):
+        assert int(e) & mhc.INDEX_BIT_MASK == bitpos[c * chunk]
+        assert int(e) >> 56 == prev[c * chunk]
+
+
+def test_decode_errors(mhc, oracle):
+    data = golden()["input_a.txt"]["data"]
+    m = mhc.Model.from_data(data, 1)
+    h = mhc.Model.from_data(data, 0)
+    blob, _, _ = m.compress(data)
+    with pytest.raises(mhc.MhError) as e:
+        h.decompress(blob)
+    assert e.value.status == mhc.MH_ERR_TYPE
+    with pytest.raises(mhc.MhError) as e:
+        m.decompress(b"\x10" + blob[1:])
+    assert e.value.status == mhc.MH_ERR_CORRUPT
+    # a context that does not exist in the table -> null LUT entry -> corrupt
+    other = mhc.Model.from_data(b"qqqqqqqq", 1)
+    with pytest.raises(mhc.MhError) as e:
+        other.decode(b"\xff\xff", 16, prev0=0x41)
+    assert e.value.status == mhc.MH_ERR_CORRUPT
+
+
+def test_large_round_trip_property(mhc, oracle):
+    """64 MiB Zipf(1.1): stream identical to the oracle's, round trip exact, and the index lets any
+    slice of chunks be decoded on its own."""
+    n = 64 << 20
+    data = zipf_bytes(n, 2)
+    m = mhc.Model.from_data(data, 1)
+    blob, nbits, idx = m.compress(data, chunk_symbols=1024)
+    ref, ref_bits = oracle.Model.from_data(data, 1).compress(data)
+    assert nbits == ref_bits
+    assert blob == ref
+    assert m.decompress(blob, index=idx, chunk_symbols=1024, n_symbols=n) == data
