@@ -1,0 +1,297 @@
+#!/usr/bin/env python3
+"""bench.py — encode+decode GB/s of the MI355X-native Markov-Huffman hot path (BASELINE.json metric).
+
+One "step" = one full pass of the hot path over one HBM-resident synthetic stream:
+    order-1 histogram -> [RCCL all-reduce of the 256x256 counts when N > 1] -> per-context tree build
+    -> encode (payload + chunk index) -> decode (from payload + index)
+N = 1 workload: BASELINE.json configs[2] — 16 GiB of Zipf(s=1.1) bytes (the configuration the metric
+is quoted on; it fits one GPU).  N > 1: the stream is sharded into contiguous 16 GiB-per-GPU chunks
+(weak scaling); the only collective on the data path is the histogram all-reduce.
+
+Prints ONE JSON line (rank 0).  `value` = total uncompressed bytes of all ranks / step time (max over
+ranks), inputs resident in HBM.  `roofline` describes the dominant kernel: algorithmic HBM bytes per
+launch / that kernel's average launch duration (HIP events on the launch stream) against 8 TB/s.
+`cpu_baseline` = the reference CPU path on the host cores (oracle/_ref binary when present, else the
+oracle port) on a bounded sample of the same workload.
+"""
+import argparse
+import ctypes
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+CHUNK = 1024
+
+
+def zipf_cdf(device, s=1.1):
+    w = 1.0 / torch.arange(1, 257, dtype=torch.float64) ** s
+    cdf = torch.cumsum(w / w.sum(), 0)
+    cdf[-1] = 1.0
+    return cdf.to(torch.float32).to(device)
+
+
+def generate(kind, n, seed, first_slice, device):
+    """Seeded synthetic bytes, produced slice by slice (2^26 B) so any shard can be regenerated alone."""
+    out = torch.empty(n, dtype=torch.uint8, device=device)
+    sl = 1 << 26
+    cdf = zipf_cdf(device)
+    g = torch.Generator(device=device)
+    for i, off in enumerate(range(0, n, sl)):
+        m = min(sl, n - off)
+        g.manual_seed(seed * 1000003 + first_slice + i)
+        if kind == "zipf":
+            u = torch.rand(m, device=device, generator=g)
+            out[off:off + m] = torch.searchsorted(cdf, u, right=False).clamp_(max=255).to(torch.uint8)
+        elif kind == "uniform":
+            out[off:off + m] = torch.randint(0, 256, (m,), device=device, generator=g, dtype=torch.uint8)
+        else:
+            raise ValueError(kind)
+    return out
+
+
+class Codec:
+    """Thin holder of device buffers + the C-ABI calls of one rank."""
+
+    def __init__(self, mhc, n, device):
+        self.mhc, self.lib, self.n, self.device = mhc, mhc.lib(), n, device
+        self.counts = torch.zeros(65536, dtype=torch.int64, device=device)
+        self.cap = n + (64 << 20)
+        self.payload = torch.empty(self.cap, dtype=torch.uint8, device=device)
+        self.decoded = torch.empty(n, dtype=torch.uint8, device=device)
+        self.nidx = (n + CHUNK - 1) // CHUNK
+        self.index = torch.empty(max(self.nidx, 1), dtype=torch.int64, device=device)
+        self.nbits = torch.zeros(2, dtype=torch.int64, device=device)
+        self.enc_ws_bytes = self.lib.mh_dev_encode_workspace(n)
+        self.enc_ws = torch.empty(self.enc_ws_bytes + 64, dtype=torch.uint8, device=device)
+        self.dec_ws = torch.empty(256, dtype=torch.uint8, device=device)
+
+    def check(self, rc, what):
+        if rc != 0:
+            raise self.mhc.MhError(rc, what)
+
+    def stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def histogram(self, data, prev0):
+        self.check(self.lib.mh_dev_histogram_o1(data.data_ptr(), self.n, prev0, self.counts.data_ptr(), None, 0,
+                                                self.stream()), "hist")
+
+    def build_model(self):
+        return self.mhc.Model.from_device_counts(self.counts.data_ptr(), 1, self.stream())
+
+    def encode(self, model, data, prev0):
+        self.check(self.lib.mh_dev_encode(model.handle, data.data_ptr(), self.n, prev0, self.payload.data_ptr(), self.cap,
+                                          self.nbits.data_ptr(), self.index.data_ptr(), CHUNK, self.enc_ws.data_ptr(),
+                                          self.enc_ws_bytes, self.stream()), "encode")
+
+    def decode(self, model, nbits):
+        self.check(self.lib.mh_dev_decode(model.handle, self.payload.data_ptr(), nbits, self.decoded.data_ptr(), self.n,
+                                          self.index.data_ptr(), CHUNK, self.dec_ws.data_ptr(), 256, self.stream()), "decode")
+
+
+def cpu_baseline(mhc, model, sample, gpu_payload_prefix_check):
+    """Reference CPU path on a bounded sample: round-trip GB/s = bytes / (compress + decompress wall)."""
+    from oracle import mh_oracle
+    n = len(sample)
+    cores = 1
+    if os.path.exists(mh_oracle.REF_BIN):
+        with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as tmp:
+            src = os.path.join(tmp, "in.bin")
+            with open(src, "wb") as f:
+                f.write(sample)
+            run = lambda a: subprocess.run([mh_oracle.REF_BIN] + a, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            t0 = time.perf_counter()
+            run([src, "-o", os.path.join(tmp, "c"), "-d", os.path.join(tmp, "t")])
+            t1 = time.perf_counter()
+            run([os.path.join(tmp, "c"), "-o", os.path.join(tmp, "d"), "-x", "-e", os.path.join(tmp, "t")])
+            t2 = time.perf_counter()
+            ok = open(os.path.join(tmp, "d"), "rb").read() == sample
+            # and the GPU stream vs the genuine reference with the GPU-built table on the same bytes
+            with open(os.path.join(tmp, "gt"), "wb") as f:
+                f.write(model.table_bytes())
+            run([src, "-o", os.path.join(tmp, "gc"), "-e", os.path.join(tmp, "gt")])
+            ref_stream = open(os.path.join(tmp, "gc"), "rb").read()[1:]
+        kind = "reference"
+    else:
+        t0 = time.perf_counter()
+        om = mh_oracle.Model.from_data(sample, 1)
+        blob, _ = om.compress(sample)
+        t1 = time.perf_counter()
+        ok = om.decompress(blob) == sample
+        t2 = time.perf_counter()
+        ref_stream = mh_oracle.Model.from_table(model.table_bytes()).compress(sample)[0][1:]
+        kind = "port"
+    stream_ok = gpu_payload_prefix_check(ref_stream)
+    return {
+        "value": round(n / (t2 - t0) / 1e9, 4), "unit": "GB/s", "cores": cores, "kind": kind,
+        "sample": "first %d MiB of rank 0's stream: compress (histogram+tree+encode) %.2f s, decompress %.2f s, 1 thread"
+                  % (n >> 20, t1 - t0, t2 - t1),
+        "compress_GBps": round(n / (t1 - t0) / 1e9, 4), "decompress_GBps": round(n / (t2 - t1) / 1e9, 4),
+        "round_trip_ok": bool(ok), "gpu_stream_equals_cpu_stream_on_sample": bool(stream_ok),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=16 << 30, help="bytes per GPU (default 16 GiB)")
+    ap.add_argument("--kind", default="zipf", choices=["zipf", "uniform"])
+    ap.add_argument("--cpu-sample", type=int, default=256 << 20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node N" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    mhc = entry.load_package()
+    mhc.lib()                      # fails loudly if libmhc.so is missing: there is no fallback path
+    n = args.size
+    seed = 2 if args.kind == "zipf" else 3          # C3 seed 2, C4 seed 3
+    slices_per_rank = (n + (1 << 26) - 1) >> 26
+    data = generate(args.kind, n, seed, rank * slices_per_rank, device)
+    # context of each shard's first byte = last byte of the previous shard (' ' for rank 0)
+    prev0 = 0x20
+    if world > 1:
+        last = torch.zeros(world, dtype=torch.uint8, device=device)
+        dist.all_gather_into_tensor(last, data[-1:].clone())
+        if rank > 0:
+            prev0 = int(last[rank - 1].item())
+    codec = Codec(mhc, n, device)
+    all_bits = torch.zeros(world, dtype=torch.int64, device=device)
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    stage_ms = {"hist": 0.0, "allreduce": 0.0, "tree": 0.0, "encode": 0.0, "decode": 0.0}
+    model = None
+    nbits = 0
+
+    def step(record):
+        nonlocal model, nbits
+        e = [ev() for _ in range(6)]
+        e[0].record()
+        codec.histogram(data, prev0)
+        e[1].record()
+        if world > 1:
+            dist.all_reduce(codec.counts)             # the one collective: 512 KiB sum over xGMI
+        e[2].record()
+        model = codec.build_model()                   # syncs the stream once (small D2H of the counts)
+        e[3].record()
+        codec.encode(model, data, prev0)
+        e[4].record()
+        nbits = int(codec.nbits[0].item())            # payload length feeds the decoder's bounds
+        if world > 1:
+            dist.all_gather_into_tensor(all_bits, codec.nbits[:1])   # shard bit lengths for placement
+        codec.decode(model, nbits)
+        e[5].record()
+        torch.cuda.synchronize()
+        if record:
+            for k, (a, b) in zip(stage_ms, [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5)]):
+                stage_ms[k] += e[a].elapsed_time(e[b])
+
+    for _ in range(args.warmup):
+        step(False)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- correctness of what was timed (outside the timed region)
+    rc = codec.lib.mh_dev_status(codec.enc_ws.data_ptr(), codec.stream())
+    rc2 = codec.lib.mh_dev_status(codec.dec_ws.data_ptr(), codec.stream())
+    round_trip = bool(rc == 0 and rc2 == 0 and torch.equal(codec.decoded, data))
+    ok = torch.tensor([1 if round_trip else 0], device=device)
+    if world > 1:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    round_trip_all = bool(ok.item())
+
+    if rank == 0:
+        K = args.steps
+        ms = {k: v / K for k, v in stage_ms.items()}
+        r = nbits / 8.0 / n
+        total_bytes = float(n) * world
+        gbps = total_bytes / (elapsed / K) / 1e9
+        # algorithmic bytes per launch: hist 1, encode 1 + r, decode r + 1 per input byte
+        kernels = {
+            "hist_o1_kernel": (1.0 * n, ms["hist"]),
+            "encode_kernel": ((1.0 + r) * n, ms["encode"]),
+            "decode_kernel": ((1.0 + r) * n, ms["decode"]),
+        }
+        dom = max(kernels, key=lambda k: kernels[k][1])
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("%s:%d" % (dom, n))
+            except Exception:
+                traffic = None
+        ach = kernels[dom][0] / (kernels[dom][1] * 1e-3) / 1e9
+        out = {
+            "metric": "encode+decode GB/s on 16 GB byte stream, bit-exact round-trip",
+            "value": round(gbps, 3), "unit": "GB/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "order-1 Markov-Huffman round trip (histogram+tree+encode+decode), %d GiB %s per GPU, "
+                                   "chunk index every %d symbols" % (n >> 30, "Zipf(s=1.1)" if args.kind == "zipf" else "uniform", CHUNK),
+                       "bytes_per_gpu": n, "sharding": "contiguous byte ranges, histogram all-reduce (RCCL)" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": int(kernels[dom][0])},
+            "stages_ms": {k: round(v, 3) for k, v in ms.items()},
+            "stage_GBps_input": {k: (round(n / (v * 1e-3) / 1e9, 2) if v > 0 else None) for k, v in ms.items()},
+            "kernel_roofline_frac": {k: round(b / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if t > 0 else None for k, (b, t) in kernels.items()},
+            "encode_read_roofline_frac": round(n / (ms["encode"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms["encode"] > 0 else None,
+            "compressed_ratio": round(r, 5), "round_trip_bit_exact": round_trip_all,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sample_n = min(args.cpu_sample, n) & ~(CHUNK - 1)
+            sample = data[:sample_n].cpu().numpy().tobytes()
+
+            def prefix_check(ref_stream):
+                # the GPU payload's first sample_n symbols end at the index entry of chunk sample_n / CHUNK
+                if sample_n == n:
+                    end_bits = nbits
+                else:
+                    end_bits = int(codec.index[sample_n // CHUNK].item()) & mhc.INDEX_BIT_MASK
+                full = end_bits // 8
+                gpu = codec.payload[:full].cpu().numpy().tobytes()
+                return gpu == ref_stream[:full] and len(ref_stream) == (end_bits + 7) // 8
+            out["cpu_baseline"] = cpu_baseline(mhc, model, sample, prefix_check)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    if not round_trip_all:
+        sys.exit(2)
+
+
+if __name__ == "__main__":
+    main()
