@@ -1,0 +1,327 @@
+// coding.cpp — implementation of the coding.h face over the C ABI (include/mh.h).
+#include "coding.h"
+
+#include <errno.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <sstream>
+
+// ------------------------------------------------------------------------------------- utils
+
+void mh_or_die(int status, const char* what) {
+    if (status == MH_OK) return;
+    // the two messages the reference prints on these paths (src/coding.cpp:104,108); others are ours
+    if (status == MH_ERR_CORRUPT) eprintf("Error while decoding file: Input appears corrupt.\n");
+    else if (status == MH_ERR_TYPE) eprintf("Error: File encoding method does not match provided encoding table.\n");
+    else eprintf("Error in %s: %s.\n", what, mh_strerror(status));
+    exit(1);
+}
+
+int read_buffer(void* ptr, size_t size, size_t count, FILE* stream) {        // src/utils.cpp:58-67
+    size_t r = fread(ptr, size, count, stream);
+    if (r != count && ferror(stream)) {
+        eprintf("Error occurred while reading file.\n");
+        exit(1);
+    }
+    return (int)r;
+}
+
+int write_buffer(void* ptr, size_t size, size_t count, FILE* stream) {       // src/utils.cpp:69-78
+    size_t r = fwrite(ptr, size, count, stream);
+    if (r != count && ferror(stream)) {
+        eprintf("Error occurred while writing file.\n");
+        exit(1);
+    }
+    return (int)r;
+}
+
+void check_access(const char* path, bool write) {                            // src/utils.cpp:44-56 (prints only)
+    if (access(path, write ? W_OK : R_OK) == -1)
+        eprintf("Error: Unable to open \"%s\" for %s; %s.", path, write ? "writing" : "reading", strerror(errno));
+}
+
+// Printable form of a byte for the -g dump; output format of src/utils.cpp:18-42.
+std::string charv(unsigned char c) {
+    static const struct { unsigned char c; const char* s; } named[] = {
+        {' ', "\\\\sp"}, {'\t', "\\\\t"}, {'\r', "\\\\r"}, {'\n', "\\\\n"}, {'"', "\\\""}, {'\'', "\\'"}, {'\\', "\\\\"}};
+    for (const auto& e : named)
+        if (e.c == c) return e.s;
+    if (c > 32 && c < 127) return std::string(1, (char)c);
+    std::ostringstream s;
+    s << "\\\\" << std::hex << (int)c;
+    return s.str();
+}
+
+void bitbuffer::fwrite_checked(const unsigned char* p, size_t n) {
+    if (n) write_buffer(const_cast<unsigned char*>(p), 1, n, file_);
+}
+
+void bitbuffer::fill() {
+    if (loaded_) return;
+    loaded_ = true;
+    unsigned char tmp[32768];
+    size_t r;
+    while ((r = (size_t)read_buffer(tmp, 1, sizeof tmp, file_)) > 0) rbuf_.insert(rbuf_.end(), tmp, tmp + r);
+}
+
+static std::vector<unsigned char> slurp(FILE* f) {
+    std::vector<unsigned char> all;
+    unsigned char tmp[1 << 16];
+    size_t r;
+    while ((r = (size_t)read_buffer(tmp, 1, sizeof tmp, f)) > 0) all.insert(all.end(), tmp, tmp + r);
+    return all;
+}
+
+// ------------------------------------------------------------------------ histogram (a1/a2)
+
+void construct_table(FILE* input_fd, int order, uint64_t* counts64) {
+    std::vector<unsigned char> all = slurp(input_fd);
+    if (order) mh_or_die(mh_histogram_o1(all.data(), all.size(), MH_PREV0, counts64), "histogram");
+    else mh_or_die(mh_histogram_o0(all.data(), all.size(), counts64), "histogram");
+}
+
+// ------------------------------------------------------------------------ provider base
+
+i_coding_provider::~i_coding_provider() { mh_model_free(model_); }
+
+void i_coding_provider::build_from_counts(const uint64_t* counts, int order) {
+    mh_model* m = nullptr;
+    mh_or_die(mh_model_from_counts(counts, order, &m), "table build");
+    adopt(m);
+}
+
+void i_coding_provider::build_from_buffer(bitbuffer& buffer, int expected_type) {
+    std::vector<unsigned char> bytes = buffer.rest();
+    mh_model* m = nullptr;
+    int rc = mh_model_from_table_bits(bytes.data(), bytes.size(), &m);
+    if (rc == MH_OK && mh_model_type(m) != expected_type) { mh_model_free(m); rc = MH_ERR_TYPE; }
+    mh_or_die(rc, "encoding table load");
+    adopt(m);
+}
+
+void i_coding_provider::write_coding_tree(bitbuffer& buffer) {
+    size_t n = 0;
+    mh_or_die(mh_model_write_table(model_, nullptr, 0, &n), "table size");
+    std::vector<unsigned char> bytes(n ? n : 1);
+    mh_or_die(mh_model_write_table(model_, bytes.data(), n, &n), "table write");
+    buffer.push_bytes(bytes.data(), n);
+}
+
+encoding_descriptor& i_coding_provider::get_encoding(unsigned char prev, unsigned char c) {
+    int len = 0;
+    uint64_t code = 0;
+    mh_model_get_code(model_, prev, c, &len, &code);
+    scratch_desc_.length = len;
+    scratch_desc_.encoding.assign((size_t)(len + 7) / 8, 0);
+    for (int i = 0; i < len && i < 64; ++i)
+        if ((code >> (len - 1 - i)) & 1) scratch_desc_.encoding[(size_t)i / 8] |= (unsigned char)(1u << (7 - i % 8));
+    return scratch_desc_;
+}
+
+const tree_node* i_coding_provider::decoding_lookup(unsigned char prev, unsigned char w) {
+    int present = 0, inner = 0, value = 0, depth = 0;
+    mh_model_get_lut(model_, prev, w, &present, &inner, &value, &depth);
+    if (!present) return nullptr;
+    scratch_node_.is_internal = inner != 0;
+    scratch_node_.value = (unsigned char)value;
+    scratch_node_.depth = depth;
+    return &scratch_node_;
+}
+
+bool i_coding_provider::context_empty(int prev) {
+    int present = 0, a, b, c;
+    mh_model_get_lut(model_, prev, 0, &present, &a, &b, &c);
+    return !present;
+}
+
+// src/coding.cpp:61-94: header placeholder, payload, header rewrite.  Here the payload comes out of the
+// HIP encoder in one piece, so the header is known before anything is written and no seek is needed.
+void i_coding_provider::compress(FILE* input_fd, FILE* output_fd) {
+    std::vector<unsigned char> in = slurp(input_fd);
+    size_t cap = mh_encode_bound(model_, in.size());
+    std::vector<unsigned char> payload(cap ? cap : 1);
+    uint64_t nbits = 0;
+    std::vector<uint64_t> index;
+    if (!index_path_.empty()) index.resize((size_t)mh_index_entries(in.size(), chunk_) + 1);
+    mh_or_die(mh_encode(model_, in.data(), in.size(), MH_PREV0, payload.data(), cap, &nbits,
+                        index.empty() ? nullptr : index.data(), chunk_), "compress");
+    unsigned char header = mh_stream_header(model_, nbits);
+    write_buffer(&header, 1, 1, output_fd);
+    size_t nbytes = (size_t)((nbits + 7) / 8);
+    if (nbytes) write_buffer(payload.data(), 1, nbytes, output_fd);
+    if (!index_path_.empty()) {
+        // sidecar: magic, chunk size, symbol count, entries (little-endian u64s)
+        FILE* f = fopen(index_path_.c_str(), "wb");
+        if (!f) { eprintf("Error while opening index output; %s.\n", strerror(errno)); exit(1); }
+        uint64_t head[3] = {0x315844494D48ull /* "HMIDX1" */, chunk_, (uint64_t)in.size()};
+        write_buffer(head, 8, 3, f);
+        size_t ne = (size_t)mh_index_entries(in.size(), chunk_);
+        if (ne) write_buffer(index.data(), 8, ne, f);
+        fclose(f);
+    }
+    fclose(input_fd);                                   // src/coding.cpp:93
+    if (output_fd != stdout) fclose(output_fd);         // src/bitbuffer.h:35-40
+    else fflush(output_fd);
+}
+
+// src/coding.cpp:96-160
+void i_coding_provider::decompress(FILE* input_fd, FILE* output_fd) {
+    std::vector<unsigned char> in = slurp(input_fd);
+    if (in.empty()) mh_or_die(MH_ERR_CORRUPT, "decompress");
+    uint64_t nbits = 0;
+    mh_or_die(mh_stream_parse_header(model_, in[0], in.size(), &nbits), "decompress");
+    std::vector<uint64_t> index;
+    uint64_t n_symbols = 0;
+    uint32_t chunk = 0;
+    if (!index_path_.empty()) {
+        FILE* f = fopen(index_path_.c_str(), "rb");
+        if (f) {
+            uint64_t head[3];
+            if (fread(head, 8, 3, f) == 3 && head[0] == 0x315844494D48ull) {
+                chunk = (uint32_t)head[1];
+                n_symbols = head[2];
+                index.resize((size_t)mh_index_entries(n_symbols, chunk) + 1);
+                size_t ne = (size_t)mh_index_entries(n_symbols, chunk);
+                if (fread(index.data(), 8, ne, f) != ne) index.clear();
+            }
+            fclose(f);
+        }
+    }
+    const bool have_index = !index.empty();
+    // without an index every code is >= 1 bit, so nbits bounds the output size; probe first
+    size_t n = 0;
+    std::vector<unsigned char> out;
+    if (have_index) {
+        out.resize(n_symbols ? (size_t)n_symbols : 1);
+        mh_or_die(mh_decode(model_, in.data() + 1, nbits, MH_PREV0, out.data(), (size_t)n_symbols, &n, index.data(), chunk, n_symbols),
+                  "decompress");
+    } else {
+        int rc = mh_decode(model_, in.data() + 1, nbits, MH_PREV0, nullptr, 0, &n, nullptr, 0, 0);
+        if (rc != MH_OK && rc != MH_ERR_CAPACITY) mh_or_die(rc, "decompress");
+        out.resize(n ? n : 1);
+        if (n) mh_or_die(mh_decode(model_, in.data() + 1, nbits, MH_PREV0, out.data(), n, &n, nullptr, 0, 0), "decompress");
+    }
+    if (n) write_buffer(out.data(), 1, n, output_fd);
+    fclose(input_fd);
+    if (output_fd != stdout) fclose(output_fd);
+    else fflush(output_fd);
+}
+
+// ------------------------------------------------------------------------ -g dumps (N3)
+
+void encoding_descriptor::print() {                                          // src/coding.cpp:29-33
+    for (int i = 0; i < length; i++) printf("%d", (encoding[(size_t)i / 8] >> (8 - i % 8 - 1)) & 1);
+}
+
+void i_coding_provider::print_table_for(int prev) {                           // src/huffman.cpp:52-62
+    printf("Table:\n");
+    for (int i = 0; i < 256; i++) {
+        encoding_descriptor& e = get_encoding((unsigned char)prev, (unsigned char)i);
+        if (e.length) {
+            printf("%s %d ", charv((unsigned char)i).c_str(), e.length);
+            e.print();
+            printf("\n");
+        }
+    }
+}
+
+// Graphviz dump in the reference's format (src/tree.cpp:7-53).  The tree is re-read from the model's
+// own pre-order serialisation (src/huffman.cpp:174-188), so no tree structure crosses the C ABI.
+namespace {
+struct dot_reader {
+    const std::vector<unsigned char>& b;
+    size_t pos;
+    int bit() { int v = (b[pos >> 3] >> (7 - (pos & 7))) & 1; ++pos; return v; }
+    int byte() { int v = 0; for (int i = 0; i < 8; ++i) v = (v << 1) | bit(); return v; }
+};
+// prints the subtree that starts at the reader's cursor; n = this node's number; returns last number used
+int dot_nodes(dot_reader& r, int n) {
+    printf("\tn%d;\n", n);
+    if (r.bit()) {
+        printf("\tn%d [label=\"%s\"];\n", n, charv((unsigned char)r.byte()).c_str());
+        return n;
+    }
+    printf("\tn%d [label=\"\"];\n", n);
+    int next = n + 1;
+    int last = dot_nodes(r, next);
+    printf("\tn%d -- n%d;\n", n, next);
+    next = last + 1;
+    last = dot_nodes(r, next);
+    printf("\tn%d -- n%d;\n", n, next);
+    return last;
+}
+}  // namespace
+
+int i_coding_provider::print_tree_for(int prev, bool subgraph, int n, const std::string& label) {
+    size_t nb = 0;
+    mh_or_die(mh_model_write_table(model_, nullptr, 0, &nb), "table size");
+    std::vector<unsigned char> bytes(nb + 1);
+    mh_or_die(mh_model_write_table(model_, bytes.data(), nb, &nb), "table write");
+    dot_reader r{bytes, 0};
+    if (get_type() == 1) {
+        // skip to context `prev`: marker bit, then per context a presence bit (+ tree)
+        r.bit();
+        for (int p = 0; p < prev; ++p) {
+            if (!r.bit()) continue;
+            int open = 1;                      // subtrees still to read
+            while (open) { if (r.bit()) { r.byte(); --open; } else { ++open; } }
+        }
+        r.bit();
+    }
+    if (subgraph) {
+        printf("subgraph clusterG%d {\n", n);
+        printf("\tlabel=\"%s\";\n", label.c_str());
+        printf("\tcolor=invis;\n");
+    } else {
+        printf("graph G {\n");
+    }
+    printf("\tnodesep=0.3;\n");
+    printf("\tranksep=0.2;\n");
+    printf("\tnode [shape=circle, fixedsize=true];\n");
+    printf("\tedge [arrowsize=0.8];\n");
+    n = dot_nodes(r, n) + 1;
+    printf("}\n");
+    return n;
+}
+
+// ------------------------------------------------------------------------ concrete providers
+
+static std::vector<uint64_t> widen_counts(const int* counts, size_t n) {
+    std::vector<uint64_t> w(n);
+    for (size_t i = 0; i < n; ++i) w[i] = (uint64_t)(counts[i] < 0 ? 0 : counts[i]);
+    return w;
+}
+
+huffman_table::huffman_table(int* counts) { build_from_counts(widen_counts(counts, 256).data(), 0); }
+huffman_table::huffman_table(const uint64_t* counts) { build_from_counts(counts, 0); }
+huffman_table::huffman_table(bitbuffer& buffer) { build_from_buffer(buffer, 0); }
+bool huffman_table::empty() { return context_empty(0); }
+void huffman_table::print_table() { print_table_for(0); }
+void huffman_table::print_tree() { print_tree_for(0, false, 0, ""); }
+
+markov_huffman_table::markov_huffman_table(int* counts) { build_from_counts(widen_counts(counts, 65536).data(), 1); }
+markov_huffman_table::markov_huffman_table(const uint64_t* counts) { build_from_counts(counts, 1); }
+markov_huffman_table::markov_huffman_table(bitbuffer& buffer) { build_from_buffer(buffer, 1); }
+
+void markov_huffman_table::print_table() {                                    // src/markov_huffman.cpp:31-38
+    for (int i = 0; i < 256; i++) {
+        if (!context_empty(i)) {
+            printf("Prev '%s' table:\n", charv((unsigned char)i).c_str());
+            print_table_for(i);
+        }
+    }
+}
+
+void markov_huffman_table::print_tree() {                                     // src/markov_huffman.cpp:40-50
+    printf("graph G {\n");
+    printf("\tpackmode=\"cluster\";\n");
+    for (int i = 0, n = 0; i < 256; i++) {
+        if (!context_empty(i)) {
+            printf("/* Prev '%s' tree: */\n", charv((unsigned char)i).c_str());
+            n = print_tree_for(i, true, n, "Prev: " + charv((unsigned char)i));
+        }
+    }
+    printf("}\n");
+}
