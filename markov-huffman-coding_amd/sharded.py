@@ -1,0 +1,132 @@
+"""Multi-GPU orchestration of the hot path: contiguous byte-range shards, one process per GPU.
+
+The data path has exactly one exchange step: a sum-all-reduce of the 65 536-entry
+conditional histogram (512 KiB of uint64, RCCL over xGMI on the GPU box), after which every rank
+builds the identical model deterministically (integer-only tree build, no broadcast).  A second tiny
+collective — an all-gather of one uint64 per rank — gives each shard payload's global bit offset.
+
+This module holds only the orchestration.  The per-shard compute comes from a `backend`:
+`HipBackend` (below) drives libmhc.so on the rank's GPU and is the only backend the product ships;
+tests inject their own backend to exercise the collective logic with gloo on CPU.
+"""
+import ctypes
+
+import torch
+import torch.distributed as dist
+
+PREV0 = 0x20
+
+
+def shard_bounds(n, world):
+    """Contiguous shards, sizes differing by at most one 16-byte unit; returns [(lo, hi)] * world."""
+    unit = 16
+    units = (n + unit - 1) // unit
+    out = []
+    for r in range(world):
+        lo = min(n, (units * r // world) * unit)
+        hi = min(n, (units * (r + 1) // world) * unit)
+        out.append((lo, hi))
+    return out
+
+
+def exchange_prev0(last_byte, has_data, group=None):
+    """Context of each shard's first byte = last byte of the nearest non-empty shard before it
+    (src/main.cpp:32: ' ' for the very first)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    mine = torch.tensor([int(last_byte) if has_data else -1], dtype=torch.int64, device=_dev(group))
+    allv = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allv, mine, group=group)
+    prev0 = PREV0
+    for r in range(rank):
+        v = int(allv[r].item())
+        if v >= 0:
+            prev0 = v
+    return prev0
+
+
+def _dev(group):
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+
+
+def merged_histogram(local_counts, group=None):
+    """local_counts: int64[65536] tensor on the rank's device (counts < 2^63).  In-place sum over ranks."""
+    dist.all_reduce(local_counts, op=dist.ReduceOp.SUM, group=group)
+    return local_counts
+
+
+def global_bit_offsets(local_nbits, group=None):
+    """All-gather of the shard payload lengths -> (this rank's global start bit, total bits, all lengths)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    mine = torch.tensor([int(local_nbits)], dtype=torch.int64, device=_dev(group))
+    allv = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allv, mine, group=group)
+    lens = [int(v.item()) for v in allv]
+    return sum(lens[:rank]), sum(lens), lens
+
+
+def compress_shard(backend, shard, last_byte, group=None):
+    """One rank's part of a sharded compress.  Returns dict(model, payload, nbits, index, prev0,
+    start_bit, total_bits)."""
+    n = backend.length(shard)
+    prev0 = exchange_prev0(last_byte, n > 0, group)
+    counts = backend.histogram(shard, prev0)
+    merged_histogram(counts, group)
+    model = backend.build_model(counts)
+    payload, nbits, index = backend.encode(model, shard, prev0)
+    start, total, _ = global_bit_offsets(nbits, group)
+    return {"model": model, "payload": payload, "nbits": nbits, "index": index, "prev0": prev0,
+            "start_bit": start, "total_bits": total}
+
+
+class HipBackend:
+    """Per-shard compute on the rank's MI355X through the C ABI (device pointers, current stream)."""
+
+    def __init__(self, mhc, chunk_symbols=1024):
+        self.mhc, self.lib, self.chunk = mhc, mhc.lib(), chunk_symbols
+        if mhc.device_count() < 1:
+            raise mhc.MhError(mhc.MH_ERR_NO_DEVICE, "HipBackend")
+
+    @staticmethod
+    def _stream():
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise self.mhc.MhError(rc, what)
+
+    def length(self, shard):
+        return shard.numel()
+
+    def histogram(self, shard, prev0):
+        counts = torch.zeros(65536, dtype=torch.int64, device=shard.device)
+        self._check(self.lib.mh_dev_histogram_o1(shard.data_ptr(), shard.numel(), prev0, counts.data_ptr(), None, 0,
+                                                 self._stream()), "mh_dev_histogram_o1")
+        return counts
+
+    def build_model(self, counts):
+        return self.mhc.Model.from_device_counts(counts.data_ptr(), 1, self._stream())
+
+    def encode(self, model, shard, prev0):
+        n = shard.numel()
+        cap = self.lib.mh_encode_bound(model.handle, n)
+        payload = torch.empty(cap, dtype=torch.uint8, device=shard.device)
+        nbits = torch.zeros(1, dtype=torch.int64, device=shard.device)
+        index = torch.empty(max((n + self.chunk - 1) // self.chunk, 1), dtype=torch.int64, device=shard.device)
+        wsb = self.lib.mh_dev_encode_workspace(n)
+        ws = torch.empty(wsb + 64, dtype=torch.uint8, device=shard.device)
+        self._check(self.lib.mh_dev_encode(model.handle, shard.data_ptr(), n, prev0, payload.data_ptr(), cap,
+                                           nbits.data_ptr(), index.data_ptr(), self.chunk, ws.data_ptr(), wsb,
+                                           self._stream()), "mh_dev_encode")
+        self._check(self.lib.mh_dev_status(ws.data_ptr(), self._stream()), "encode status")
+        nb = int(nbits.item())
+        return payload[:(nb + 7) // 8], nb, index[:(n + self.chunk - 1) // self.chunk]
+
+    def decode(self, model, payload, nbits, index, n):
+        out = torch.empty(max(n, 1), dtype=torch.uint8, device=payload.device)
+        ws = torch.empty(256, dtype=torch.uint8, device=payload.device)
+        self._check(self.lib.mh_dev_decode(model.handle, payload.data_ptr(), nbits, out.data_ptr(), n, index.data_ptr(),
+                                           self.chunk, ws.data_ptr(), 256, self._stream()), "mh_dev_decode")
+        self._check(self.lib.mh_dev_status(ws.data_ptr(), self._stream()), "decode status")
+        return out[:n]

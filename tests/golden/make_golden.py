@@ -87,6 +87,14 @@ def main():
                 if not (entry["formula"] and len(data) > 1000):
                     with open(os.path.join(exp_dir, name + ext), "wb") as f:
                         f.write(b)
+            # -g debug dumps (stdout of print_table + print_tree, src/main.cpp:186-190) for small cases
+            if name in ("input_a.txt", "input_b.txt", "input_ipsum.txt", "one_Z", "nine_Z"):
+                for ext, extra in ((".g", []), (".gh", ["-h"])):
+                    r = subprocess.run([REF_BIN, src, "-o", os.devnull, "-g"] + extra, check=True,
+                                       stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+                    entry[ext[1:]] = {"size": len(r.stdout), "sha256": sha(r.stdout)}
+                    with open(os.path.join(exp_dir, name + ext), "wb") as f:
+                        f.write(r.stdout)
             # the reference's own inputs are committed as data; formula inputs are regenerated
             if not entry["formula"]:
                 with open(os.path.join(in_dir, name), "wb") as f:
