@@ -19,9 +19,12 @@ struct mh_model {
     // device images (owned)
     uint16_t *d_enc16 = nullptr;
     uint8_t *d_len8 = nullptr;
+    uint8_t *d_len_slot = nullptr;
     uint64_t *d_code64 = nullptr;
     uint16_t *d_dec16 = nullptr;
     uint32_t *d_tree = nullptr;
+    uint16_t *d_sub16 = nullptr;
+    uint32_t *d_sub_base = nullptr;
 };
 
 namespace {
@@ -87,9 +90,16 @@ int upload_model(mh_model *m) {
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_tree), 256 * mh::TREE_STRIDE * 4));
     HIP_TRY(hipMemcpy(m->d_enc16, pk.enc16.data(), 65536 * 2, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(m->d_len8, pk.len8.data(), 65536, hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_len_slot), 65536));
+    HIP_TRY(hipMemcpy(m->d_len_slot, pk.len_slot.data(), 65536, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(m->d_code64, pk.code64.data(), 65536 * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(m->d_dec16, pk.dec16.data(), 65536 * 2, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(m->d_tree, pk.tree.data(), 256 * mh::TREE_STRIDE * 4, hipMemcpyHostToDevice));
+    size_t sub_bytes = pk.sub16.size() * 2;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_sub16), sub_bytes ? sub_bytes : 16));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_sub_base), 256 * 4));
+    if (sub_bytes) HIP_TRY(hipMemcpy(m->d_sub16, pk.sub16.data(), sub_bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(m->d_sub_base, pk.sub_base.data(), 256 * 4, hipMemcpyHostToDevice));
     return MH_OK;
 }
 
@@ -202,9 +212,12 @@ void mh_model_free(mh_model *m) {
     if (!m) return;
     if (m->d_enc16) (void)hipFree(m->d_enc16);
     if (m->d_len8) (void)hipFree(m->d_len8);
+    if (m->d_len_slot) (void)hipFree(m->d_len_slot);
     if (m->d_code64) (void)hipFree(m->d_code64);
     if (m->d_dec16) (void)hipFree(m->d_dec16);
     if (m->d_tree) (void)hipFree(m->d_tree);
+    if (m->d_sub16) (void)hipFree(m->d_sub16);
+    if (m->d_sub_base) (void)hipFree(m->d_sub_base);
     delete m;
 }
 
@@ -235,13 +248,12 @@ int mh_dev_encode(const mh_model *m, const uint8_t *d_data, size_t n, uint8_t pr
     if (ws_bytes < mhk::encode_workspace_bytes(n)) return MH_ERR_CAPACITY;
     if (m->packed.max_len > mh::MAX_CODE_BITS) return MH_ERR_CODE_TOO_LONG;
     if (!m->d_enc16) return MH_ERR_NO_DEVICE;
-    mhk::EncParams p{};
+    mhk::EncodeArgs p{};
     p.data = d_data; p.n = n; p.prev0 = prev0; p.chunk_shift = uint32_t(shift);
     p.out = d_payload; p.cap = cap;
-    p.enc16 = m->d_enc16; p.len8 = m->d_len8; p.code64 = m->d_code64;
+    p.enc16 = m->d_enc16; p.len_slot = m->d_len_slot; p.len8 = m->d_len8; p.code64 = m->d_code64;
     p.nbits = reinterpret_cast<unsigned long long *>(d_nbits);
     p.index = reinterpret_cast<unsigned long long *>(d_index);
-    p.seed = 0;
     HIP_TRY(mhk::launch_encode(p, d_ws, static_cast<hipStream_t>(stream)));
     return MH_OK;
 }
@@ -264,6 +276,7 @@ int mh_dev_decode(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, u
     p.nchunks = mh_index_entries(n_symbols, chunk_symbols);
     p.chunk_shift = uint32_t(shift);
     p.dec16 = m->d_dec16; p.tree = m->d_tree;
+    p.sub16 = m->d_sub16; p.sub_base = m->d_sub_base; p.sub_bits = uint32_t(m->packed.sub_bits);
     HIP_TRY(mhk::launch_decode(p, d_ws, static_cast<hipStream_t>(stream)));
     return MH_OK;
 }
@@ -281,6 +294,7 @@ int mh_dev_build_index(const mh_model *m, const uint8_t *d_payload, uint64_t nbi
     p.index = reinterpret_cast<unsigned long long *>(d_index); p.index_cap = index_cap;
     p.n_symbols = reinterpret_cast<unsigned long long *>(d_n_symbols);
     p.dec16 = m->d_dec16; p.tree = m->d_tree;
+    p.sub16 = m->d_sub16; p.sub_base = m->d_sub_base; p.sub_bits = uint32_t(m->packed.sub_bits);
     HIP_TRY(mhk::launch_build_index(p, d_ws, static_cast<hipStream_t>(stream)));
     return MH_OK;
 }

@@ -10,7 +10,8 @@ namespace mhk {
 // device-side status word values (first int32 of every workspace)
 enum { MHK_STATUS_OK = 0, MHK_STATUS_TIMEOUT = 1, MHK_STATUS_CAPACITY = 2, MHK_STATUS_CORRUPT = 3 };
 
-struct EncParams {
+// host-side description of one encode call (device pointers)
+struct EncodeArgs {
     const uint8_t *data;          // n input bytes, 16-byte aligned
     uint64_t n;
     uint32_t prev0;
@@ -18,16 +19,45 @@ struct EncParams {
     uint8_t *out;                 // payload, 16-byte aligned
     uint64_t cap;                 // bytes available at out
     const uint16_t *enc16;        // 65536 entries, slot order
+    const uint8_t *len_slot;      // 65536 code lengths, slot order (length pass)
     const uint8_t *len8;          // 65536, prev*256+sym
     const uint64_t *code64;       // 65536, prev*256+sym
     unsigned long long *nbits;    // out: payload bits
     unsigned long long *index;    // out: chunk index or nullptr
-    uint64_t seed;                // (tail7 << 55 | start bit) of the virtual tile -1; 0 for a fresh stream
-    // filled by launch_encode from the workspace
-    unsigned long long *desc;
-    unsigned int *ticket;
+};
+
+struct LenParams {
+    const uint8_t *data;
+    uint64_t n;
+    uint32_t prev0;
+    const uint8_t *len_slot;
+    uint32_t *wt_bits;
+    uint64_t nwt;
+};
+
+struct ScanParams {
+    unsigned long long *wt_start;
+    const unsigned long long *blk_sum;
+    uint64_t nwt, nblk;
+    uint8_t *out;
+    uint64_t cap;
+    unsigned long long *nbits;
     int *status;
-    uint32_t ntiles;
+};
+
+struct EmitParams {
+    const uint8_t *data;
+    uint64_t n;
+    uint32_t prev0;
+    uint32_t chunk_shift;
+    uint8_t *out;
+    const uint16_t *enc16;
+    const uint8_t *len8;
+    const uint64_t *code64;
+    const unsigned long long *wt_start;
+    uint64_t nwt;
+    unsigned long long *index;
+    const int *status;
 };
 
 struct DecParams {
@@ -41,6 +71,9 @@ struct DecParams {
     uint32_t chunk_shift;
     const uint16_t *dec16;        // 65536, prev*256+window
     const uint32_t *tree;         // 256 * TREE_STRIDE
+    const uint16_t *sub16;        // second-level tables
+    const uint32_t *sub_base;     // 256
+    uint32_t sub_bits;
     int *status;
 };
 
@@ -55,14 +88,16 @@ struct IdxParams {
     unsigned long long *n_symbols;
     const uint16_t *dec16;
     const uint32_t *tree;
+    const uint16_t *sub16;
+    const uint32_t *sub_base;
+    uint32_t sub_bits;
     int *status;
 };
 
 hipError_t launch_hist_o1(const uint8_t *d_data, uint64_t n, uint32_t prev0, unsigned long long *d_counts, hipStream_t st);
 hipError_t launch_hist_o0(const uint8_t *d_data, uint64_t n, unsigned long long *d_counts, hipStream_t st);
-uint64_t encode_tiles(uint64_t n);
 size_t encode_workspace_bytes(uint64_t n);
-hipError_t launch_encode(EncParams p, void *d_ws, hipStream_t st);
+hipError_t launch_encode(const EncodeArgs &a, void *d_ws, hipStream_t st);
 hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st);
 hipError_t launch_build_index(IdxParams p, void *d_ws, hipStream_t st);
 

@@ -173,44 +173,195 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_o0_kernel(const uint8_t *__
 }
 
 // ------------------------------------------------------------------------------------------------
-// encode
+// encode: three dependency-free steps
 // ------------------------------------------------------------------------------------------------
-// One workgroup (1024 lanes, one per CU because the codeword table takes 128 KiB of LDS) pulls tiles
-// of ENC_TILE input bytes from a ticket counter.  Per tile:
-//   A  each lane loads 8 consecutive bytes (+ the byte before them), looks up 8 codewords in LDS,
-//      concatenates them in registers (two <=48-bit groups), and the wave scans (L, tail7);
-//   B  waves exchange their aggregates through LDS; wave 0 publishes the tile aggregate, looks back
-//      over earlier tiles' descriptors for the tile's absolute bit offset and publishes the inclusive
-//      prefix; every lane ORs its bits into the LDS staging image at tile-local alignment;
-//   C  the staging image is funnel-shifted to the absolute alignment, byte-swapped to the stream's
-//      MSB-first order and stored as coalesced dwords (byte stores at the two seams; the byte that
-//      straddles two tiles is written by the later tile, which got the earlier bits as `tail7`).
-// Codes longer than 12 bits are escapes into the full table in HBM/L2; a wave that sees one deposits
-// symbol by symbol, and a tile whose bits exceed the staging image is emitted in several rounds.
-constexpr int ENC_THREADS = 1024;
-constexpr int ENC_WAVES = ENC_THREADS / 64;
-constexpr int ENC_SPL = 8;                          // symbols per lane per tile
-constexpr int ENC_TILE = ENC_THREADS * ENC_SPL;     // 8192 input bytes
-constexpr int ENC_STAGE_WORDS = ENC_TILE * mh::ENC16_MAX_LEN / 32;   // 3072 words = 12 KiB
-constexpr int ENC_STAGE_BITS = ENC_STAGE_WORDS * 32;
-constexpr int ENC_MAX_CPT = ENC_TILE / 256;         // chunks per tile at the smallest chunk size
-constexpr int ENC_LDS_BYTES = 131072 + (ENC_STAGE_WORDS + 4) * 4 + ENC_WAVES * 4 + ENC_MAX_CPT * 8 + 64;
-constexpr uint32_t SPIN_LIMIT = 1u << 22;
+//   enc_len_kernel   per wave-tile (4 KiB of input) sum of code lengths          reads n
+//   scan_*           exclusive prefix over the wave-tile sums -> absolute bit offsets; zeroes the
+//                    one output dword at every wave-tile seam
+//   enc_emit_kernel  every WAVE encodes its wave-tiles on its own: LDS codeword table, wave
+//                    prefix-sum of bit lengths, bits OR-ed into a wave-private LDS image that is
+//                    already aligned to the absolute output dwords, coalesced dword stores; the
+//                    two seam dwords of a wave-tile are merged with global atomic OR.  No barrier,
+//                    no inter-workgroup hand-off, nothing to wait for.
+// A single-pass variant with decoupled look-back across tiles was measured first (round 1): its
+// prefix chain advances <= 64 tiles per ~2 us descriptor hop across XCDs, i.e. ~260 GB/s; the extra
+// read of the length pass costs far less than that chain.
+constexpr int E_THREADS = 1024;
+constexpr int E_WAVES = E_THREADS / 64;
+constexpr int E_VEC = 16;                              // bytes per lane per sub-step
+constexpr int E_SUB = 64 * E_VEC;                      // 1 KiB per wave sub-step
+constexpr int E_SUBSTEPS = 4;
+constexpr int E_WT = E_SUB * E_SUBSTEPS;               // 4 KiB wave-tile
+constexpr int E_STAGE_BITS = E_SUB * mh::ENC16_MAX_LEN;            // 12288 payload bits per sub-step
+constexpr int E_STAGE_WORDS = E_STAGE_BITS / 32 + 8;               // + alignment word + pad
+constexpr int EMIT_LDS_BYTES = 131072 + E_WAVES * E_STAGE_WORDS * 4;
+constexpr int LEN_LDS_BYTES = 65536;
 
-// OR a left-aligned string (first bit at bit 63 of `vl`) into the staging image at tile-local bit
-// offset `o`.  CLIP: only words inside [wbase, wbase + ENC_STAGE_WORDS) are touched.
+// 16 consecutive input bytes of a lane (little-endian dwords) + the byte before them -> the 16
+// (prev, sym) windows, window = sym << 8 | prev = the raw 16-bit field of the stream.
+__device__ __forceinline__ void windows16(const uint4 &x, uint32_t pb, uint32_t (&w)[16]) {
+    w[0] = ((x.x << 8) | pb) & 0xFFFFu;
+    w[1] = x.x & 0xFFFFu;  w[2] = (x.x >> 8) & 0xFFFFu;  w[3] = x.x >> 16;
+    w[4] = __builtin_amdgcn_alignbyte(x.y, x.x, 3) & 0xFFFFu;
+    w[5] = x.y & 0xFFFFu;  w[6] = (x.y >> 8) & 0xFFFFu;  w[7] = x.y >> 16;
+    w[8] = __builtin_amdgcn_alignbyte(x.z, x.y, 3) & 0xFFFFu;
+    w[9] = x.z & 0xFFFFu;  w[10] = (x.z >> 8) & 0xFFFFu; w[11] = x.z >> 16;
+    w[12] = __builtin_amdgcn_alignbyte(x.w, x.z, 3) & 0xFFFFu;
+    w[13] = x.w & 0xFFFFu; w[14] = (x.w >> 8) & 0xFFFFu; w[15] = x.w >> 16;
+}
+
+// Loads the lane's 16 bytes at `off` (zero past n) and the byte before them.  nvalid = bytes < n.
+__device__ __forceinline__ void load_lane(const uint8_t *__restrict__ data, uint64_t n, uint64_t off, uint32_t prev0,
+                                          uint4 &x, uint32_t &pb, uint32_t &nvalid) {
+    x = make_uint4(0, 0, 0, 0);
+    nvalid = 0;
+    if (off + E_VEC <= n) {
+        x = *reinterpret_cast<const uint4 *>(data + off);
+        nvalid = E_VEC;
+    } else if (off < n) {
+        nvalid = uint32_t(n - off);
+        uint32_t b[4] = {0, 0, 0, 0};
+        for (uint32_t j = 0; j < nvalid; ++j) b[j >> 2] |= uint32_t(data[off + j]) << (8u * (j & 3u));
+        x = make_uint4(b[0], b[1], b[2], b[3]);
+    }
+    // byte before the lane's vector: the previous lane's last byte, except in lane 0
+    uint32_t up = __shfl_up(x.w >> 24, 1);
+    if ((threadIdx.x & 63u) == 0) up = off ? (off - 1 < n ? uint32_t(data[off - 1]) : 0u) : prev0;
+    pb = up;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+// ---- pass 1 ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(E_THREADS, 8) void enc_len_kernel(LenParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint8_t *ltab = smem;   // code length per slot (0..64)
+    for (int i = threadIdx.x; i < 4096; i += E_THREADS)
+        reinterpret_cast<uint4 *>(ltab)[i] = reinterpret_cast<const uint4 *>(p.len_slot)[i];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave0 = uint64_t(blockIdx.x) * E_WAVES + (threadIdx.x >> 6);
+    const uint64_t nwaves = uint64_t(gridDim.x) * E_WAVES;
+    for (uint64_t wt = wave0; wt < p.nwt; wt += nwaves) {
+        uint32_t sum = 0;
+#pragma unroll 2
+        for (int k = 0; k < E_SUBSTEPS; ++k) {
+            uint64_t off = wt * E_WT + uint64_t(k) * E_SUB + lane * E_VEC;
+            uint4 x; uint32_t pb, nvalid;
+            load_lane(p.data, p.n, off, p.prev0, x, pb, nvalid);
+            uint32_t w[16];
+            windows16(x, pb, w);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                uint32_t l = ltab[mh::enc_slot(w[j])];
+                sum += (uint32_t(j) < nvalid) ? l : 0u;
+            }
+        }
+        sum = wave_sum(sum);
+        if (lane == 0) p.wt_bits[wt] = sum;
+    }
+}
+
+// ---- scan over wave-tile sums --------------------------------------------------------------------
+constexpr int SCAN_THREADS = 1024;
+constexpr int SCAN_PER_THREAD = 4;
+constexpr int SCAN_BLOCK = SCAN_THREADS * SCAN_PER_THREAD;
+
+__device__ __forceinline__ uint64_t block_excl_scan(uint64_t v, uint64_t *lds, uint64_t &total) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint64_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint64_t t = __shfl_up(inc, d);
+        if (lane >= uint32_t(d)) inc += t;
+    }
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    uint64_t base = 0, tot = 0;
+    for (uint32_t w = 0; w < SCAN_THREADS / 64; ++w) {
+        uint64_t a = lds[w];
+        if (w < wave) base += a;
+        tot += a;
+    }
+    __syncthreads();
+    total = tot;
+    return base + inc - v;
+}
+
+// per block of 4096 wave-tiles: exclusive prefix within the block + the block's total
+__global__ __launch_bounds__(SCAN_THREADS) void scan_local_kernel(const uint32_t *wt_bits, uint64_t nwt,
+                                                                  unsigned long long *wt_start, unsigned long long *blk_sum) {
+    __shared__ uint64_t lds[SCAN_THREADS / 64];
+    uint64_t i0 = uint64_t(blockIdx.x) * SCAN_BLOCK + uint64_t(threadIdx.x) * SCAN_PER_THREAD;
+    uint64_t v[SCAN_PER_THREAD], s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) { v[k] = (i0 + k < nwt) ? wt_bits[i0 + k] : 0; s += v[k]; }
+    uint64_t total;
+    uint64_t ex = block_excl_scan(s, lds, total);
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) { if (i0 + k < nwt) wt_start[i0 + k] = ex; ex += v[k]; }
+    if (threadIdx.x == 0) blk_sum[blockIdx.x] = total;
+}
+
+// one block: exclusive scan of the block totals in place; writes the grand total after the last entry
+__global__ __launch_bounds__(SCAN_THREADS) void scan_top_kernel(unsigned long long *blk_sum, uint64_t nblk) {
+    __shared__ uint64_t lds[SCAN_THREADS / 64];
+    uint64_t carry = 0;
+    for (uint64_t base = 0; base < nblk; base += SCAN_THREADS) {
+        uint64_t i = base + threadIdx.x;
+        uint64_t v = i < nblk ? blk_sum[i] : 0;
+        uint64_t total;
+        uint64_t ex = block_excl_scan(v, lds, total);
+        if (i < nblk) blk_sum[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) blk_sum[nblk] = carry;
+}
+
+// adds the block offsets, publishes the total, zeroes the output dword under every wave-tile seam
+// (those dwords are completed by global atomic OR from two neighbouring waves)
+__global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(ScanParams p) {
+    const unsigned long long boff = p.blk_sum[blockIdx.x];
+    const uint64_t total = p.blk_sum[p.nblk];
+    const uint64_t cap_bits = p.cap * 8;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *p.nbits = total;
+        if (total > cap_bits) atomicExch(p.status, MHK_STATUS_CAPACITY);
+        uint64_t endw = total >> 5;
+        if ((total & 31u) && (endw + 1) * 4 <= p.cap) reinterpret_cast<uint32_t *>(p.out)[endw] = 0;
+        else if (total & 31u) for (uint64_t b = endw * 4; b < p.cap; ++b) p.out[b] = 0;
+    }
+    uint64_t i0 = uint64_t(blockIdx.x) * SCAN_BLOCK + uint64_t(threadIdx.x) * SCAN_PER_THREAD;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
+        uint64_t i = i0 + k;
+        if (i < p.nwt) {
+            uint64_t s = p.wt_start[i] + boff;
+            p.wt_start[i] = s;
+            if ((s & 31u) && ((s >> 5) + 1) * 4 <= p.cap) reinterpret_cast<uint32_t *>(p.out)[s >> 5] = 0;
+        }
+    }
+}
+
+// ---- pass 2 ------------------------------------------------------------------------------------
+// OR a left-aligned string (first bit at bit 63 of `vl`) into the wave's staging image at image bit
+// offset `o` (image word j <-> output dword base + j).  CLIP: only words in [wbase, wbase + nwords).
 template <bool CLIP>
-__device__ __forceinline__ void deposit(uint32_t *stage, uint64_t vl, uint32_t o, uint32_t wbase) {
+__device__ __forceinline__ void deposit(uint32_t *stage, uint64_t vl, uint32_t o, uint32_t wbase, uint32_t nwords) {
     uint32_t hi = uint32_t(vl >> 32), lo = uint32_t(vl);
     uint32_t sh = o & 31u;
     uint32_t w0 = hi >> sh;
     uint32_t w1 = __builtin_amdgcn_alignbit(hi, lo, sh);
     uint32_t w2 = __builtin_amdgcn_alignbit(lo, 0u, sh);
-    uint32_t wi = (o >> 5) - wbase;  // wraps when below the window; the unsigned compare rejects it
+    uint32_t wi = (o >> 5) - wbase;   // wraps when below the window; the unsigned compares reject it
     if (CLIP) {
-        if (w0 && wi < uint32_t(ENC_STAGE_WORDS)) atomicOr(&stage[wi], w0);
-        if (w1 && wi + 1u < uint32_t(ENC_STAGE_WORDS)) atomicOr(&stage[wi + 1u], w1);
-        if (w2 && wi + 2u < uint32_t(ENC_STAGE_WORDS)) atomicOr(&stage[wi + 2u], w2);
+        if (w0 && wi < nwords) atomicOr(&stage[wi], w0);
+        if (w1 && wi + 1u < nwords) atomicOr(&stage[wi + 1u], w1);
+        if (w2 && wi + 2u < nwords) atomicOr(&stage[wi + 2u], w2);
     } else {
         if (w0) atomicOr(&stage[wi], w0);
         if (w1) atomicOr(&stage[wi + 1u], w1);
@@ -218,256 +369,181 @@ __device__ __forceinline__ void deposit(uint32_t *stage, uint64_t vl, uint32_t o
     }
 }
 
-// Phase C for one round: bits [0, lr) of the staging image sit at absolute bit offset s; `carry` holds
-// the (s & 7) stream bits just before s.
-__device__ __forceinline__ void write_out(const uint32_t *stage, uint8_t *out, uint64_t cap, uint64_t s,
-                                          uint32_t carry, uint32_t lr, bool last) {
-    uint64_t e = s + lr;
-    uint64_t b0 = s >> 3, b1 = last ? (e + 7) >> 3 : e >> 3;
-    if (b1 > cap) b1 = cap;      // capacity overrun is reported by the caller; never write past it
-    if (b0 >= b1) return;
-    uint64_t g0 = b0 >> 2, g1 = (b1 + 3) >> 2;
-    uint32_t k = uint32_t(s & 7u);
-    uint32_t cbits = carry & ((1u << k) - 1u);
-    for (uint64_t g = g0 + threadIdx.x; g < g1; g += ENC_THREADS) {
-        int32_t o = int32_t(int64_t(g << 5) - int64_t(s));   // |o| < 2^20
-        uint32_t val;
-        if (o < 0) {
-            uint32_t m = uint32_t(-o);                       // 1..31
-            val = (cbits << (32u - m)) | (stage[0] >> m);
-        } else {
-            uint32_t q = uint32_t(o) >> 5, r = uint32_t(o) & 31u;
-            uint64_t two = (uint64_t(stage[q]) << 32) | stage[q + 1u];
-            val = uint32_t(two >> (32u - r));
-        }
-        uint64_t lo = g << 2, hi = lo + 4;
-        if (lo >= b0 && hi <= b1) {
-            reinterpret_cast<uint32_t *>(out)[g] = __builtin_bswap32(val);
-        } else {
-            for (uint64_t b = (lo > b0 ? lo : b0); b < (hi < b1 ? hi : b1); ++b)
-                out[b] = uint8_t(val >> (24u - 8u * uint32_t(b - lo)));
-        }
+// Stores image words [0, nfull) to output dwords gbase + j (MSB-first bytes), clears them, and moves
+// image word `nfull` (the partial tail) to word 0.  Word 0 goes out with an atomic OR when it is the
+// seam with the previous wave-tile (`seam0`).  Wave-synchronous: LDS ops of one wave execute in order.
+__device__ __forceinline__ void flush_words(uint32_t *stage, uint32_t *out32, uint64_t gbase, uint32_t nfull,
+                                            bool seam0, uint32_t lane) {
+    const uint32_t tail = stage[nfull];
+    for (uint32_t j = lane; j < nfull; j += 64u) {
+        uint32_t v = __builtin_bswap32(stage[j]);
+        stage[j] = 0;
+        if (j == 0 && seam0) atomicOr(&out32[gbase], v);
+        else out32[gbase + j] = v;
     }
+    if (lane == 0) { stage[nfull] = 0; stage[0] = tail; }
 }
 
-__global__ __launch_bounds__(ENC_THREADS) void encode_kernel(EncParams p) {
+// Escape path of one sub-step (some code in the wave is longer than 12 bits): everything is recomputed
+// from the lane's 16 input bytes so that the hot path keeps no per-symbol state alive.  The sub-step
+// may carry up to 64 bits per symbol, so the image is filled and flushed in rounds.
+__device__ __forceinline__ void emit_substep_slow(const EmitParams &p, const uint16_t *tab, uint32_t *stage, uint32_t *out32,
+                                                  uint4 x, uint32_t pb, uint32_t nvalid, uint32_t lane, uint64_t off,
+                                                  uint64_t abs_bits, uint64_t &gbase, uint32_t &cur, bool &seam0,
+                                                  uint32_t &sub_bits_out) {
+    // opaque to the optimiser, so that nothing of the hot path is kept alive for this rare branch
+    asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w), "+v"(pb));
+    // rolling walk over the lane's bytes: no per-symbol arrays, a handful of registers
+    struct Roll {
+        uint4 x; uint32_t prev;
+        __device__ __forceinline__ uint32_t next_window() {
+            uint32_t sym = x.x & 255u;
+            uint32_t win = (sym << 8) | prev;
+            prev = sym;
+            x.x = __builtin_amdgcn_alignbyte(x.y, x.x, 1);
+            x.y = __builtin_amdgcn_alignbyte(x.z, x.y, 1);
+            x.z = __builtin_amdgcn_alignbyte(x.w, x.z, 1);
+            x.w >>= 8;
+            return win;
+        }
+    };
+    auto code_of = [&](uint32_t win, bool valid, uint32_t &l, uint64_t &c) {
+        uint32_t e = valid ? uint32_t(tab[mh::enc_slot(win)]) : 0u;
+        l = e >> 12;
+        c = e & 0xFFFu;
+        if (e >= 0xD000u) {
+            uint32_t nat = ((win & 255u) << 8) | (win >> 8);     // prev * 256 + sym
+            l = p.len8[nat];
+            c = p.code64[nat];
+            if (l > 64u) { l = 0; c = 0; }                       // rejected on the host
+        }
+    };
+    uint32_t L = 0;
+    {
+        Roll r{x, pb};
+#pragma unroll 1
+        for (uint32_t j = 0; j < 16; ++j) { uint32_t l; uint64_t c; code_of(r.next_window(), j < nvalid, l, c); L += l; }
+    }
+    uint32_t inc = L;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(inc, d);
+        if (lane >= uint32_t(d)) inc += t;
+    }
+    const uint32_t sub_bits = __shfl(inc, 63);
+    const uint32_t exc = inc - L;
+    const uint32_t S = 1u << p.chunk_shift;
+    if (p.index && nvalid && ((uint32_t(off) & (S - 1u)) == 0u))
+        p.index[off >> p.chunk_shift] = (uint64_t(pb) << 56) | (abs_bits + exc);
+
+    const uint32_t end = cur + sub_bits;     // image bit one past the sub-step (frame of this sub-step)
+    const uint32_t nwords = uint32_t(E_STAGE_WORDS - 2);
+    uint32_t wbase = 0;                       // frame word that stage[0] currently holds
+    for (;;) {
+        uint32_t o = cur + exc;
+        Roll r{x, pb};
+#pragma unroll 1
+        for (uint32_t j = 0; j < 16; ++j) {
+            uint32_t l; uint64_t c;
+            code_of(r.next_window(), j < nvalid, l, c);
+            if (l) deposit<true>(stage, c << (64u - l), o, wbase, nwords);
+            o += l;
+        }
+        uint32_t nfull = (end >> 5) - wbase;
+        const bool more = nfull > nwords - 1u;
+        if (more) nfull = nwords - 1u;        // keep one word as the moving tail
+        flush_words(stage, out32, gbase, nfull, seam0, lane);
+        seam0 = seam0 && nfull == 0;
+        gbase += nfull;
+        wbase += nfull;
+        if (!more) break;
+    }
+    cur = end & 31u;
+    sub_bits_out = sub_bits;
+}
+
+__global__ __launch_bounds__(E_THREADS) void enc_emit_kernel(EmitParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t *tab = reinterpret_cast<uint16_t *>(smem);
-    uint32_t *stage = reinterpret_cast<uint32_t *>(smem + 131072);
-    uint32_t *wagg = stage + ENC_STAGE_WORDS + 4;
-    uint32_t *chunk_off = wagg + ENC_WAVES;
-    uint32_t *chunk_prev = chunk_off + ENC_MAX_CPT;
-    uint32_t *sh = chunk_prev + ENC_MAX_CPT;   // [0]=tile [1]=abort [2..3]=s [4]=carry [5]=round carry
-    volatile uint32_t *vsh = sh;
-
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-
-    for (int i = tid; i < 8192; i += ENC_THREADS)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t *stage = reinterpret_cast<uint32_t *>(smem + 131072) + wave * E_STAGE_WORDS;
+    for (int i = threadIdx.x; i < 8192; i += E_THREADS)
         reinterpret_cast<uint4 *>(tab)[i] = reinterpret_cast<const uint4 *>(p.enc16)[i];
-    for (int i = tid; i < ENC_STAGE_WORDS + 4; i += ENC_THREADS) stage[i] = 0;
-    if (tid == 0) { sh[0] = atomicAdd(p.ticket, 1u); sh[1] = 0; }
+    for (int i = lane; i < E_STAGE_WORDS; i += 64) stage[i] = 0;
     __syncthreads();
+    if (*p.status != MHK_STATUS_OK) return;     // capacity overrun found by the scan: write nothing
 
+    uint32_t *out32 = reinterpret_cast<uint32_t *>(p.out);
     const uint32_t S = 1u << p.chunk_shift;
-    const uint32_t cpt = ENC_TILE >> p.chunk_shift;
-
-    for (;;) {
-        const uint32_t tile = vsh[0];
-        if (tile >= p.ntiles || vsh[1]) break;
-
-        // ---------------------------------------------------------------- phase A
-        const uint64_t off = uint64_t(tile) * ENC_TILE + uint64_t(tid) * ENC_SPL;
-        uint32_t lo = 0, hi = 0, nvalid = 0, pb = p.prev0;
-        if (off < p.n) {
-            uint64_t rem = p.n - off;
-            nvalid = rem >= ENC_SPL ? ENC_SPL : uint32_t(rem);
-            if (nvalid == ENC_SPL) {
-                uint2 v = *reinterpret_cast<const uint2 *>(p.data + off);
-                lo = v.x; hi = v.y;
-            } else {
-                for (uint32_t j = 0; j < nvalid; ++j) {
-                    uint32_t b = p.data[off + j];
-                    if (j < 4) lo |= b << (8 * j); else hi |= b << (8 * (j - 4));
-                }
-            }
-            if (off) pb = p.data[off - 1];
-        }
-        uint32_t win[ENC_SPL];
-        win[0] = ((lo << 8) | pb) & 0xFFFFu;
-        win[1] = lo & 0xFFFFu;
-        win[2] = (lo >> 8) & 0xFFFFu;
-        win[3] = lo >> 16;
-        win[4] = __builtin_amdgcn_alignbyte(hi, lo, 3) & 0xFFFFu;
-        win[5] = hi & 0xFFFFu;
-        win[6] = (hi >> 8) & 0xFFFFu;
-        win[7] = hi >> 16;
-        uint32_t ent[ENC_SPL];
-        bool esc = false;
+    const uint64_t wave0 = uint64_t(blockIdx.x) * E_WAVES + wave;
+    const uint64_t nwaves = uint64_t(gridDim.x) * E_WAVES;
+    for (uint64_t wt = wave0; wt < p.nwt; wt += nwaves) {
+        const uint64_t s = p.wt_start[wt];
+        uint64_t gbase = s >> 5;                 // output dword under image word 0
+        uint32_t cur = uint32_t(s & 31u);        // image bit where the next code goes
+        uint64_t abs_bits = s;                   // absolute bit offset of image bit `cur`
+        bool seam0 = cur != 0;                   // word 0 is shared with the previous wave-tile
+#pragma unroll 1
+        for (int k = 0; k < E_SUBSTEPS; ++k) {
+            const uint64_t off = wt * E_WT + uint64_t(k) * E_SUB + lane * E_VEC;
+            uint4 x; uint32_t pb, nvalid;
+            load_lane(p.data, p.n, off, p.prev0, x, pb, nvalid);
+            uint32_t L = 0;
+            uint64_t g[4]; uint32_t gl[4];
+            bool esc = false;
+            {
+                uint32_t w[16];
+                windows16(x, pb, w);
 #pragma unroll
-        for (int j = 0; j < ENC_SPL; ++j) {
-            ent[j] = (uint32_t(j) < nvalid) ? uint32_t(tab[mh::enc_slot(win[j])]) : 0u;
-            esc |= ent[j] >= 0xD000u;
-        }
-        const bool slow = __any(esc) != 0;     // wave-uniform
-
-        uint64_t g0 = 0, g1 = 0;               // fast path: two groups of four codes, right aligned
-        uint32_t gl0 = 0, gl1 = 0;
-        uint32_t slen[ENC_SPL];                // slow path: per-symbol codes
-        uint64_t scode[ENC_SPL];
-        uint32_t P;                            // (L << 7) | tail7 of this lane
-        if (!slow) {
-            uint32_t l[ENC_SPL], c[ENC_SPL];
+                for (int q = 0; q < 4; ++q) {
+                    uint32_t e[4];
 #pragma unroll
-            for (int j = 0; j < ENC_SPL; ++j) { l[j] = ent[j] >> 12; c[j] = ent[j] & 0xFFFu; }
-            uint32_t p01 = (c[0] << l[1]) | c[1], l01 = l[0] + l[1];
-            uint32_t p23 = (c[2] << l[3]) | c[3], l23 = l[2] + l[3];
-            uint32_t p45 = (c[4] << l[5]) | c[5], l45 = l[4] + l[5];
-            uint32_t p67 = (c[6] << l[7]) | c[7], l67 = l[6] + l[7];
-            g0 = (uint64_t(p01) << l23) | p23; gl0 = l01 + l23;
-            g1 = (uint64_t(p45) << l67) | p67; gl1 = l45 + l67;
-            uint32_t t0 = uint32_t(g0) & 127u, t1 = uint32_t(g1) & 127u;
-            uint32_t tail = gl1 >= 7 ? t1 : (((t0 << gl1) | t1) & 127u);
-            P = ((gl0 + gl1) << 7) | tail;
-        } else {
-            P = 0;
-#pragma unroll
-            for (int j = 0; j < ENC_SPL; ++j) {
-                uint32_t e = ent[j];
-                uint32_t l = e >> 12;
-                uint64_t c = e & 0xFFFu;
-                if (e >= 0xD000u) {
-                    uint32_t nat = ((win[j] & 255u) << 8) | (win[j] >> 8);   // prev * 256 + sym
-                    l = p.len8[nat];
-                    c = p.code64[nat];
-                    if (l > 64u) { l = 0; c = 0; }   // rejected on the host; keep the device safe
-                }
-                slen[j] = l; scode[j] = c;
-                uint32_t t = uint32_t(c) & 127u;     // c < 2^l, so for l < 7 this is the whole code
-                P = comb32(P, (l << 7) | t);
-            }
-        }
-        // inclusive wave scan of (L, tail7)
-        uint32_t inc = P;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t t = __shfl_up(inc, d);
-            if (lane >= uint32_t(d)) inc = comb32(t, inc);
-        }
-        uint32_t exc = __shfl_up(inc, 1);
-        if (lane == 0) exc = 0;
-        if (lane == 63) wagg[wave] = inc;
-        __syncthreads();                                                   // ---- barrier 1
-
-        // ---------------------------------------------------------------- phase B
-        uint32_t base = 0, tile_agg = 0;
-#pragma unroll
-        for (int w = 0; w < ENC_WAVES; ++w) {
-            uint32_t a = wagg[w];
-            if (uint32_t(w) < wave) base = comb32(base, a);
-            tile_agg = comb32(tile_agg, a);
-        }
-        const uint32_t my_off = (base >> 7) + (exc >> 7);    // tile-local bit offset of this lane
-        const uint32_t tile_bits = tile_agg >> 7;
-
-        if (wave == 0) {
-            // publish the aggregate, look back for the exclusive prefix, publish the inclusive prefix
-            uint64_t agg64 = widen(tile_agg);
-            uint64_t excl = p.seed & D_PAYLOAD;
-            bool timeout = false;
-            if (tile != 0) {
-                if (lane == 0) st_desc(&p.desc[tile], D_AGG | agg64);
-                excl = 0;
-                int64_t top = int64_t(tile) - 1;
-                for (;;) {
-                    int64_t mine = top - 63 + int64_t(lane);
-                    uint64_t v = D_PREFIX | (p.seed & D_PAYLOAD);      // virtual tile -1
-                    uint32_t spins = 0;
-                    for (;;) {
-                        if (mine >= 0) v = ld_desc(&p.desc[mine]);
-                        if (__all((v >> 62) != 0)) break;
-                        if (++spins > SPIN_LIMIT) { timeout = true; break; }
-                        __builtin_amdgcn_s_sleep(2);
+                    for (int j = 0; j < 4; ++j) {
+                        e[j] = (uint32_t(4 * q + j) < nvalid) ? uint32_t(tab[mh::enc_slot(w[4 * q + j])]) : 0u;
+                        esc |= e[j] >= 0xD000u;
                     }
-                    if (timeout) break;
-                    uint64_t pm = __ballot((v >> 62) == 2);
-                    int ptop = pm ? 63 - __builtin_clzll(pm) : -1;
-                    uint64_t x = (int(lane) >= ptop) ? (v & D_PAYLOAD) : 0ull;
-#pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) {
-                        uint64_t t = __shfl_up(x, d);
-                        if (lane >= uint32_t(d)) x = comb64(t, x);
-                    }
-                    uint64_t window = __shfl(x, 63);
-                    excl = comb64(window, excl);
-                    if (pm) break;
-                    top -= 64;
+                    uint32_t l0 = e[0] >> 12, l1 = e[1] >> 12, l2 = e[2] >> 12, l3 = e[3] >> 12;
+                    uint32_t p01 = ((e[0] & 0xFFFu) << l1) | (e[1] & 0xFFFu);
+                    uint32_t p23 = ((e[2] & 0xFFFu) << l3) | (e[3] & 0xFFFu);
+                    g[q] = (uint64_t(p01) << (l2 + l3)) | p23;
+                    gl[q] = l0 + l1 + l2 + l3;
+                    L += gl[q];
                 }
             }
-            if (lane == 0) {
-                if (timeout) {
-                    sh[1] = 1;
-                    atomicExch(p.status, MHK_STATUS_TIMEOUT);
-                } else {
-                    st_desc(&p.desc[tile], D_PREFIX | comb64(excl, agg64));
-                    sh[2] = uint32_t(excl & D_LMASK);
-                    sh[3] = uint32_t((excl & D_LMASK) >> 32);
-                    sh[4] = uint32_t(excl >> 55) & 127u;
-                }
-            }
-        }
-        // chunk index bookkeeping: the lane that starts a chunk records its offset and context
-        if ((tid * ENC_SPL & (S - 1u)) == 0u) {
-            uint32_t c = (tid * ENC_SPL) >> p.chunk_shift;
-            chunk_off[c] = my_off;
-            chunk_prev[c] = pb;
-        }
-
-        const uint32_t nrounds = tile_bits <= uint32_t(ENC_STAGE_BITS) ? 1u : (tile_bits + ENC_STAGE_BITS - 1) / ENC_STAGE_BITS;
-        for (uint32_t r = 0; r < nrounds; ++r) {
-            const uint32_t wbase = r * ENC_STAGE_WORDS;
-            if (!slow) {
-                // fast-path waves never exceed 12 bits/symbol, but the tile may still be in multi-round
-                // mode because of another wave: clip whenever nrounds > 1
-                if (nrounds == 1) {
-                    if (gl0) deposit<false>(stage, g0 << (64u - gl0), my_off, 0);
-                    if (gl1) deposit<false>(stage, g1 << (64u - gl1), my_off + gl0, 0);
-                } else {
-                    if (gl0) deposit<true>(stage, g0 << (64u - gl0), my_off, wbase);
-                    if (gl1) deposit<true>(stage, g1 << (64u - gl1), my_off + gl0, wbase);
-                }
+            uint32_t sub_bits;
+            if (__any(esc)) {                    // wave-uniform
+                emit_substep_slow(p, tab, stage, out32, x, pb, nvalid, lane, off, abs_bits, gbase, cur, seam0, sub_bits);
             } else {
-                uint32_t o = my_off;
+                // exclusive wave scan of the lane totals
+                uint32_t inc = L;
 #pragma unroll
-                for (int j = 0; j < ENC_SPL; ++j) {
-                    if (slen[j]) deposit<true>(stage, scode[j] << (64u - slen[j]), o, wbase);
-                    o += slen[j];
+                for (int d = 1; d < 64; d <<= 1) {
+                    uint32_t t = __shfl_up(inc, d);
+                    if (lane >= uint32_t(d)) inc += t;
                 }
-            }
-            __syncthreads();                                               // ---- barrier 2
-            if (vsh[1]) break;                                             // look-back timed out
-            const uint64_t s_tile = (uint64_t(vsh[3]) << 32) | vsh[2];
-            const uint32_t lr = (r + 1 == nrounds) ? tile_bits - r * ENC_STAGE_BITS : uint32_t(ENC_STAGE_BITS);
-            const uint64_t s_round = s_tile + uint64_t(r) * ENC_STAGE_BITS;
-            // round r > 0 continues from the previous round: its carry sits in slot 5 + ((r - 1) & 1)
-            const uint32_t carry = r == 0 ? vsh[4] : vsh[5u + ((r - 1u) & 1u)];
-            const bool last = (tile + 1 == p.ntiles) && (r + 1 == nrounds);
-            write_out(stage, p.out, p.cap, s_round, carry, lr, last);
-            if (r == 0 && p.index && tid < cpt) {
-                uint64_t ci = uint64_t(tile) * cpt + tid;
-                if ((ci << p.chunk_shift) < p.n)
-                    p.index[ci] = (uint64_t(chunk_prev[tid]) << 56) | (s_tile + chunk_off[tid]);
-            }
-            if (tid == 0) {
-                sh[5u + (r & 1u)] = stage[ENC_STAGE_WORDS - 1] & 127u;    // slot not read this round
-                if (last) {
-                    *p.nbits = s_tile + tile_bits;
-                    if (((s_tile + tile_bits + 7) >> 3) > p.cap) atomicExch(p.status, MHK_STATUS_CAPACITY);
+                sub_bits = __shfl(inc, 63);
+                const uint32_t exc = inc - L;
+                // chunk index: the lane whose first byte starts a chunk records (context, bit offset)
+                if (p.index && nvalid && ((uint32_t(off) & (S - 1u)) == 0u))
+                    p.index[off >> p.chunk_shift] = (uint64_t(pb) << 56) | (abs_bits + exc);
+                uint32_t o = cur + exc;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (gl[q]) deposit<false>(stage, g[q] << (64u - gl[q]), o, 0, 0);
+                    o += gl[q];
                 }
-                if (r + 1 == nrounds) sh[0] = atomicAdd(p.ticket, 1u);
+                const uint32_t nfull = (cur + sub_bits) >> 5;
+                flush_words(stage, out32, gbase, nfull, seam0, lane);
+                seam0 = seam0 && nfull == 0;
+                gbase += nfull;
+                cur = (cur + sub_bits) & 31u;
             }
-            __syncthreads();                                               // ---- barrier 3
-            for (int i = tid; i < ENC_STAGE_WORDS + 4; i += ENC_THREADS) stage[i] = 0;
-            if (r + 1 < nrounds) __syncthreads();                          // multi-round only
+            abs_bits += sub_bits;
+        }
+        // last partial dword of the wave-tile: seam with the next wave-tile (or the stream's end)
+        if (cur != 0 && lane == 0) {
+            atomicOr(&out32[gbase], __builtin_bswap32(stage[0]));
+            stage[0] = 0;
         }
     }
 }
@@ -492,64 +568,98 @@ struct BitSrc {
     }
 };
 
+// 64-bit window + one prefetched word: the load for the NEXT refill is always in flight, so a refill
+// never waits on memory.
 struct BitCursor {
     uint64_t buf;     // next bits, first at bit 63
     uint32_t cnt;     // valid bits in buf
+    uint32_t ahead;   // stream word `next - 1`, already loaded
     uint64_t next;    // next word index to fetch
     __device__ __forceinline__ void init(const BitSrc &src, uint64_t bitpos) {
         uint64_t w = bitpos >> 5;
         uint32_t sh = uint32_t(bitpos & 31u);
         buf = ((uint64_t(src.word(w)) << 32) | src.word(w + 1)) << sh;
         cnt = 64u - sh;
-        next = w + 2;
+        ahead = src.word(w + 2);
+        next = w + 3;
     }
+    // afterwards cnt >= 33
     __device__ __forceinline__ void refill(const BitSrc &src) {
         if (cnt <= 32u) {
-            buf |= uint64_t(src.word(next++)) << (32u - cnt);
+            buf |= uint64_t(ahead) << (32u - cnt);
             cnt += 32u;
+            ahead = src.word(next++);
         }
     }
+    __device__ __forceinline__ void drop(uint32_t n) { buf <<= n; cnt -= n; }
 };
 
-// Decodes one symbol; returns the symbol (0..255) or -1 on a corrupt stream.  *used = bits consumed.
-template <typename LutPtr>
-__device__ __forceinline__ int decode_one(LutPtr lut, const uint32_t *__restrict__ tree, const BitSrc &src,
-                                          BitCursor &bc, uint32_t prev, uint32_t *used) {
-    bc.refill(src);
+struct DecTables {
+    const uint16_t *sub16;       // second-level tables (HBM/L2)
+    const uint32_t *tree;        // last-resort walk (HBM/L2)
+    uint32_t sub_bits;
+};
+
+// Decodes one symbol.  Returns the symbol, or 0 with *bad set on a null table entry (corrupt
+// stream / context missing from the table).  *used accumulates the bits consumed.
+// LUT / BASE are LDS or global pointers (decode_kernel / build_index_kernel).
+template <typename LUT, typename BASE>
+__device__ __forceinline__ uint32_t decode_one(LUT lut, BASE sub_base, const DecTables &t, const BitSrc &src,
+                                               BitCursor &bc, uint32_t prev, uint32_t &used, bool &bad) {
+    bc.refill(src);                                        // >= 33 bits: enough for 8 + sub_bits
     uint32_t e = lut[(prev << 8) | uint32_t(bc.buf >> 56)];
-    if (e == 0) return -1;
-    if (!(e & DEC16_INNER)) {
+    if (!(e & DEC16_INNER)) {                              // code of <= 8 bits (src/coding.cpp:150-156)
         uint32_t len = e >> 8;
-        bc.buf <<= len; bc.cnt -= len; *used = len;
-        return int(e & 255u);
+        bad |= (e == 0);
+        bc.drop(len); used += len;
+        return e & 255u;
     }
-    // code longer than 8 bits: consume the window, then walk the context's tree bit by bit
-    uint32_t node = e & 0x1FFu, n = 8;
-    bc.buf <<= 8; bc.cnt -= 8;
-    const uint32_t *t = tree + prev * TREE_STRIDE;
+    // code longer than 8 bits (src/coding.cpp:129-149): consume the window, then ONE second-level
+    // lookup on the next sub_bits bits
+    bc.drop(8);
+    uint32_t idx = ((sub_base[prev] + (e & 255u)) << t.sub_bits) | uint32_t(bc.buf >> (64u - t.sub_bits));
+    uint32_t e2 = t.sub16[idx];
+    if (!(e2 & DEC16_INNER)) {
+        uint32_t len = e2 >> 8;
+        bad |= (e2 == 0);
+        bc.drop(len); used += 8u + len;
+        return e2 & 255u;
+    }
+    // longer than 8 + sub_bits: walk the context's tree bit by bit from that node
+    bc.drop(t.sub_bits);
+    uint32_t node = e2 & 0x1FFu, n = 8u + t.sub_bits;
+    const uint32_t *tr = t.tree + prev * TREE_STRIDE;
     for (int guard = 0; guard < 256; ++guard) {
         bc.refill(src);
         uint32_t bit = uint32_t(bc.buf >> 63);
-        bc.buf <<= 1; bc.cnt -= 1; ++n;
-        uint32_t pair = t[node];
+        bc.drop(1); ++n;
+        uint32_t pair = tr[node];
         uint32_t c = bit ? (pair >> 16) : (pair & 0xFFFFu);
-        if (c & TREE_LEAF) { *used = n; return int(c & 255u); }
+        if (c & TREE_LEAF) { used += n; return c & 255u; }
         node = c;
     }
-    return -1;
+    bad = true;
+    used += n;
+    return 0;
 }
 
+// One workgroup per CU (the 256 8-bit LUTs take 128 KiB of LDS), one lane per chunk, consecutive lanes
+// on consecutive chunks.  Each lane streams its chunk: 64-bit bit window fed by dword loads that stay
+// one word ahead, LDS LUT per symbol, 16 decoded bytes per 16-byte store.
 constexpr int DEC_THREADS = 1024;
-constexpr int DEC_LDS_BYTES = 131072;
+constexpr int DEC_LDS_BYTES = 131072 + 1024;
 
 __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t *lut = reinterpret_cast<uint16_t *>(smem);
+    uint32_t *sub_base = reinterpret_cast<uint32_t *>(smem + 131072);
     for (int i = threadIdx.x; i < 8192; i += DEC_THREADS)
         reinterpret_cast<uint4 *>(lut)[i] = reinterpret_cast<const uint4 *>(p.dec16)[i];
+    if (threadIdx.x < 256) sub_base[threadIdx.x] = p.sub_base[threadIdx.x];
     __syncthreads();
 
     const BitSrc src{p.payload, p.payload_bytes >> 2, p.payload_bytes};
+    const DecTables tabs{p.sub16, p.tree, p.sub_bits};
     const uint32_t S = 1u << p.chunk_shift;
     for (uint64_t chunk = uint64_t(blockIdx.x) * DEC_THREADS + threadIdx.x; chunk < p.nchunks;
          chunk += uint64_t(gridDim.x) * DEC_THREADS) {
@@ -562,50 +672,53 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecParams p) {
         BitCursor bc;
         bc.init(src, bitpos);
         uint8_t *o = p.out + first;
-        uint32_t packed = 0;
         bool bad = false;
-        for (uint32_t i = 0; i < nsym; ++i) {
-            uint32_t used;
-            int sym = decode_one(lut, p.tree, src, bc, prev, &used);
-            if (sym < 0) { bad = true; break; }
-            prev = uint32_t(sym);
-            packed |= uint32_t(sym) << (8u * (i & 3u));
-            if ((i & 3u) == 3u) {
-                *reinterpret_cast<uint32_t *>(o + i - 3u) = packed;
-                packed = 0;
+        uint32_t used = 0;
+        const uint32_t nblk = nsym >> 4;
+        for (uint32_t blk = 0; blk < nblk; ++blk) {
+            uint32_t q[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                prev = decode_one(lut, sub_base, tabs, src, bc, prev, used, bad);
+                q[j >> 2] |= prev << (8 * (j & 3));
             }
+            reinterpret_cast<uint4 *>(o)[blk] = make_uint4(q[0], q[1], q[2], q[3]);
         }
-        if (bad) { atomicExch(p.status, MHK_STATUS_CORRUPT); continue; }
-        for (uint32_t i = nsym & ~3u; i < nsym; ++i) o[i] = uint8_t(packed >> (8u * (i & 3u)));
+        for (uint32_t i = nblk << 4; i < nsym; ++i) {          // ragged tail of the last chunk
+            prev = decode_one(lut, sub_base, tabs, src, bc, prev, used, bad);
+            o[i] = uint8_t(prev);
+        }
+        if (bad || bitpos + used > p.nbits) atomicExch(p.status, MHK_STATUS_CORRUPT);
     }
 }
 
-// Sequential pass over a stream that has no index (one produced by the reference, src/coding.cpp
+// Sequential pass over a stream that has no index (one produced by the reference: src/coding.cpp
 // has none): walks the whole payload once on one lane, recording (bit offset, context) every
 // chunk_symbols symbols and the total symbol count.  The loop condition is the reference's
 // `while(bi < length)` (src/coding.cpp:124).
 __global__ void build_index_kernel(IdxParams p) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     const BitSrc src{p.payload, p.payload_bytes >> 2, p.payload_bytes};
+    const DecTables tabs{p.sub16, p.tree, p.sub_bits};
     BitCursor bc;
     bc.init(src, 0);
     uint64_t bi = 0, nsym = 0;
     uint32_t prev = p.prev0;
     const uint64_t S = 1ull << p.chunk_shift;
+    bool bad = false;
     while (bi < p.nbits) {
         if ((nsym & (S - 1)) == 0) {
             uint64_t ci = nsym >> p.chunk_shift;
             if (ci >= p.index_cap) { atomicExch(p.status, MHK_STATUS_CAPACITY); break; }
             p.index[ci] = (uint64_t(prev) << 56) | bi;
         }
-        uint32_t used;
-        int sym = decode_one(p.dec16, p.tree, src, bc, prev, &used);
-        if (sym < 0) { atomicExch(p.status, MHK_STATUS_CORRUPT); break; }
-        prev = uint32_t(sym);
+        uint32_t used = 0;
+        prev = decode_one(p.dec16, p.sub_base, tabs, src, bc, prev, used, bad);
+        if (bad) break;
         bi += used;
         ++nsym;
     }
-    if (bi > p.nbits) atomicExch(p.status, MHK_STATUS_CORRUPT);
+    if (bad || bi > p.nbits) atomicExch(p.status, MHK_STATUS_CORRUPT);
     *p.n_symbols = nsym;
 }
 
@@ -650,28 +763,54 @@ hipError_t launch_hist_o0(const uint8_t *d_data, uint64_t n, unsigned long long 
     return hipGetLastError();
 }
 
-uint64_t encode_tiles(uint64_t n) { return (n + ENC_TILE - 1) / ENC_TILE; }
+uint64_t encode_wave_tiles(uint64_t n) { return (n + E_WT - 1) / E_WT; }
 
-size_t encode_workspace_bytes(uint64_t n) {
-    // [0,64): status(int) + ticket(u32) + pad ; then one descriptor per tile
-    return 64 + size_t(encode_tiles(n)) * 8 + 64;
+// workspace: [0,64) status | wt_bits u32[nwt] | wt_start u64[nwt] | blk_sum u64[nblk + 1]
+struct EncWs { size_t off_bits, off_start, off_blk, total; uint64_t nwt, nblk; };
+static EncWs enc_ws_layout(uint64_t n) {
+    EncWs w;
+    w.nwt = encode_wave_tiles(n);
+    w.nblk = (w.nwt + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    auto up = [](size_t v) { return (v + 63) & ~size_t(63); };
+    w.off_bits = 64;
+    w.off_start = up(w.off_bits + size_t(w.nwt) * 4);
+    w.off_blk = up(w.off_start + size_t(w.nwt) * 8);
+    w.total = up(w.off_blk + size_t(w.nblk + 1) * 8);
+    return w;
 }
+size_t encode_workspace_bytes(uint64_t n) { return enc_ws_layout(n).total; }
 
-hipError_t launch_encode(EncParams p, void *d_ws, hipStream_t st) {
-    // workspace layout: see encode_workspace_bytes
+hipError_t launch_encode(const EncodeArgs &a, void *d_ws, hipStream_t st) {
     unsigned char *ws = static_cast<unsigned char *>(d_ws);
-    p.status = reinterpret_cast<int *>(ws);
-    p.ticket = reinterpret_cast<unsigned int *>(ws + 4);
-    p.desc = reinterpret_cast<unsigned long long *>(ws + 64);
-    p.ntiles = uint32_t(encode_tiles(p.n));
-    hipError_t e = hipMemsetAsync(ws, 0, 64 + size_t(p.ntiles) * 8, st);
+    const EncWs L = enc_ws_layout(a.n);
+    int *status = reinterpret_cast<int *>(ws);
+    hipError_t e = hipMemsetAsync(ws, 0, 64, st);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(p.nbits, 0, 8, st);
-    if (e != hipSuccess || p.n == 0) return e;
+    if (a.n == 0) return hipMemsetAsync(a.nbits, 0, 8, st);
     static bool once = false;
-    if (!once) { e = allow_lds(reinterpret_cast<const void *>(encode_kernel), ENC_LDS_BYTES); if (e != hipSuccess) return e; once = true; }
-    int grid = int(p.ntiles < uint32_t(cu_count()) ? p.ntiles : uint32_t(cu_count()));
-    hipLaunchKernelGGL(encode_kernel, dim3(grid), dim3(ENC_THREADS), ENC_LDS_BYTES, st, p);
+    if (!once) {
+        e = allow_lds(reinterpret_cast<const void *>(enc_len_kernel), LEN_LDS_BYTES); if (e != hipSuccess) return e;
+        e = allow_lds(reinterpret_cast<const void *>(enc_emit_kernel), EMIT_LDS_BYTES); if (e != hipSuccess) return e;
+        once = true;
+    }
+    uint32_t *wt_bits = reinterpret_cast<uint32_t *>(ws + L.off_bits);
+    unsigned long long *wt_start = reinterpret_cast<unsigned long long *>(ws + L.off_start);
+    unsigned long long *blk_sum = reinterpret_cast<unsigned long long *>(ws + L.off_blk);
+
+    LenParams lp{a.data, a.n, a.prev0, a.len_slot, wt_bits, L.nwt};
+    uint64_t want = (L.nwt + E_WAVES - 1) / E_WAVES;
+    int grid = int(want > uint64_t(2 * cu_count()) ? uint64_t(2 * cu_count()) : want);
+    hipLaunchKernelGGL(enc_len_kernel, dim3(grid), dim3(E_THREADS), LEN_LDS_BYTES, st, lp);
+
+    hipLaunchKernelGGL(scan_local_kernel, dim3(unsigned(L.nblk)), dim3(SCAN_THREADS), 0, st, wt_bits, L.nwt, wt_start, blk_sum);
+    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, blk_sum, L.nblk);
+    // the emit pass stores whole dwords: only the 4-byte-aligned part of the buffer counts as capacity
+    ScanParams sp{wt_start, blk_sum, L.nwt, L.nblk, a.out, a.cap & ~uint64_t(3), a.nbits, status};
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(unsigned(L.nblk)), dim3(SCAN_THREADS), 0, st, sp);
+
+    EmitParams ep{a.data, a.n, a.prev0, a.chunk_shift, a.out, a.enc16, a.len8, a.code64, wt_start, L.nwt, a.index, status};
+    grid = int(want > uint64_t(cu_count()) ? uint64_t(cu_count()) : want);
+    hipLaunchKernelGGL(enc_emit_kernel, dim3(grid), dim3(E_THREADS), EMIT_LDS_BYTES, st, ep);
     return hipGetLastError();
 }
 

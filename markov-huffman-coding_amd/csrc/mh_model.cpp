@@ -204,30 +204,52 @@ bool ContextCoder::load(BitReader &in) {
     return true;
 }
 
-void ContextCoder::pack_decode(uint16_t *dec, uint32_t *tree) const {
+int ContextCoder::pack_decode(uint16_t *dec, uint32_t *tree, std::vector<uint16_t> &sub, int sub_bits) const {
     for (int i = 0; i < 256; ++i) dec[i] = 0;
     for (int i = 0; i < TREE_STRIDE; ++i) tree[i] = 0;
-    if (root_ < 0) return;
-    // number inner nodes in visiting order, root = 0
+    if (root_ < 0) return 0;
+    // number inner nodes for the walk, root = 0
     std::vector<int> id(nodes_.size(), -1);
-    int next = 0;
+    int next = 1;
     for (size_t i = 0; i < nodes_.size(); ++i)
-        if (!nodes_[i].leaf) id[i] = (int(i) == root_) ? 0 : -2;
-    next = 1;
-    for (size_t i = 0; i < nodes_.size(); ++i)
-        if (id[i] == -2) id[i] = next++;
+        if (!nodes_[i].leaf) id[i] = (int(i) == root_) ? 0 : next++;
     auto enc_child = [&](int c) -> uint32_t {
         return nodes_[c].leaf ? (TREE_LEAF | nodes_[c].sym) : uint32_t(id[c]);
     };
     for (size_t i = 0; i < nodes_.size(); ++i)
         if (!nodes_[i].leaf)
             tree[id[i]] = (enc_child(nodes_[i].child[1]) << 16) | enc_child(nodes_[i].child[0]);
+    int ninner8 = 0;
     for (int w = 0; w < 256; ++w) {
         int n = lut_[w];
         if (n < 0) continue;
-        dec[w] = nodes_[n].leaf ? uint16_t((nodes_[n].depth << 8) | nodes_[n].sym)
-                                : uint16_t(DEC16_INNER | id[n]);
+        if (nodes_[n].leaf) {
+            dec[w] = uint16_t((nodes_[n].depth << 8) | nodes_[n].sym);
+            continue;
+        }
+        dec[w] = uint16_t(DEC16_INNER | ninner8++);
+        // second-level table of this depth-8 node: every path of sub_bits further bits
+        size_t base = sub.size();
+        sub.resize(base + (size_t(1) << sub_bits), 0);
+        struct Item { int node; int depth; uint32_t path; };
+        std::vector<Item> stack{{n, 0, 0}};
+        while (!stack.empty()) {
+            Item it = stack.back();
+            stack.pop_back();
+            const Node &nd = nodes_[it.node];
+            if (nd.leaf) {
+                uint32_t lo = it.path << (sub_bits - it.depth);
+                for (uint32_t k = 0; k < (1u << (sub_bits - it.depth)); ++k)
+                    sub[base + lo + k] = uint16_t((it.depth << 8) | nd.sym);
+            } else if (it.depth == sub_bits) {
+                sub[base + it.path] = uint16_t(DEC16_INNER | id[it.node]);
+            } else {
+                stack.push_back({nd.child[1], it.depth + 1, (it.path << 1) | 1u});
+                stack.push_back({nd.child[0], it.depth + 1, it.path << 1});
+            }
+        }
     }
+    return ninner8;
 }
 
 int Model::max_code_len() const {
@@ -281,13 +303,24 @@ Model::Packed Model::pack() const {
     Packed pk;
     pk.enc16.assign(65536, 0);
     pk.len8.assign(65536, 0);
+    pk.len_slot.assign(65536, 0);
     pk.code64.assign(65536, 0);
     pk.dec16.assign(65536, 0);
     pk.tree.assign(256 * TREE_STRIDE, 0);
     pk.max_len = max_code_len();
+    pk.sub_bits = std::min(std::max(pk.max_len - 8, 1), SUB_BITS_MAX);
+    pk.sub_base.assign(256, 0);
+    uint32_t nsub = 0;
     for (int prev = 0; prev < 256; ++prev) {
         const ContextCoder &c = context(prev);
-        c.pack_decode(&pk.dec16[prev * 256], &pk.tree[prev * TREE_STRIDE]);
+        if (type == 0 && prev > 0) {
+            // one table replicated over all contexts: share context 0's second-level tables
+            std::vector<uint16_t> scratch;
+            c.pack_decode(&pk.dec16[prev * 256], &pk.tree[prev * TREE_STRIDE], scratch, pk.sub_bits);
+        } else {
+            pk.sub_base[prev] = nsub;
+            nsub += uint32_t(c.pack_decode(&pk.dec16[prev * 256], &pk.tree[prev * TREE_STRIDE], pk.sub16, pk.sub_bits));
+        }
         for (int sym = 0; sym < 256; ++sym) {
             const Code &cd = c.code(sym);
             uint32_t window = uint32_t(sym) << 8 | uint32_t(prev);
@@ -299,6 +332,7 @@ Model::Packed Model::pack() const {
                 e = uint16_t((cd.len << 12) | uint32_t(cd.right_aligned()));
             }
             pk.enc16[enc_slot(window)] = e;
+            pk.len_slot[enc_slot(window)] = uint8_t(std::min(cd.len, 255));
             pk.len8[prev * 256 + sym] = uint8_t(std::min(cd.len, 255));
             pk.code64[prev * 256 + sym] = cd.len <= 64 ? cd.right_aligned() : 0;
         }

@@ -29,9 +29,15 @@ constexpr uint32_t enc_slot(uint32_t window) { return (window ^ (window >> 8)) &
 // Decode LUT, LDS-resident: 65536 x u16 indexed prev << 8 | next-8-stream-bits.
 //   0                      null (empty context)
 //   leaf   : len(1..8) << 8 | symbol
-//   inner  : 0x8000 | internal-node id (node stored at depth 8, src/huffman.cpp:111-113)
+//   inner  : 0x8000 | k, k = rank of this depth-8 internal node among the context's depth-8
+//            internal nodes (the node stored by src/huffman.cpp:111-113)
 constexpr uint16_t DEC16_INNER = 0x8000;
-// Fallback tree in HBM/L2: per context 256 x u32 = right << 16 | left; a child is
+// Second-level tables in HBM/L2 (one L2 access instead of a bit-serial walk): for the k-th depth-8
+// internal node of context c, 2^sub_bits entries at ((sub_base[c] + k) << sub_bits), indexed by the
+// next sub_bits stream bits:  leaf: extra_len(1..sub_bits) << 8 | symbol;
+//                              inner (code longer than 8 + sub_bits): 0x8000 | tree node id.
+constexpr int SUB_BITS_MAX = 8;
+// Last-resort tree in HBM/L2: per context 256 x u32 = right << 16 | left; a child is
 // 0x8000 | symbol for a leaf, else the internal-node id (0 = root).
 constexpr uint32_t TREE_LEAF = 0x8000;
 constexpr int TREE_STRIDE = 256;
@@ -71,8 +77,9 @@ public:
     const Node &node(int i) const { return nodes_[i]; }
     int root() const { return root_; }
     int max_len() const { return max_len_; }
-    // packed device images for this context
-    void pack_decode(uint16_t *dec256, uint32_t *tree256) const;
+    // packed device images for this context; appends this context's second-level tables to `sub`
+    // and returns how many (= number of depth-8 internal nodes)
+    int pack_decode(uint16_t *dec256, uint32_t *tree256, std::vector<uint16_t> &sub, int sub_bits) const;
 
 private:
     void derive_tables();
@@ -131,9 +138,13 @@ public:
     struct Packed {
         std::vector<uint16_t> enc16;     // 65536, slot order (enc_slot)
         std::vector<uint8_t> len8;       // 65536, prev*256+sym
+        std::vector<uint8_t> len_slot;   // 65536, slot order: code length (0..64) for the length pass
         std::vector<uint64_t> code64;    // 65536, prev*256+sym, right aligned
         std::vector<uint16_t> dec16;     // 65536, prev*256+w
         std::vector<uint32_t> tree;      // 256*TREE_STRIDE
+        std::vector<uint16_t> sub16;     // second-level tables, (#depth-8 inner nodes) << sub_bits entries
+        std::vector<uint32_t> sub_base;  // 256: index of each context's first second-level table
+        int sub_bits = 1;
         int max_len = 0;
         bool any_escape = false;
     };
