@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-CHUNK = 1024
+CHUNK = int(os.environ.get("MH_BENCH_CHUNK", "1024"))
 
 
 def zipf_cdf(device, s=1.1):
@@ -271,6 +271,8 @@ def main():
             "kernel_roofline_frac": {k: round(b / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if t > 0 else None for k, (b, t) in kernels.items()},
             "encode_read_roofline_frac": round(n / (ms["encode"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms["encode"] > 0 else None,
             "compressed_ratio": round(r, 5), "round_trip_bit_exact": round_trip_all,
+            "max_code_len": model.max_code_len,
+            "decode_tables": dict(zip(("primary_bits", "secondary_entries", "in_lds"), model.decode_layout())),
         }
         if world == 1 and not args.no_cpu_baseline:
             sample_n = min(args.cpu_sample, n) & ~(CHUNK - 1)

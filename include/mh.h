@@ -96,6 +96,11 @@ int mh_model_get_code(const mh_model *m, int prev, int sym, int *len, uint64_t *
 /* decoding_lookup(prev, w) (src/markov_huffman.cpp:56-58 -> src/huffman.cpp:87-89): the 8-bit-window
  * LUT entry.  *present == 0 for a null entry (empty context). */
 int mh_model_get_lut(const mh_model *m, int prev, int w, int *present, int *is_internal, int *value, int *depth);
+/* How the decode tables of this model are laid out on the device: *primary_bits = width P of the
+ * first-level window (8 = the reference's own 8-bit LUT, src/huffman.cpp:97-123; narrower when that
+ * is what makes both table levels fit LDS), *secondary_entries = second-level entries,
+ * *in_lds = 1 when both levels are LDS-resident in the decode kernel. */
+int mh_model_decode_layout(const mh_model *m, int *primary_bits, int *secondary_entries, int *in_lds);
 void mh_model_free(mh_model *m);
 
 /* ------------------------------------------------------------- chunk index */

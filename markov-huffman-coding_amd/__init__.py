@@ -27,7 +27,8 @@ INDEX_BIT_MASK = 0x00FFFFFFFFFFFFFF
 EXPORTS = [
     "mh_strerror", "mh_last_hip_error", "mh_device_count", "mh_set_device",
     "mh_model_from_counts", "mh_dev_model_from_counts", "mh_model_from_table_bits", "mh_model_write_table",
-    "mh_model_type", "mh_model_max_code_len", "mh_model_get_code", "mh_model_get_lut", "mh_model_free",
+    "mh_model_type", "mh_model_max_code_len", "mh_model_get_code", "mh_model_get_lut", "mh_model_decode_layout",
+    "mh_model_free",
     "mh_histogram_o1", "mh_histogram_o0", "mh_encode", "mh_encode_bound", "mh_stream_header",
     "mh_stream_parse_header", "mh_decode",
     "mh_dev_histogram_workspace", "mh_dev_histogram_o1", "mh_dev_histogram_o0",
@@ -66,6 +67,7 @@ def lib():
         l.mh_model_max_code_len.argtypes = [vp]
         l.mh_model_get_code.argtypes = [vp, i32, i32, pi, pu64]
         l.mh_model_get_lut.argtypes = [vp, i32, i32, pi, pi, pi, pi]
+        l.mh_model_decode_layout.argtypes = [vp, pi, pi, pi]
         l.mh_model_free.argtypes = [vp]
         l.mh_model_free.restype = None
         l.mh_histogram_o1.argtypes = [vp, sz, u8, vp]
@@ -175,6 +177,12 @@ class Model:
     @property
     def max_code_len(self):
         return lib().mh_model_max_code_len(self._h)
+
+    def decode_layout(self):
+        """(primary_bits, secondary_entries, in_lds) of the device decode tables."""
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        _check(lib().mh_model_decode_layout(self._h, C.byref(a), C.byref(b), C.byref(c)), "mh_model_decode_layout")
+        return a.value, b.value, bool(c.value)
 
     def table_bytes(self):
         n = C.c_size_t(0)

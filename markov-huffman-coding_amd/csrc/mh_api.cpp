@@ -21,10 +21,10 @@ struct mh_model {
     uint8_t *d_len8 = nullptr;
     uint8_t *d_len_slot = nullptr;
     uint64_t *d_code64 = nullptr;
-    uint16_t *d_dec16 = nullptr;
+    uint16_t *d_prim = nullptr;
+    uint16_t *d_sec = nullptr;
+    uint32_t *d_sec_base = nullptr;
     uint32_t *d_tree = nullptr;
-    uint16_t *d_sub16 = nullptr;
-    uint32_t *d_sub_base = nullptr;
 };
 
 namespace {
@@ -86,20 +86,22 @@ int upload_model(mh_model *m) {
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_enc16), 65536 * 2));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_len8), 65536));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_code64), 65536 * 8));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_dec16), 65536 * 2));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_tree), 256 * mh::TREE_STRIDE * 4));
     HIP_TRY(hipMemcpy(m->d_enc16, pk.enc16.data(), 65536 * 2, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(m->d_len8, pk.len8.data(), 65536, hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_len_slot), 65536));
     HIP_TRY(hipMemcpy(m->d_len_slot, pk.len_slot.data(), 65536, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(m->d_code64, pk.code64.data(), 65536 * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(m->d_dec16, pk.dec16.data(), 65536 * 2, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(m->d_tree, pk.tree.data(), 256 * mh::TREE_STRIDE * 4, hipMemcpyHostToDevice));
-    size_t sub_bytes = pk.sub16.size() * 2;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_sub16), sub_bytes ? sub_bytes : 16));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_sub_base), 256 * 4));
-    if (sub_bytes) HIP_TRY(hipMemcpy(m->d_sub16, pk.sub16.data(), sub_bytes, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(m->d_sub_base, pk.sub_base.data(), 256 * 4, hipMemcpyHostToDevice));
+    const size_t prim_bytes = pk.dec_prim.size() * 2;
+    const size_t sec_bytes = (pk.dec_sec.size() * 2 + 15) & ~size_t(15);     // kernels copy whole uint4s
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_prim), prim_bytes));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_sec), sec_bytes ? sec_bytes : 16));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_sec_base), 256 * 4));
+    HIP_TRY(hipMemcpy(m->d_prim, pk.dec_prim.data(), prim_bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(m->d_sec, 0, sec_bytes ? sec_bytes : 16));
+    if (!pk.dec_sec.empty()) HIP_TRY(hipMemcpy(m->d_sec, pk.dec_sec.data(), pk.dec_sec.size() * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(m->d_sec_base, pk.sec_base.data(), 256 * 4, hipMemcpyHostToDevice));
     return MH_OK;
 }
 
@@ -208,16 +210,24 @@ int mh_model_get_lut(const mh_model *m, int prev, int w, int *present, int *is_i
     return MH_OK;
 }
 
+int mh_model_decode_layout(const mh_model *m, int *primary_bits, int *secondary_entries, int *in_lds) {
+    if (!m || !primary_bits || !secondary_entries || !in_lds) return MH_ERR_ARG;
+    *primary_bits = m->packed.dec_bits;
+    *secondary_entries = int(m->packed.dec_sec.size());
+    *in_lds = m->packed.dec_lds ? 1 : 0;
+    return MH_OK;
+}
+
 void mh_model_free(mh_model *m) {
     if (!m) return;
     if (m->d_enc16) (void)hipFree(m->d_enc16);
     if (m->d_len8) (void)hipFree(m->d_len8);
     if (m->d_len_slot) (void)hipFree(m->d_len_slot);
     if (m->d_code64) (void)hipFree(m->d_code64);
-    if (m->d_dec16) (void)hipFree(m->d_dec16);
+    if (m->d_prim) (void)hipFree(m->d_prim);
+    if (m->d_sec) (void)hipFree(m->d_sec);
+    if (m->d_sec_base) (void)hipFree(m->d_sec_base);
     if (m->d_tree) (void)hipFree(m->d_tree);
-    if (m->d_sub16) (void)hipFree(m->d_sub16);
-    if (m->d_sub_base) (void)hipFree(m->d_sub_base);
     delete m;
 }
 
@@ -268,15 +278,15 @@ int mh_dev_decode(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, u
     int shift = chunk_shift_of(chunk_symbols);
     if (shift < 0) return MH_ERR_ARG;
     if (m->packed.max_len > mh::MAX_CODE_BITS) return MH_ERR_CODE_TOO_LONG;
-    if (!m->d_dec16) return MH_ERR_NO_DEVICE;
+    if (!m->d_prim) return MH_ERR_NO_DEVICE;
     mhk::DecParams p{};
     p.payload = d_payload; p.payload_bytes = (nbits + 7) / 8; p.nbits = nbits;
     p.out = d_out; p.n = n_symbols;
     p.index = reinterpret_cast<const unsigned long long *>(d_index);
     p.nchunks = mh_index_entries(n_symbols, chunk_symbols);
     p.chunk_shift = uint32_t(shift);
-    p.dec16 = m->d_dec16; p.tree = m->d_tree;
-    p.sub16 = m->d_sub16; p.sub_base = m->d_sub_base; p.sub_bits = uint32_t(m->packed.sub_bits);
+    p.prim = m->d_prim; p.sec = m->d_sec; p.sec_base = m->d_sec_base; p.tree = m->d_tree;
+    p.P = uint32_t(m->packed.dec_bits); p.nsec = uint32_t(m->packed.dec_sec.size()); p.sec_lds = m->packed.dec_lds ? 1u : 0u;
     HIP_TRY(mhk::launch_decode(p, d_ws, static_cast<hipStream_t>(stream)));
     return MH_OK;
 }
@@ -287,14 +297,14 @@ int mh_dev_build_index(const mh_model *m, const uint8_t *d_payload, uint64_t nbi
     int shift = chunk_shift_of(chunk_symbols);
     if (shift < 0 || !aligned16(d_payload)) return MH_ERR_ARG;
     if (m->packed.max_len > mh::MAX_CODE_BITS) return MH_ERR_CODE_TOO_LONG;
-    if (!m->d_dec16) return MH_ERR_NO_DEVICE;
+    if (!m->d_prim) return MH_ERR_NO_DEVICE;
     mhk::IdxParams p{};
     p.payload = d_payload; p.payload_bytes = (nbits + 7) / 8; p.nbits = nbits;
     p.prev0 = prev0; p.chunk_shift = uint32_t(shift);
     p.index = reinterpret_cast<unsigned long long *>(d_index); p.index_cap = index_cap;
     p.n_symbols = reinterpret_cast<unsigned long long *>(d_n_symbols);
-    p.dec16 = m->d_dec16; p.tree = m->d_tree;
-    p.sub16 = m->d_sub16; p.sub_base = m->d_sub_base; p.sub_bits = uint32_t(m->packed.sub_bits);
+    p.prim = m->d_prim; p.sec = m->d_sec; p.sec_base = m->d_sec_base; p.tree = m->d_tree;
+    p.P = uint32_t(m->packed.dec_bits);
     HIP_TRY(mhk::launch_build_index(p, d_ws, static_cast<hipStream_t>(stream)));
     return MH_OK;
 }

@@ -69,11 +69,13 @@ struct DecParams {
     const unsigned long long *index;
     uint64_t nchunks;
     uint32_t chunk_shift;
-    const uint16_t *dec16;        // 65536, prev*256+window
+    const uint16_t *prim;         // 256 << P entries (mh_model.hpp)
+    const uint16_t *sec;          // nsec second-level entries, buffer padded to 16 bytes
+    const uint32_t *sec_base;     // 256
     const uint32_t *tree;         // 256 * TREE_STRIDE
-    const uint16_t *sub16;        // second-level tables
-    const uint32_t *sub_base;     // 256
-    uint32_t sub_bits;
+    uint32_t P;
+    uint32_t nsec;
+    uint32_t sec_lds;             // 1: prim + sec fit LDS
     int *status;
 };
 
@@ -86,11 +88,11 @@ struct IdxParams {
     unsigned long long *index;
     uint64_t index_cap;
     unsigned long long *n_symbols;
-    const uint16_t *dec16;
+    const uint16_t *prim;
+    const uint16_t *sec;
+    const uint32_t *sec_base;
     const uint32_t *tree;
-    const uint16_t *sub16;
-    const uint32_t *sub_base;
-    uint32_t sub_bits;
+    uint32_t P;
     int *status;
 };
 

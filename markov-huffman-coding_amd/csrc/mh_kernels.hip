@@ -28,6 +28,17 @@ using mh::TREE_STRIDE;
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
+// 16-byte accesses with the non-temporal hint (data touched once: do not keep it in the vector L1)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld_stream16(const uint4 *p) {
+    u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st_stream16(uint4 *p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    u32x4 v = {a, b, c, d};
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p));
+}
+
 // (L, tail7) monoid: L = bit length of a run of codewords, tail = its last min(7, L) bits, right
 // aligned.  combine(a, b) describes the concatenation a||b.  Identity = 0.
 // 32-bit packing (inside a tile): L << 7 | tail.       L < 2^25
@@ -595,39 +606,37 @@ struct BitCursor {
 };
 
 struct DecTables {
-    const uint16_t *sub16;       // second-level tables (HBM/L2)
+    const uint16_t *sec;         // second-level tables (LDS when they fit, else HBM/L2)
     const uint32_t *tree;        // last-resort walk (HBM/L2)
-    uint32_t sub_bits;
+    uint32_t P;                  // primary width in bits
 };
 
-// Decodes one symbol.  Returns the symbol, or 0 with *bad set on a null table entry (corrupt
-// stream / context missing from the table).  *used accumulates the bits consumed.
-// LUT / BASE are LDS or global pointers (decode_kernel / build_index_kernel).
-template <typename LUT, typename BASE>
-__device__ __forceinline__ uint32_t decode_one(LUT lut, BASE sub_base, const DecTables &t, const BitSrc &src,
-                                               BitCursor &bc, uint32_t prev, uint32_t &used, bool &bad) {
-    bc.refill(src);                                        // >= 33 bits: enough for 8 + sub_bits
-    uint32_t e = lut[(prev << 8) | uint32_t(bc.buf >> 56)];
-    if (!(e & DEC16_INNER)) {                              // code of <= 8 bits (src/coding.cpp:150-156)
+// Decodes one symbol (sequential index builder; tables read from global memory).  Returns the symbol,
+// or 0 with *bad set on a null table entry (corrupt stream / context missing from the table).
+// *used accumulates the bits consumed.
+__device__ __forceinline__ uint32_t decode_one(const uint16_t *prim, const uint32_t *sec_base, const DecTables &t,
+                                               const BitSrc &src, BitCursor &bc, uint32_t prev, uint32_t &used, bool &bad) {
+    bc.refill(src);                                        // >= 33 bits: enough for P + 8
+    uint32_t e = prim[(prev << t.P) | uint32_t(bc.buf >> (64u - t.P))];
+    if (!(e & DEC16_INNER)) {                              // code of <= P bits (src/coding.cpp:150-156)
         uint32_t len = e >> 8;
         bad |= (e == 0);
         bc.drop(len); used += len;
         return e & 255u;
     }
-    // code longer than 8 bits (src/coding.cpp:129-149): consume the window, then ONE second-level
-    // lookup on the next sub_bits bits
-    bc.drop(8);
-    uint32_t idx = ((sub_base[prev] + (e & 255u)) << t.sub_bits) | uint32_t(bc.buf >> (64u - t.sub_bits));
-    uint32_t e2 = t.sub16[idx];
+    // longer code (src/coding.cpp:129-149): the node's own table, indexed by the next h bits
+    const uint32_t h = ((e >> 12) & 7u) + 1u;
+    bc.drop(t.P);
+    uint32_t e2 = t.sec[sec_base[prev] + (e & 0xFFFu) + uint32_t(bc.buf >> (64u - h))];
     if (!(e2 & DEC16_INNER)) {
         uint32_t len = e2 >> 8;
         bad |= (e2 == 0);
-        bc.drop(len); used += 8u + len;
+        bc.drop(len); used += t.P + len;
         return e2 & 255u;
     }
-    // longer than 8 + sub_bits: walk the context's tree bit by bit from that node
-    bc.drop(t.sub_bits);
-    uint32_t node = e2 & 0x1FFu, n = 8u + t.sub_bits;
+    // longer than P + h: walk the context's tree bit by bit from that node
+    bc.drop(h);
+    uint32_t node = e2 & 0x1FFu, n = t.P + h;
     const uint32_t *tr = t.tree + prev * TREE_STRIDE;
     for (int guard = 0; guard < 256; ++guard) {
         bc.refill(src);
@@ -643,52 +652,293 @@ __device__ __forceinline__ uint32_t decode_one(LUT lut, BASE sub_base, const Dec
     return 0;
 }
 
-// One workgroup per CU (the 256 8-bit LUTs take 128 KiB of LDS), one lane per chunk, consecutive lanes
-// on consecutive chunks.  Each lane streams its chunk: 64-bit bit window fed by dword loads that stay
-// one word ahead, LDS LUT per symbol, 16 decoded bytes per 16-byte store.
-constexpr int DEC_THREADS = 1024;
-constexpr int DEC_LDS_BYTES = 131072 + 1024;
+// ---- the hot decoder ---------------------------------------------------------------------------
+// One workgroup per CU, one lane per chunk, consecutive lanes on consecutive chunks.  Two measured
+// facts shape the input side:
+//  (1) a lane's compressed bytes are ~0.7 KiB away from its neighbour's, so a per-lane dword read costs
+//      a whole cache line, and with ~1000 streams per CU the lines do not survive in L2 between two
+//      reads (16x read amplification, L2 hit rate 32 %).  Each lane therefore pulls its stream in
+//      32-byte aligned granules (two 16-byte loads): every byte is fetched once.
+//  (2) vmcnt retires in order.  A load issued by SOME lane in a round sits in front of that round's
+//      table gather for the WHOLE wave, so per-lane "refill when empty" loads put an HBM latency into
+//      every round.  Loads are therefore issued only at block boundaries (every 16 symbols, all lanes
+//      together) and consumed one block later: `pre` is in flight, `nxt` is resident, `cur` feeds the
+//      bit window; inside a block a granule switch is register-to-register.
+// A block of 16 symbols decoded through the tables consumes at most 16 * 16 = 256 bits = one granule,
+// and a block starts with `nxt` full, so the hot path never runs dry; longer codes (the walk) and the
+// set-up use the checked pop.
+struct LaneStream {
+    const uint4 *g0;      // granule 0 of this lane (32-byte aligned), two uint4 per granule
+    uint32_t gmax;        // last readable granule, relative to g0
+    uint32_t gnext;       // granule that goes into `pre` next
+    uint32_t cur[8];      // granule feeding the window, cur[0] is next
+    uint32_t ccnt;        // dwords left in cur
+    uint32_t nxt[8];      // following granule, resident
+    bool nxt_full;
+    uint32_t pre[8];      // the one after, possibly still in flight
+    uint64_t buf;         // next bits, first at bit 63
+    uint32_t cnt;         // valid bits in buf
+    uint32_t taken;       // dwords moved into buf
 
+    __device__ __forceinline__ void issue_pre() {
+        const uint32_t g = gnext < gmax ? gnext : gmax;
+        const uint4 a = g0[2 * g], b = g0[2 * g + 1];
+        pre[0] = a.x; pre[1] = a.y; pre[2] = a.z; pre[3] = a.w;
+        pre[4] = b.x; pre[5] = b.y; pre[6] = b.z; pre[7] = b.w;
+        ++gnext;
+    }
+    // wave-synchronous point (block boundary): the only place where loads are issued and awaited
+    __device__ __forceinline__ void block_sync() {
+        if (!nxt_full) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) nxt[i] = pre[i];
+            nxt_full = true;
+            issue_pre();
+        }
+    }
+    // CHECKED (set-up, walk of over-long codes, tail chunks): keeps `nxt` full around every pop, so any
+    // amount may be consumed.  Unchecked (hot path): relies on the per-block budget above.
+    template <bool CHECKED>
+    __device__ __forceinline__ uint32_t pop_word() {
+        if (CHECKED) block_sync();
+        const uint32_t w = cur[0];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) cur[i] = cur[i + 1];
+        if (--ccnt == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+            ccnt = 8;
+            nxt_full = false;
+            if (CHECKED) block_sync();
+        }
+        return w;
+    }
+    // total_bytes > 0 and bitpos < 8 * total_bytes (checked by the caller)
+    __device__ __forceinline__ void init(const uint8_t *payload, uint64_t total_bytes, uint64_t bitpos) {
+        const uint64_t w = bitpos >> 5;                      // first stream dword
+        const uint64_t gran = w >> 3;
+        g0 = reinterpret_cast<const uint4 *>(payload) + 2 * gran;
+        const uint64_t left = ((total_bytes - 1) >> 5) - gran;
+        gmax = left > 0xFFFFFFFFull ? 0xFFFFFFFFu : uint32_t(left);
+        gnext = 0;
+        issue_pre();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cur[i] = pre[i];
+        ccnt = 8;
+        issue_pre();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) nxt[i] = pre[i];
+        nxt_full = true;
+        issue_pre();
+        for (uint32_t skip = uint32_t(w & 7u); skip; --skip) (void)pop_word<true>();
+        const uint32_t hi = __builtin_bswap32(pop_word<true>());
+        const uint32_t lo = __builtin_bswap32(pop_word<true>());
+        const uint32_t sh = uint32_t(bitpos & 31u);
+        buf = ((uint64_t(hi) << 32) | lo) << sh;
+        cnt = 64u - sh;
+        taken = 2;
+    }
+    template <bool CHECKED>
+    __device__ __forceinline__ void refill() {               // afterwards cnt >= 33
+        if (cnt <= 32u) {
+            buf |= uint64_t(__builtin_bswap32(pop_word<CHECKED>())) << (32u - cnt);
+            cnt += 32u;
+            ++taken;
+        }
+    }
+    // stream bits consumed since init(bitpos)
+    __device__ __forceinline__ uint32_t consumed(uint64_t bitpos) const {
+        return taken * 32u - cnt - uint32_t(bitpos & 31u);
+    }
+};
+
+// Walk for codes longer than P + h (rare).  `skip` = P + h bits of the window have NOT been consumed.
+// Returns false on a corrupt stream.
+__device__ __forceinline__ bool walk_long(const DecTables &t, LaneStream &ls, uint32_t prev, uint32_t e2, uint32_t skip,
+                                          uint32_t &sym) {
+    ls.buf <<= skip; ls.cnt -= skip;
+    uint32_t node = e2 & 0x1FFu;
+    const uint32_t *tr = t.tree + prev * TREE_STRIDE;
+    for (int guard = 0; guard < 256; ++guard) {
+        ls.refill<true>();
+        uint32_t bit = uint32_t(ls.buf >> 63);
+        ls.buf <<= 1; ls.cnt -= 1u;
+        uint32_t pair = tr[node];
+        uint32_t c = bit ? (pair >> 16) : (pair & 0xFFFFu);
+        if (c & TREE_LEAF) { sym = c & 255u; return true; }
+        node = c;
+    }
+    sym = 0;
+    return false;
+}
+
+// One symbol from each of the lane's K independent streams.  prim and sec_base live in LDS; sec lives
+// in LDS too whenever the model's tables fit (t.sec then points into LDS).  The second-level step is
+// skipped by the whole wave when no lane needs it.
+template <int K, bool CHECKED>
+__device__ __forceinline__ void decode_step(const uint16_t *prim, const uint32_t *sec_base, const DecTables &t,
+                                            LaneStream (&ls)[K], uint32_t (&prev)[K], uint32_t &minlen) {
+    uint32_t hi[K], e[K], sb[K], len[K], sym[K];
+    bool inner = false;
+#pragma unroll
+    for (int k = 0; k < K; ++k) ls[k].template refill<CHECKED>();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        hi[k] = uint32_t(ls[k].buf >> 32);
+        e[k] = prim[(prev[k] << t.P) | (hi[k] >> (32u - t.P))];
+        sb[k] = sec_base[prev[k]];                              // independent of e[k]: same latency
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        len[k] = e[k] >> 8;
+        sym[k] = e[k] & 255u;
+        inner |= (e[k] & DEC16_INNER) != 0;
+    }
+    if (__any(inner)) {                                         // wave-uniform
+        uint32_t e2[K], h[K];
+        bool deep = false;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const bool in = (e[k] & DEC16_INNER) != 0;
+            h[k] = ((e[k] >> 12) & 7u) + 1u;
+            // only the lanes that need it take part in the gather: every extra quad of lanes costs the
+            // vector L1 a tag lookup even when it reads a dummy address
+            e2[k] = 0;
+            if (in) e2[k] = t.sec[sb[k] + (e[k] & 0xFFFu) + ((hi[k] << t.P) >> (32u - h[k]))];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (e[k] & DEC16_INNER) {
+                len[k] = t.P + (e2[k] >> 8);
+                sym[k] = e2[k] & 255u;
+                if ((e2[k] >> 8) == 0) len[k] = 0;              // null second-level entry
+                deep |= (e2[k] & DEC16_INNER) != 0;
+            }
+        }
+        if (__any(deep)) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                if ((e[k] & DEC16_INNER) && (e2[k] & DEC16_INNER)) {
+                    if (!walk_long(t, ls[k], prev[k], e2[k], t.P + h[k], sym[k])) minlen = 0;
+                    len[k] = 0x100u;                            // already consumed
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const uint32_t l = len[k] & 0xFFu;                      // 0x100 -> consume nothing more
+        minlen = len[k] < minlen ? len[k] : minlen;             // a null entry has len 0
+        ls[k].buf <<= l;
+        ls[k].cnt -= l;
+        prev[k] = sym[k];
+    }
+}
+
+constexpr int DEC_THREADS = 1024;
+constexpr int DEC_K = 1;                                        // streams per lane
+constexpr int DEC_LDS_MAX = 163840;
+
+// Decodes `nsym` symbols of ONE chunk (tail groups and the ragged last chunk).
+__device__ __forceinline__ void decode_chunk_single(const uint16_t *lut, const uint32_t *sub_base, const DecTables &t,
+                                                    const uint8_t *payload, uint64_t total_bytes, uint64_t nbits,
+                                                    uint64_t entry, uint8_t *o, uint32_t nsym, int *status) {
+    const uint64_t bitpos = entry & 0x00FFFFFFFFFFFFFFull;
+    if (bitpos >= nbits) { atomicExch(status, MHK_STATUS_CORRUPT); return; }
+    LaneStream ls[1];
+    uint32_t prev[1] = {uint32_t(entry >> 56)};
+    ls[0].init(payload, total_bytes, bitpos);
+    uint32_t minlen = 64;
+    uint32_t q = 0;
+    for (uint32_t i = 0; i < nsym; ++i) {
+        decode_step<1, true>(lut, sub_base, t, ls, prev, minlen);
+        q |= prev[0] << (8u * (i & 3u));
+        if ((i & 3u) == 3u) { *reinterpret_cast<uint32_t *>(o + i - 3u) = q; q = 0; }
+    }
+    for (uint32_t i = nsym & ~3u; i < nsym; ++i) o[i] = uint8_t(q >> (8u * (i & 3u)));
+    if (minlen == 0 || bitpos + ls[0].consumed(bitpos) > nbits) atomicExch(status, MHK_STATUS_CORRUPT);
+}
+
+template <bool SEC_LDS>
 __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint16_t *lut = reinterpret_cast<uint16_t *>(smem);
-    uint32_t *sub_base = reinterpret_cast<uint32_t *>(smem + 131072);
-    for (int i = threadIdx.x; i < 8192; i += DEC_THREADS)
-        reinterpret_cast<uint4 *>(lut)[i] = reinterpret_cast<const uint4 *>(p.dec16)[i];
-    if (threadIdx.x < 256) sub_base[threadIdx.x] = p.sub_base[threadIdx.x];
+    // LDS: sec_base u32[256] | prim u16[256 << P] | sec u16[nsec] (only when the model's tables fit)
+    uint32_t *sub_base = reinterpret_cast<uint32_t *>(smem);
+    uint16_t *lut = reinterpret_cast<uint16_t *>(smem + 1024);
+    const uint32_t nprim16 = (256u << p.P) / 8u;                // uint4 units
+    for (uint32_t i = threadIdx.x; i < nprim16; i += DEC_THREADS)
+        reinterpret_cast<uint4 *>(lut)[i] = reinterpret_cast<const uint4 *>(p.prim)[i];
+    uint16_t *lsec = lut + (256u << p.P);
+    if (SEC_LDS) {
+        const uint32_t nsec16 = (p.nsec + 7u) / 8u;             // the buffer is padded to 16 bytes
+        for (uint32_t i = threadIdx.x; i < nsec16; i += DEC_THREADS)
+            reinterpret_cast<uint4 *>(lsec)[i] = reinterpret_cast<const uint4 *>(p.sec)[i];
+    }
+    if (threadIdx.x < 256) sub_base[threadIdx.x] = p.sec_base[threadIdx.x];
     __syncthreads();
 
-    const BitSrc src{p.payload, p.payload_bytes >> 2, p.payload_bytes};
-    const DecTables tabs{p.sub16, p.tree, p.sub_bits};
+    const DecTables tabs{SEC_LDS ? lsec : p.sec, p.tree, p.P};
     const uint32_t S = 1u << p.chunk_shift;
-    for (uint64_t chunk = uint64_t(blockIdx.x) * DEC_THREADS + threadIdx.x; chunk < p.nchunks;
-         chunk += uint64_t(gridDim.x) * DEC_THREADS) {
-        const uint64_t entry = p.index[chunk];
-        const uint64_t bitpos = entry & 0x00FFFFFFFFFFFFFFull;
-        uint32_t prev = uint32_t(entry >> 56);
-        const uint64_t first = chunk << p.chunk_shift;
-        const uint32_t nsym = (p.n - first) >= S ? S : uint32_t(p.n - first);
-        if (bitpos > p.nbits) { atomicExch(p.status, MHK_STATUS_CORRUPT); continue; }
-        BitCursor bc;
-        bc.init(src, bitpos);
-        uint8_t *o = p.out + first;
-        bool bad = false;
-        uint32_t used = 0;
-        const uint32_t nblk = nsym >> 4;
-        for (uint32_t blk = 0; blk < nblk; ++blk) {
-            uint32_t q[4] = {0, 0, 0, 0};
+    const uint64_t full_chunks = p.n >> p.chunk_shift;          // chunks with exactly S symbols
+    const uint64_t group = uint64_t(DEC_THREADS) * DEC_K;       // chunks per workgroup iteration
+    for (uint64_t g0 = uint64_t(blockIdx.x) * group; g0 < p.nchunks; g0 += uint64_t(gridDim.x) * group) {
+        const uint64_t c0 = g0 + threadIdx.x;                   // stream k -> chunk c0 + k * DEC_THREADS
+        if (c0 + uint64_t(DEC_K - 1) * DEC_THREADS < full_chunks) {
+            // ---- K full chunks: interleaved decode
+            LaneStream ls[DEC_K];
+            uint32_t prev[DEC_K];
+            uint64_t bitpos[DEC_K];
+            bool ok = true;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                prev = decode_one(lut, sub_base, tabs, src, bc, prev, used, bad);
-                q[j >> 2] |= prev << (8 * (j & 3));
+            for (int k = 0; k < DEC_K; ++k) {
+                const uint64_t entry = p.index[c0 + uint64_t(k) * DEC_THREADS];
+                bitpos[k] = entry & 0x00FFFFFFFFFFFFFFull;
+                prev[k] = uint32_t(entry >> 56);
+                ok = ok && bitpos[k] < p.nbits;
             }
-            reinterpret_cast<uint4 *>(o)[blk] = make_uint4(q[0], q[1], q[2], q[3]);
+            if (!ok) { atomicExch(p.status, MHK_STATUS_CORRUPT); continue; }
+#pragma unroll
+            for (int k = 0; k < DEC_K; ++k) ls[k].init(p.payload, p.payload_bytes, bitpos[k]);
+            uint32_t minlen = 64;
+            for (uint32_t blk = 0; blk < (S >> 4); ++blk) {
+#pragma unroll
+                for (int k = 0; k < DEC_K; ++k) ls[k].block_sync();
+                uint32_t q[DEC_K][4];
+                // 4 x (4 symbols -> one dword); the dwords rotate through q so that indexing stays static
+#pragma unroll 1
+                for (int jj = 0; jj < 4; ++jj) {
+                    uint32_t d[DEC_K];
+#pragma unroll
+                    for (int k = 0; k < DEC_K; ++k) d[k] = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        decode_step<DEC_K, false>(lut, sub_base, tabs, ls, prev, minlen);
+#pragma unroll
+                        for (int k = 0; k < DEC_K; ++k) d[k] |= prev[k] << (8 * j);
+                    }
+#pragma unroll
+                    for (int k = 0; k < DEC_K; ++k) { q[k][0] = q[k][1]; q[k][1] = q[k][2]; q[k][2] = q[k][3]; q[k][3] = d[k]; }
+                }
+#pragma unroll
+                for (int k = 0; k < DEC_K; ++k) {
+                    uint4 *o16 = reinterpret_cast<uint4 *>(p.out + ((c0 + uint64_t(k) * DEC_THREADS) << p.chunk_shift));
+                    o16[blk] = make_uint4(q[k][0], q[k][1], q[k][2], q[k][3]);
+                }
+            }
+            bool bad = minlen == 0;
+#pragma unroll
+            for (int k = 0; k < DEC_K; ++k) bad |= bitpos[k] + ls[k].consumed(bitpos[k]) > p.nbits;
+            if (bad) atomicExch(p.status, MHK_STATUS_CORRUPT);
+        } else {
+            // ---- end of the stream: whatever chunks exist, one at a time
+            for (int k = 0; k < DEC_K; ++k) {
+                const uint64_t c = c0 + uint64_t(k) * DEC_THREADS;
+                if (c >= p.nchunks) break;
+                const uint64_t first = c << p.chunk_shift;
+                const uint32_t nsym = (p.n - first) >= S ? S : uint32_t(p.n - first);
+                decode_chunk_single(lut, sub_base, tabs, p.payload, p.payload_bytes, p.nbits, p.index[c], p.out + first, nsym, p.status);
+            }
         }
-        for (uint32_t i = nblk << 4; i < nsym; ++i) {          // ragged tail of the last chunk
-            prev = decode_one(lut, sub_base, tabs, src, bc, prev, used, bad);
-            o[i] = uint8_t(prev);
-        }
-        if (bad || bitpos + used > p.nbits) atomicExch(p.status, MHK_STATUS_CORRUPT);
     }
 }
 
@@ -699,7 +949,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecParams p) {
 __global__ void build_index_kernel(IdxParams p) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     const BitSrc src{p.payload, p.payload_bytes >> 2, p.payload_bytes};
-    const DecTables tabs{p.sub16, p.tree, p.sub_bits};
+    const DecTables tabs{p.sec, p.tree, p.P};
     BitCursor bc;
     bc.init(src, 0);
     uint64_t bi = 0, nsym = 0;
@@ -713,7 +963,7 @@ __global__ void build_index_kernel(IdxParams p) {
             p.index[ci] = (uint64_t(prev) << 56) | bi;
         }
         uint32_t used = 0;
-        prev = decode_one(p.dec16, p.sub_base, tabs, src, bc, prev, used, bad);
+        prev = decode_one(p.prim, p.sec_base, tabs, src, bc, prev, used, bad);
         if (bad) break;
         bi += used;
         ++nsym;
@@ -819,10 +1069,17 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
     hipError_t e = hipMemsetAsync(d_ws, 0, 64, st);
     if (e != hipSuccess || p.nchunks == 0) return e;
     static bool once = false;
-    if (!once) { e = allow_lds(reinterpret_cast<const void *>(decode_kernel), DEC_LDS_BYTES); if (e != hipSuccess) return e; once = true; }
-    uint64_t want = (p.nchunks + DEC_THREADS - 1) / DEC_THREADS;
+    if (!once) {
+        e = allow_lds(reinterpret_cast<const void *>(decode_kernel<true>), DEC_LDS_MAX); if (e != hipSuccess) return e;
+        e = allow_lds(reinterpret_cast<const void *>(decode_kernel<false>), DEC_LDS_MAX); if (e != hipSuccess) return e;
+        once = true;
+    }
+    size_t lds = 1024 + (size_t(256) << p.P) * 2 + (p.sec_lds ? ((size_t(p.nsec) * 2 + 15) & ~size_t(15)) : 0);
+    if (lds > size_t(DEC_LDS_MAX)) return hipErrorInvalidValue;
+    uint64_t want = (p.nchunks + uint64_t(DEC_THREADS) * DEC_K - 1) / (uint64_t(DEC_THREADS) * DEC_K);
     int grid = int(want > uint64_t(cu_count()) ? uint64_t(cu_count()) : want);
-    hipLaunchKernelGGL(decode_kernel, dim3(grid), dim3(DEC_THREADS), DEC_LDS_BYTES, st, p);
+    if (p.sec_lds) hipLaunchKernelGGL(decode_kernel<true>, dim3(grid), dim3(DEC_THREADS), lds, st, p);
+    else hipLaunchKernelGGL(decode_kernel<false>, dim3(grid), dim3(DEC_THREADS), lds, st, p);
     return hipGetLastError();
 }
 

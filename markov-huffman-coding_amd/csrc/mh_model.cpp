@@ -204,11 +204,28 @@ bool ContextCoder::load(BitReader &in) {
     return true;
 }
 
-int ContextCoder::pack_decode(uint16_t *dec, uint32_t *tree, std::vector<uint16_t> &sub, int sub_bits) const {
-    for (int i = 0; i < 256; ++i) dec[i] = 0;
-    for (int i = 0; i < TREE_STRIDE; ++i) tree[i] = 0;
+size_t ContextCoder::sec_entries(int P, int hcap) const {
     if (root_ < 0) return 0;
-    // number inner nodes for the walk, root = 0
+    size_t total = 0;
+    std::vector<std::pair<int, int>> stack{{root_, 0}};
+    while (!stack.empty()) {
+        auto [n, d] = stack.back();
+        stack.pop_back();
+        const Node &nd = nodes_[n];
+        if (nd.leaf) continue;
+        if (d == P) { total += size_t(1) << std::min(nd.height, hcap); continue; }
+        stack.push_back({nd.child[0], d + 1});
+        stack.push_back({nd.child[1], d + 1});
+    }
+    return total;
+}
+
+void ContextCoder::pack_decode(int P, int hcap, uint16_t *prim, std::vector<uint16_t> &sec, size_t sec_start,
+                               uint32_t *tree) const {
+    for (int i = 0; i < (1 << P); ++i) prim[i] = 0;
+    for (int i = 0; i < TREE_STRIDE; ++i) tree[i] = 0;
+    if (root_ < 0) return;
+    // inner-node ids for the last-resort walk, root = 0
     std::vector<int> id(nodes_.size(), -1);
     int next = 1;
     for (size_t i = 0; i < nodes_.size(); ++i)
@@ -219,37 +236,35 @@ int ContextCoder::pack_decode(uint16_t *dec, uint32_t *tree, std::vector<uint16_
     for (size_t i = 0; i < nodes_.size(); ++i)
         if (!nodes_[i].leaf)
             tree[id[i]] = (enc_child(nodes_[i].child[1]) << 16) | enc_child(nodes_[i].child[0]);
-    int ninner8 = 0;
-    for (int w = 0; w < 256; ++w) {
-        int n = lut_[w];
-        if (n < 0) continue;
-        if (nodes_[n].leaf) {
-            dec[w] = uint16_t((nodes_[n].depth << 8) | nodes_[n].sym);
-            continue;
-        }
-        dec[w] = uint16_t(DEC16_INNER | ninner8++);
-        // second-level table of this depth-8 node: every path of sub_bits further bits
-        size_t base = sub.size();
-        sub.resize(base + (size_t(1) << sub_bits), 0);
-        struct Item { int node; int depth; uint32_t path; };
-        std::vector<Item> stack{{n, 0, 0}};
-        while (!stack.empty()) {
-            Item it = stack.back();
-            stack.pop_back();
+
+    struct Item { int node; int depth; uint32_t path; };
+    // fills a 2^width table (dst) with the subtree under `top`: leaves -> len << 8 | sym for every
+    // completion of their path, internal nodes at depth `width` -> inner_entry(node)
+    auto fill = [&](int top, int width, uint16_t *dst, auto inner_entry) {
+        std::vector<Item> st{{top, 0, 0}};
+        while (!st.empty()) {
+            Item it = st.back();
+            st.pop_back();
             const Node &nd = nodes_[it.node];
             if (nd.leaf) {
-                uint32_t lo = it.path << (sub_bits - it.depth);
-                for (uint32_t k = 0; k < (1u << (sub_bits - it.depth)); ++k)
-                    sub[base + lo + k] = uint16_t((it.depth << 8) | nd.sym);
-            } else if (it.depth == sub_bits) {
-                sub[base + it.path] = uint16_t(DEC16_INNER | id[it.node]);
+                uint32_t lo = it.path << (width - it.depth);
+                for (uint32_t k = 0; k < (1u << (width - it.depth)); ++k)
+                    dst[lo + k] = uint16_t((it.depth << 8) | nd.sym);
+            } else if (it.depth == width) {
+                dst[it.path] = inner_entry(it.node);
             } else {
-                stack.push_back({nd.child[1], it.depth + 1, (it.path << 1) | 1u});
-                stack.push_back({nd.child[0], it.depth + 1, it.path << 1});
+                st.push_back({nd.child[1], it.depth + 1, (it.path << 1) | 1u});
+                st.push_back({nd.child[0], it.depth + 1, it.path << 1});
             }
         }
-    }
-    return ninner8;
+    };
+    fill(root_, P, prim, [&](int node) -> uint16_t {
+        const int h = std::min(nodes_[node].height, hcap);          // >= 1: the node is internal
+        const size_t off = sec.size() - sec_start;
+        sec.resize(sec.size() + (size_t(1) << h), 0);
+        fill(node, h, sec.data() + sec_start + off, [&](int deep) -> uint16_t { return uint16_t(DEC16_INNER | id[deep]); });
+        return uint16_t(DEC16_INNER | ((h - 1) << 12) | uint32_t(off));
+    });
 }
 
 int Model::max_code_len() const {
@@ -305,21 +320,39 @@ Model::Packed Model::pack() const {
     pk.len8.assign(65536, 0);
     pk.len_slot.assign(65536, 0);
     pk.code64.assign(65536, 0);
-    pk.dec16.assign(65536, 0);
     pk.tree.assign(256 * TREE_STRIDE, 0);
     pk.max_len = max_code_len();
-    pk.sub_bits = std::min(std::max(pk.max_len - 8, 1), SUB_BITS_MAX);
-    pk.sub_base.assign(256, 0);
-    uint32_t nsub = 0;
+    // ---- decode tables: widest primary whose two levels fit the LDS budget
+    const int nctx = type ? 256 : 1;                 // a type-0 model shares one set of tables
+    auto fits = [&](int P, int hcap, bool lds) {
+        size_t total = 0;
+        for (int i = 0; i < nctx; ++i) {
+            size_t e = ctx[i].sec_entries(P, hcap);
+            if (e > size_t(DEC_SEC_MAX_PER_CTX)) return false;
+            total += e;
+        }
+        return !lds || (size_t(256) << P) + total <= size_t(DEC_LDS_ENTRIES);
+    };
+    int hcap = 8;
+    pk.dec_bits = 0;
+    for (int P = 8; P >= 4 && !pk.dec_bits; --P)
+        if (fits(P, 8, true)) pk.dec_bits = P;
+    pk.dec_lds = pk.dec_bits != 0;
+    if (!pk.dec_lds) {
+        pk.dec_bits = 8;
+        while (hcap > 1 && !fits(8, hcap, false)) --hcap;
+    }
+    const int P = pk.dec_bits;
+    pk.dec_prim.assign(size_t(256) << P, 0);
+    pk.sec_base.assign(256, 0);
     for (int prev = 0; prev < 256; ++prev) {
         const ContextCoder &c = context(prev);
         if (type == 0 && prev > 0) {
-            // one table replicated over all contexts: share context 0's second-level tables
-            std::vector<uint16_t> scratch;
-            c.pack_decode(&pk.dec16[prev * 256], &pk.tree[prev * TREE_STRIDE], scratch, pk.sub_bits);
+            std::copy(pk.dec_prim.begin(), pk.dec_prim.begin() + (1 << P), pk.dec_prim.begin() + (size_t(prev) << P));
+            std::copy(pk.tree.begin(), pk.tree.begin() + TREE_STRIDE, pk.tree.begin() + size_t(prev) * TREE_STRIDE);
         } else {
-            pk.sub_base[prev] = nsub;
-            nsub += uint32_t(c.pack_decode(&pk.dec16[prev * 256], &pk.tree[prev * TREE_STRIDE], pk.sub16, pk.sub_bits));
+            pk.sec_base[prev] = uint32_t(pk.dec_sec.size());
+            c.pack_decode(P, hcap, &pk.dec_prim[size_t(prev) << P], pk.dec_sec, pk.dec_sec.size(), &pk.tree[prev * TREE_STRIDE]);
         }
         for (int sym = 0; sym < 256; ++sym) {
             const Code &cd = c.code(sym);

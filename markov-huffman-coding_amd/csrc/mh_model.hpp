@@ -26,17 +26,21 @@ constexpr uint16_t ENC16_ESCAPE = 0xFFFF;
 constexpr int ENC16_MAX_LEN = 12;
 constexpr uint32_t enc_slot(uint32_t window) { return (window ^ (window >> 8)) & 0xFFFFu; }
 
-// Decode LUT, LDS-resident: 65536 x u16 indexed prev << 8 | next-8-stream-bits.
-//   0                      null (empty context)
-//   leaf   : len(1..8) << 8 | symbol
-//   inner  : 0x8000 | k, k = rank of this depth-8 internal node among the context's depth-8
-//            internal nodes (the node stored by src/huffman.cpp:111-113)
+// Decode tables: two levels, BOTH LDS-resident whenever they fit (a code that needs an L2 gather per
+// symbol costs the whole wave ~10x an LDS lookup, and with 64 lanes some lane always needs it).
+//   prim[ctx << P | first P stream bits]   u16, P = dec_bits, model-wide, 4..8
+//       0      null (empty context)
+//       leaf   len(1..P) << 8 | symbol
+//       inner  0x8000 | (h - 1) << 12 | off : the internal node at depth P; its 2^h-entry table starts
+//              at sec[sec_base[ctx] + off] and is indexed by the next h stream bits (1 <= h <= 8)
+//   sec[...]   u16
+//       leaf   extra_len(1..h) << 8 | symbol
+//       inner  0x8000 | tree node id : code longer than P + h, walked bit by bit in the L2 tree (rare)
+// P is the largest width for which prim + sec fit the LDS budget; if none does (pathological models)
+// P = 8 and sec stays in HBM/L2.  P = 8 is the reference's own 8-bit LUT (src/huffman.cpp:97-123).
 constexpr uint16_t DEC16_INNER = 0x8000;
-// Second-level tables in HBM/L2 (one L2 access instead of a bit-serial walk): for the k-th depth-8
-// internal node of context c, 2^sub_bits entries at ((sub_base[c] + k) << sub_bits), indexed by the
-// next sub_bits stream bits:  leaf: extra_len(1..sub_bits) << 8 | symbol;
-//                              inner (code longer than 8 + sub_bits): 0x8000 | tree node id.
-constexpr int SUB_BITS_MAX = 8;
+constexpr int DEC_LDS_ENTRIES = (163840 - 1024) / 2;   // u16 entries beside the 1 KiB sec_base array
+constexpr int DEC_SEC_MAX_PER_CTX = 4096;              // 12-bit offsets
 // Last-resort tree in HBM/L2: per context 256 x u32 = right << 16 | left; a child is
 // 0x8000 | symbol for a leaf, else the internal-node id (0 = root).
 constexpr uint32_t TREE_LEAF = 0x8000;
@@ -77,9 +81,11 @@ public:
     const Node &node(int i) const { return nodes_[i]; }
     int root() const { return root_; }
     int max_len() const { return max_len_; }
-    // packed device images for this context; appends this context's second-level tables to `sub`
-    // and returns how many (= number of depth-8 internal nodes)
-    int pack_decode(uint16_t *dec256, uint32_t *tree256, std::vector<uint16_t> &sub, int sub_bits) const;
+    // second-level entries this context needs for primary width P and table-height cap hcap
+    size_t sec_entries(int P, int hcap) const;
+    // packed device images for this context: prim (1 << P entries), this context's second-level
+    // tables appended to `sec` (offsets relative to sec_start), walk tree (TREE_STRIDE entries)
+    void pack_decode(int P, int hcap, uint16_t *prim, std::vector<uint16_t> &sec, size_t sec_start, uint32_t *tree256) const;
 
 private:
     void derive_tables();
@@ -140,11 +146,12 @@ public:
         std::vector<uint8_t> len8;       // 65536, prev*256+sym
         std::vector<uint8_t> len_slot;   // 65536, slot order: code length (0..64) for the length pass
         std::vector<uint64_t> code64;    // 65536, prev*256+sym, right aligned
-        std::vector<uint16_t> dec16;     // 65536, prev*256+w
+        std::vector<uint16_t> dec_prim;  // 256 << dec_bits
+        std::vector<uint16_t> dec_sec;   // second-level tables
+        std::vector<uint32_t> sec_base;  // 256: index of each context's first second-level entry
         std::vector<uint32_t> tree;      // 256*TREE_STRIDE
-        std::vector<uint16_t> sub16;     // second-level tables, (#depth-8 inner nodes) << sub_bits entries
-        std::vector<uint32_t> sub_base;  // 256: index of each context's first second-level table
-        int sub_bits = 1;
+        int dec_bits = 8;                // P
+        bool dec_lds = true;             // prim + sec fit the LDS budget
         int max_len = 0;
         bool any_escape = false;
     };

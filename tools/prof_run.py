@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Small fixed workload for rocprofv3 counter passes: one histogram, model build, encode, decode of
+`--size` bytes of Zipf(1.1) (default 1 GiB), round trip checked.  Usage on the GPU box:
+   rocprofv3 --pmc <counters> --kernel-trace --output-format csv -d <dir> -- python3 tools/prof_run.py"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import __graft_entry__ as entry  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--size", type=int, default=1 << 30)
+ap.add_argument("--kind", default="zipf")
+ap.add_argument("--reps", type=int, default=1)
+a = ap.parse_args()
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+mhc = entry.load_package()
+data = bench.generate(a.kind, a.size, 2, 0, dev)
+codec = bench.Codec(mhc, a.size, dev)
+for _ in range(a.reps):
+    codec.histogram(data, 0x20)
+    model = codec.build_model()
+    codec.encode(model, data, 0x20)
+    nbits = int(codec.nbits[0].item())
+    codec.decode(model, nbits)
+torch.cuda.synchronize()
+assert torch.equal(codec.decoded, data)
+print("ok", nbits)
