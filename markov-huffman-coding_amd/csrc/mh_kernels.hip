@@ -679,6 +679,7 @@ struct LaneStream {
     uint64_t buf;         // next bits, first at bit 63
     uint32_t cnt;         // valid bits in buf
     uint32_t taken;       // dwords moved into buf
+    uint32_t sh0;         // bit offset of the stream start inside its first dword
 
     __device__ __forceinline__ void issue_pre() {
         const uint32_t g = gnext < gmax ? gnext : gmax;
@@ -733,9 +734,9 @@ struct LaneStream {
         for (uint32_t skip = uint32_t(w & 7u); skip; --skip) (void)pop_word<true>();
         const uint32_t hi = __builtin_bswap32(pop_word<true>());
         const uint32_t lo = __builtin_bswap32(pop_word<true>());
-        const uint32_t sh = uint32_t(bitpos & 31u);
-        buf = ((uint64_t(hi) << 32) | lo) << sh;
-        cnt = 64u - sh;
+        sh0 = uint32_t(bitpos & 31u);
+        buf = ((uint64_t(hi) << 32) | lo) << sh0;
+        cnt = 64u - sh0;
         taken = 2;
     }
     template <bool CHECKED>
@@ -746,10 +747,8 @@ struct LaneStream {
             ++taken;
         }
     }
-    // stream bits consumed since init(bitpos)
-    __device__ __forceinline__ uint32_t consumed(uint64_t bitpos) const {
-        return taken * 32u - cnt - uint32_t(bitpos & 31u);
-    }
+    // stream bits consumed since init()
+    __device__ __forceinline__ uint32_t consumed() const { return taken * 32u - cnt - sh0; }
 };
 
 // Walk for codes longer than P + h (rare).  `skip` = P + h bits of the window have NOT been consumed.
@@ -765,7 +764,7 @@ __device__ __forceinline__ bool walk_long(const DecTables &t, LaneStream &ls, ui
         ls.buf <<= 1; ls.cnt -= 1u;
         uint32_t pair = tr[node];
         uint32_t c = bit ? (pair >> 16) : (pair & 0xFFFFu);
-        if (c & TREE_LEAF) { sym = c & 255u; return true; }
+        if (c & TREE_LEAF) { sym = c & 255u; ls.refill<true>(); return true; }
         node = c;
     }
     sym = 0;
@@ -775,13 +774,19 @@ __device__ __forceinline__ bool walk_long(const DecTables &t, LaneStream &ls, ui
 // One symbol from each of the lane's K independent streams.  prim and sec_base live in LDS; sec lives
 // in LDS too whenever the model's tables fit (t.sec then points into LDS).  The second-level step is
 // skipped by the whole wave when no lane needs it.
-template <int K, bool CHECKED>
+// REFILL: top the bit windows up first (>= 33 bits).  A table-resolved code is at most P + h <= 16
+// bits, so one refill covers two symbols — four when the model has no code longer than 8 bits.
+// A null table entry consumes nothing; the caller detects it because the chunk then ends at the wrong
+// bit offset.
+template <int K, bool CHECKED, bool REFILL>
 __device__ __forceinline__ void decode_step(const uint16_t *prim, const uint32_t *sec_base, const DecTables &t,
-                                            LaneStream (&ls)[K], uint32_t (&prev)[K], uint32_t &minlen) {
+                                            LaneStream (&ls)[K], uint32_t (&prev)[K], bool &bad) {
     uint32_t hi[K], e[K], sb[K], len[K], sym[K];
     bool inner = false;
+    if (REFILL) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) ls[k].template refill<CHECKED>();
+        for (int k = 0; k < K; ++k) ls[k].template refill<CHECKED>();
+    }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         hi[k] = uint32_t(ls[k].buf >> 32);
@@ -809,9 +814,8 @@ __device__ __forceinline__ void decode_step(const uint16_t *prim, const uint32_t
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             if (e[k] & DEC16_INNER) {
-                len[k] = t.P + (e2[k] >> 8);
+                len[k] = (e2[k] >> 8) ? t.P + (e2[k] >> 8) : 0u;        // null second-level entry -> 0
                 sym[k] = e2[k] & 255u;
-                if ((e2[k] >> 8) == 0) len[k] = 0;              // null second-level entry
                 deep |= (e2[k] & DEC16_INNER) != 0;
             }
         }
@@ -819,47 +823,46 @@ __device__ __forceinline__ void decode_step(const uint16_t *prim, const uint32_t
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 if ((e[k] & DEC16_INNER) && (e2[k] & DEC16_INNER)) {
-                    if (!walk_long(t, ls[k], prev[k], e2[k], t.P + h[k], sym[k])) minlen = 0;
-                    len[k] = 0x100u;                            // already consumed
+                    if (!walk_long(t, ls[k], prev[k], e2[k], t.P + h[k], sym[k])) bad = true;
+                    len[k] = 0;                                 // already consumed
                 }
             }
         }
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const uint32_t l = len[k] & 0xFFu;                      // 0x100 -> consume nothing more
-        minlen = len[k] < minlen ? len[k] : minlen;             // a null entry has len 0
-        ls[k].buf <<= l;
-        ls[k].cnt -= l;
+        ls[k].buf <<= len[k];
+        ls[k].cnt -= len[k];
         prev[k] = sym[k];
     }
 }
 
-constexpr int DEC_THREADS = 1024;
-constexpr int DEC_K = 1;                                        // streams per lane
+constexpr int DEC_THREADS = 512;
+constexpr int DEC_K = 4;                                        // streams per lane
 constexpr int DEC_LDS_MAX = 163840;
 
-// Decodes `nsym` symbols of ONE chunk (tail groups and the ragged last chunk).
+// Decodes `nsym` symbols of ONE chunk that must end at bit `end_bits` (tail groups and the ragged
+// last chunk).
 __device__ __forceinline__ void decode_chunk_single(const uint16_t *lut, const uint32_t *sub_base, const DecTables &t,
                                                     const uint8_t *payload, uint64_t total_bytes, uint64_t nbits,
-                                                    uint64_t entry, uint8_t *o, uint32_t nsym, int *status) {
+                                                    uint64_t entry, uint64_t end_bits, uint8_t *o, uint32_t nsym, int *status) {
     const uint64_t bitpos = entry & 0x00FFFFFFFFFFFFFFull;
     if (bitpos >= nbits) { atomicExch(status, MHK_STATUS_CORRUPT); return; }
     LaneStream ls[1];
     uint32_t prev[1] = {uint32_t(entry >> 56)};
     ls[0].init(payload, total_bytes, bitpos);
-    uint32_t minlen = 64;
+    bool bad = false;
     uint32_t q = 0;
     for (uint32_t i = 0; i < nsym; ++i) {
-        decode_step<1, true>(lut, sub_base, t, ls, prev, minlen);
+        decode_step<1, true, true>(lut, sub_base, t, ls, prev, bad);
         q |= prev[0] << (8u * (i & 3u));
         if ((i & 3u) == 3u) { *reinterpret_cast<uint32_t *>(o + i - 3u) = q; q = 0; }
     }
     for (uint32_t i = nsym & ~3u; i < nsym; ++i) o[i] = uint8_t(q >> (8u * (i & 3u)));
-    if (minlen == 0 || bitpos + ls[0].consumed(bitpos) > nbits) atomicExch(status, MHK_STATUS_CORRUPT);
+    if (bad || bitpos + ls[0].consumed() != end_bits) atomicExch(status, MHK_STATUS_CORRUPT);
 }
 
-template <bool SEC_LDS>
+template <bool SEC_LDS, int SPR>   // SPR = symbols per window refill (2, or 4 when no code exceeds 8 bits)
 __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS: sec_base u32[256] | prim u16[256 << P] | sec u16[nsec] (only when the model's tables fit)
@@ -887,19 +890,22 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecParams p) {
             // ---- K full chunks: interleaved decode
             LaneStream ls[DEC_K];
             uint32_t prev[DEC_K];
-            uint64_t bitpos[DEC_K];
+            uint32_t expect[DEC_K];                              // bits each chunk must consume
             bool ok = true;
 #pragma unroll
             for (int k = 0; k < DEC_K; ++k) {
-                const uint64_t entry = p.index[c0 + uint64_t(k) * DEC_THREADS];
-                bitpos[k] = entry & 0x00FFFFFFFFFFFFFFull;
+                const uint64_t c = c0 + uint64_t(k) * DEC_THREADS;
+                const uint64_t entry = p.index[c];
+                const uint64_t bitpos = entry & 0x00FFFFFFFFFFFFFFull;
+                const uint64_t endpos = (c + 1 < p.nchunks) ? (p.index[c + 1] & 0x00FFFFFFFFFFFFFFull) : p.nbits;
                 prev[k] = uint32_t(entry >> 56);
-                ok = ok && bitpos[k] < p.nbits;
+                const bool fine = bitpos < p.nbits && endpos >= bitpos && endpos - bitpos <= (uint64_t(S) << 6);
+                ok = ok && fine;
+                expect[k] = uint32_t(endpos - bitpos);
+                if (fine) ls[k].init(p.payload, p.payload_bytes, bitpos);
             }
             if (!ok) { atomicExch(p.status, MHK_STATUS_CORRUPT); continue; }
-#pragma unroll
-            for (int k = 0; k < DEC_K; ++k) ls[k].init(p.payload, p.payload_bytes, bitpos[k]);
-            uint32_t minlen = 64;
+            bool bad = false;
             for (uint32_t blk = 0; blk < (S >> 4); ++blk) {
 #pragma unroll
                 for (int k = 0; k < DEC_K; ++k) ls[k].block_sync();
@@ -912,7 +918,8 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecParams p) {
                     for (int k = 0; k < DEC_K; ++k) d[k] = 0;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        decode_step<DEC_K, false>(lut, sub_base, tabs, ls, prev, minlen);
+                        if (j % SPR == 0) decode_step<DEC_K, false, true>(lut, sub_base, tabs, ls, prev, bad);
+                        else decode_step<DEC_K, false, false>(lut, sub_base, tabs, ls, prev, bad);
 #pragma unroll
                         for (int k = 0; k < DEC_K; ++k) d[k] |= prev[k] << (8 * j);
                     }
@@ -925,9 +932,10 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecParams p) {
                     o16[blk] = make_uint4(q[k][0], q[k][1], q[k][2], q[k][3]);
                 }
             }
-            bool bad = minlen == 0;
+            // every chunk must end exactly where the next one starts (null entries, a wrong table or a
+            // damaged stream all miss it)
 #pragma unroll
-            for (int k = 0; k < DEC_K; ++k) bad |= bitpos[k] + ls[k].consumed(bitpos[k]) > p.nbits;
+            for (int k = 0; k < DEC_K; ++k) bad |= ls[k].consumed() != expect[k];
             if (bad) atomicExch(p.status, MHK_STATUS_CORRUPT);
         } else {
             // ---- end of the stream: whatever chunks exist, one at a time
@@ -936,7 +944,8 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecParams p) {
                 if (c >= p.nchunks) break;
                 const uint64_t first = c << p.chunk_shift;
                 const uint32_t nsym = (p.n - first) >= S ? S : uint32_t(p.n - first);
-                decode_chunk_single(lut, sub_base, tabs, p.payload, p.payload_bytes, p.nbits, p.index[c], p.out + first, nsym, p.status);
+                const uint64_t endb = (c + 1 < p.nchunks) ? (p.index[c + 1] & 0x00FFFFFFFFFFFFFFull) : p.nbits;
+                decode_chunk_single(lut, sub_base, tabs, p.payload, p.payload_bytes, p.nbits, p.index[c], endb, p.out + first, nsym, p.status);
             }
         }
     }
@@ -1070,16 +1079,18 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
     if (e != hipSuccess || p.nchunks == 0) return e;
     static bool once = false;
     if (!once) {
-        e = allow_lds(reinterpret_cast<const void *>(decode_kernel<true>), DEC_LDS_MAX); if (e != hipSuccess) return e;
-        e = allow_lds(reinterpret_cast<const void *>(decode_kernel<false>), DEC_LDS_MAX); if (e != hipSuccess) return e;
+        e = allow_lds(reinterpret_cast<const void *>(decode_kernel<true, 2>), DEC_LDS_MAX); if (e != hipSuccess) return e;
+        e = allow_lds(reinterpret_cast<const void *>(decode_kernel<true, 4>), DEC_LDS_MAX); if (e != hipSuccess) return e;
+        e = allow_lds(reinterpret_cast<const void *>(decode_kernel<false, 2>), DEC_LDS_MAX); if (e != hipSuccess) return e;
         once = true;
     }
     size_t lds = 1024 + (size_t(256) << p.P) * 2 + (p.sec_lds ? ((size_t(p.nsec) * 2 + 15) & ~size_t(15)) : 0);
     if (lds > size_t(DEC_LDS_MAX)) return hipErrorInvalidValue;
     uint64_t want = (p.nchunks + uint64_t(DEC_THREADS) * DEC_K - 1) / (uint64_t(DEC_THREADS) * DEC_K);
     int grid = int(want > uint64_t(cu_count()) ? uint64_t(cu_count()) : want);
-    if (p.sec_lds) hipLaunchKernelGGL(decode_kernel<true>, dim3(grid), dim3(DEC_THREADS), lds, st, p);
-    else hipLaunchKernelGGL(decode_kernel<false>, dim3(grid), dim3(DEC_THREADS), lds, st, p);
+    if (p.sec_lds && p.nsec == 0 && p.P == 8) hipLaunchKernelGGL((decode_kernel<true, 4>), dim3(grid), dim3(DEC_THREADS), lds, st, p);
+    else if (p.sec_lds) hipLaunchKernelGGL((decode_kernel<true, 2>), dim3(grid), dim3(DEC_THREADS), lds, st, p);
+    else hipLaunchKernelGGL((decode_kernel<false, 2>), dim3(grid), dim3(DEC_THREADS), lds, st, p);
     return hipGetLastError();
 }
 

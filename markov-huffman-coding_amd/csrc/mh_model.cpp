@@ -14,38 +14,49 @@ namespace {
 // These rules fix every tie and therefore every codeword.
 class TieExactHeap {
 public:
+    // Same comparisons, in the same order, as swap-based swim/sink; a "hole" is moved instead of
+    // swapping pairs (the sequence of element positions is identical).
     void push(int64_t key, int item) {
-        slots_.push_back({key, item});
-        size_t i = slots_.size() - 1;
+        int i = n_++;
         while (i != 0) {
-            size_t parent = (i - 1) / 2;
-            if (!(slots_[parent].first > slots_[i].first)) break;
-            std::swap(slots_[parent], slots_[i]);
+            int parent = (i - 1) / 2;
+            if (!(key_[parent] > key)) break;
+            key_[i] = key_[parent]; item_[i] = item_[parent];
             i = parent;
         }
+        key_[i] = key; item_[i] = item;
     }
     int pop() {
-        int top = slots_.front().second;
-        slots_.front() = slots_.back();
-        slots_.pop_back();
-        size_t i = 0, n = slots_.size();
+        const int top = item_[0];
+        --n_;
+        const int64_t key = key_[n_];
+        const int item = item_[n_];
+        int i = 0;
         for (;;) {
-            size_t l = 2 * i + 1, r = l + 1;
-            size_t pick = (r < n && slots_[r].first < slots_[l].first) ? r : l;
-            if (pick < n && slots_[pick].first < slots_[i].first) {
-                std::swap(slots_[pick], slots_[i]);
+            int l = 2 * i + 1, r = l + 1;
+            int pick = (r < n_ && key_[r] < key_[l]) ? r : l;
+            if (pick < n_ && key_[pick] < key) {
+                key_[i] = key_[pick]; item_[i] = item_[pick];
                 i = pick;
             } else {
                 break;
             }
         }
+        if (n_ > 0 || i == 0) { key_[i] = key; item_[i] = item; }
         return top;
     }
-    size_t size() const { return slots_.size(); }
+    int size() const { return n_; }
 
 private:
-    std::vector<std::pair<int64_t, int>> slots_;
+    int64_t key_[257];
+    int item_[257];
+    int n_ = 0;
 };
+
+template <typename F>
+void parallel_for(int n, F body) {   // contexts are independent; kept serial (host threads did not pay off)
+    for (int i = 0; i < n; ++i) body(i);
+}
 
 inline void code_set_bit(Code &c, int pos, int v) {
     uint64_t mask = 1ull << (63 - (pos & 63));
@@ -56,6 +67,7 @@ inline void code_set_bit(Code &c, int pos, int v) {
 
 void ContextCoder::clear() {
     nodes_.clear();
+    nodes_.reserve(520);
     root_ = -1;
     codes_.fill(Code{});
     lut_.fill(-1);
@@ -110,35 +122,45 @@ void ContextCoder::derive_tables() {
     lut_.fill(-1);
     max_len_ = 0;
     if (root_ < 0) return;
-    struct Frame { int node; int depth; Code path; };
+    // frames carry the first 64 path bits; deeper paths (pathological tables only) rebuild the full
+    // 256-bit code from parent links
+    struct Frame { int node; int depth; uint64_t path; };
+    std::vector<int> parent(nodes_.size(), -1);
     std::vector<Frame> stack;
-    stack.push_back({root_, 0, Code{}});
+    stack.reserve(64);
+    stack.push_back({root_, 0, 0});
     while (!stack.empty()) {
         Frame f = stack.back();
         stack.pop_back();
         Node &n = nodes_[f.node];
         n.depth = f.depth;
         if (!n.leaf) {
-            if (f.depth == 8) lut_[int(f.path.bits[0] >> 56)] = f.node;          // :111-113
+            if (f.depth == 8) lut_[int(f.path >> 56)] = f.node;                   // :111-113
             if (f.depth >= 255) continue;
-            Frame right{n.child[1], f.depth + 1, f.path};
-            code_set_bit(right.path, f.depth, 1);
-            Frame left{n.child[0], f.depth + 1, f.path};
-            stack.push_back(right);   // popped second
-            stack.push_back(left);    // popped first: left subtree is visited before right
+            parent[n.child[0]] = parent[n.child[1]] = f.node;
+            const uint64_t one = f.depth < 64 ? (1ull << (63 - f.depth)) : 0;
+            stack.push_back({n.child[1], f.depth + 1, f.path | one});   // popped second
+            stack.push_back({n.child[0], f.depth + 1, f.path});         // popped first: left before right
         } else {
-            Code c = f.path;
+            Code c;
             c.len = f.depth;
+            c.bits[0] = f.path;
+            if (f.depth > 64) {
+                int child = f.node;
+                for (int d = f.depth - 1; d >= 64; --d) {
+                    int par = parent[child];
+                    code_set_bit(c, d, nodes_[par].child[1] == child);
+                    child = par;
+                }
+            }
             codes_[n.sym] = c;
-            max_len_ = std::max(max_len_, f.depth);
             if (f.depth >= 1 && f.depth <= 8) {                                   // :116-121
-                int base = int(f.path.bits[0] >> 56);
+                int base = int(f.path >> 56);
                 for (int i = 0; i < (1 << (8 - f.depth)); ++i) lut_[base + i] = f.node;
             }
         }
     }
-    // max_len_ must reflect surviving codes only (a duplicate symbol may have been overwritten)
-    max_len_ = 0;
+    // max_len_ reflects surviving codes only (a duplicate symbol may have been overwritten)
     for (const Code &c : codes_) max_len_ = std::max(max_len_, c.len);
 }
 
@@ -220,6 +242,22 @@ size_t ContextCoder::sec_entries(int P, int hcap) const {
     return total;
 }
 
+void ContextCoder::sec_profile(int hcap, size_t (&out)[9]) const {
+    for (size_t &v : out) v = 0;
+    if (root_ < 0) return;
+    std::vector<std::pair<int, int>> stack{{root_, 0}};
+    while (!stack.empty()) {
+        auto [n, d] = stack.back();
+        stack.pop_back();
+        const Node &nd = nodes_[n];
+        if (nd.leaf) continue;
+        out[d] += size_t(1) << std::min(nd.height, hcap);
+        if (d == 8) continue;
+        stack.push_back({nd.child[0], d + 1});
+        stack.push_back({nd.child[1], d + 1});
+    }
+}
+
 void ContextCoder::pack_decode(int P, int hcap, uint16_t *prim, std::vector<uint16_t> &sec, size_t sec_start,
                                uint32_t *tree) const {
     for (int i = 0; i < (1 << P); ++i) prim[i] = 0;
@@ -276,7 +314,7 @@ int Model::max_code_len() const {
 void Model::build_from_counts(const uint64_t *counts, int order) {
     type = order ? 1 : 0;
     ctx.assign(order ? 256 : 1, ContextCoder{});
-    for (size_t i = 0; i < ctx.size(); ++i) ctx[i].build_from_counts(counts + 256 * i);  // src/markov_huffman.cpp:10-12
+    parallel_for(int(ctx.size()), [&](int i) { ctx[i].build_from_counts(counts + 256 * i); });  // src/markov_huffman.cpp:10-12
 }
 
 bool Model::load_table(const uint8_t *bytes, size_t n) {
@@ -324,50 +362,50 @@ Model::Packed Model::pack() const {
     pk.max_len = max_code_len();
     // ---- decode tables: widest primary whose two levels fit the LDS budget
     const int nctx = type ? 256 : 1;                 // a type-0 model shares one set of tables
-    auto fits = [&](int P, int hcap, bool lds) {
-        size_t total = 0;
-        for (int i = 0; i < nctx; ++i) {
-            size_t e = ctx[i].sec_entries(P, hcap);
-            if (e > size_t(DEC_SEC_MAX_PER_CTX)) return false;
-            total += e;
-        }
-        return !lds || (size_t(256) << P) + total <= size_t(DEC_LDS_ENTRIES);
-    };
     int hcap = 8;
+    auto profile = [&](int cap, size_t (&total)[9], size_t (&worst)[9]) {
+        std::vector<std::array<size_t, 9>> per(nctx);
+        parallel_for(nctx, [&](int i) { size_t o[9]; ctx[i].sec_profile(cap, o); for (int P = 0; P < 9; ++P) per[i][P] = o[P]; });
+        for (int P = 0; P < 9; ++P) { total[P] = worst[P] = 0; for (int i = 0; i < nctx; ++i) { total[P] += per[i][P]; worst[P] = std::max(worst[P], per[i][P]); } }
+    };
+    size_t total[9], worst[9];
+    profile(8, total, worst);
     pk.dec_bits = 0;
     for (int P = 8; P >= 4 && !pk.dec_bits; --P)
-        if (fits(P, 8, true)) pk.dec_bits = P;
+        if (worst[P] <= size_t(DEC_SEC_MAX_PER_CTX) && (size_t(256) << P) + total[P] <= size_t(DEC_LDS_ENTRIES)) pk.dec_bits = P;
     pk.dec_lds = pk.dec_bits != 0;
     if (!pk.dec_lds) {
         pk.dec_bits = 8;
-        while (hcap > 1 && !fits(8, hcap, false)) --hcap;
+        while (worst[8] > size_t(DEC_SEC_MAX_PER_CTX) && hcap > 1) { --hcap; profile(hcap, total, worst); }
     }
     const int P = pk.dec_bits;
     pk.dec_prim.assign(size_t(256) << P, 0);
     pk.sec_base.assign(256, 0);
-    for (int prev = 0; prev < 256; ++prev) {
+    std::vector<std::vector<uint16_t>> sec_of(nctx);
+    parallel_for(256, [&](int prev) {
         const ContextCoder &c = context(prev);
+        if (type != 0 || prev == 0)
+            c.pack_decode(P, hcap, &pk.dec_prim[size_t(prev) << P], sec_of[prev], 0, &pk.tree[prev * TREE_STRIDE]);
+        for (int sym = 0; sym < 256; ++sym) {
+            const Code &cd = c.code(sym);
+            uint32_t window = uint32_t(sym) << 8 | uint32_t(prev);
+            uint16_t e = 0;
+            if (cd.len > ENC16_MAX_LEN) e = ENC16_ESCAPE;
+            else if (cd.len > 0) e = uint16_t((cd.len << 12) | uint32_t(cd.right_aligned()));
+            pk.enc16[enc_slot(window)] = e;
+            pk.len_slot[enc_slot(window)] = uint8_t(std::min(cd.len, 255));
+            pk.len8[prev * 256 + sym] = uint8_t(std::min(cd.len, 255));
+            pk.code64[prev * 256 + sym] = cd.len <= 64 ? cd.right_aligned() : 0;
+        }
+    });
+    pk.any_escape = pk.max_len > ENC16_MAX_LEN;
+    for (int prev = 0; prev < 256; ++prev) {
         if (type == 0 && prev > 0) {
             std::copy(pk.dec_prim.begin(), pk.dec_prim.begin() + (1 << P), pk.dec_prim.begin() + (size_t(prev) << P));
             std::copy(pk.tree.begin(), pk.tree.begin() + TREE_STRIDE, pk.tree.begin() + size_t(prev) * TREE_STRIDE);
         } else {
             pk.sec_base[prev] = uint32_t(pk.dec_sec.size());
-            c.pack_decode(P, hcap, &pk.dec_prim[size_t(prev) << P], pk.dec_sec, pk.dec_sec.size(), &pk.tree[prev * TREE_STRIDE]);
-        }
-        for (int sym = 0; sym < 256; ++sym) {
-            const Code &cd = c.code(sym);
-            uint32_t window = uint32_t(sym) << 8 | uint32_t(prev);
-            uint16_t e = 0;
-            if (cd.len > ENC16_MAX_LEN) {
-                e = ENC16_ESCAPE;
-                pk.any_escape = true;
-            } else if (cd.len > 0) {
-                e = uint16_t((cd.len << 12) | uint32_t(cd.right_aligned()));
-            }
-            pk.enc16[enc_slot(window)] = e;
-            pk.len_slot[enc_slot(window)] = uint8_t(std::min(cd.len, 255));
-            pk.len8[prev * 256 + sym] = uint8_t(std::min(cd.len, 255));
-            pk.code64[prev * 256 + sym] = cd.len <= 64 ? cd.right_aligned() : 0;
+            pk.dec_sec.insert(pk.dec_sec.end(), sec_of[prev].begin(), sec_of[prev].end());
         }
     }
     return pk;

@@ -83,6 +83,8 @@ public:
     int max_len() const { return max_len_; }
     // second-level entries this context needs for primary width P and table-height cap hcap
     size_t sec_entries(int P, int hcap) const;
+    // the same for every P in 0..8 at once (one tree walk): out[P]
+    void sec_profile(int hcap, size_t (&out)[9]) const;
     // packed device images for this context: prim (1 << P entries), this context's second-level
     // tables appended to `sec` (offsets relative to sec_start), walk tree (TREE_STRIDE entries)
     void pack_decode(int P, int hcap, uint16_t *prim, std::vector<uint16_t> &sec, size_t sec_start, uint32_t *tree256) const;
