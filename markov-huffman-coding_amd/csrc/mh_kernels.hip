@@ -221,24 +221,37 @@ __device__ __forceinline__ void windows16(const uint4 &x, uint32_t pb, uint32_t 
     w[13] = x.w & 0xFFFFu; w[14] = (x.w >> 8) & 0xFFFFu; w[15] = x.w >> 16;
 }
 
-// Loads the lane's 16 bytes at `off` (zero past n) and the byte before them.  nvalid = bytes < n.
+// The lane's 16 bytes at `off` (zero past n), issued early so that the next sub-step's HBM latency
+// hides behind the current one's work.  nvalid = bytes < n.  head = the byte before the vector, loaded
+// by lane 0 only (the other lanes take their neighbour's last byte at use time).
+struct LaneIn { uint4 x; uint32_t nvalid; uint32_t head; };
+
+__device__ __forceinline__ LaneIn load_raw(const uint8_t *__restrict__ data, uint64_t n, uint64_t off, uint32_t prev0) {
+    LaneIn r;
+    r.x = make_uint4(0, 0, 0, 0);
+    r.nvalid = 0;
+    r.head = prev0;
+    if (off + E_VEC <= n) {
+        r.x = *reinterpret_cast<const uint4 *>(data + off);
+        r.nvalid = E_VEC;
+    } else if (off < n) {
+        r.nvalid = uint32_t(n - off);
+        uint32_t b[4] = {0, 0, 0, 0};
+        for (uint32_t j = 0; j < r.nvalid; ++j) b[j >> 2] |= uint32_t(data[off + j]) << (8u * (j & 3u));
+        r.x = make_uint4(b[0], b[1], b[2], b[3]);
+    }
+    if ((threadIdx.x & 63u) == 0 && off) r.head = (off - 1 < n) ? uint32_t(data[off - 1]) : 0u;
+    return r;
+}
+// byte before the lane's vector: the previous lane's last byte, except in lane 0
+__device__ __forceinline__ uint32_t head_byte(const LaneIn &in) {
+    uint32_t up = __shfl_up(in.x.w >> 24, 1);
+    return (threadIdx.x & 63u) == 0 ? in.head : up;
+}
 __device__ __forceinline__ void load_lane(const uint8_t *__restrict__ data, uint64_t n, uint64_t off, uint32_t prev0,
                                           uint4 &x, uint32_t &pb, uint32_t &nvalid) {
-    x = make_uint4(0, 0, 0, 0);
-    nvalid = 0;
-    if (off + E_VEC <= n) {
-        x = *reinterpret_cast<const uint4 *>(data + off);
-        nvalid = E_VEC;
-    } else if (off < n) {
-        nvalid = uint32_t(n - off);
-        uint32_t b[4] = {0, 0, 0, 0};
-        for (uint32_t j = 0; j < nvalid; ++j) b[j >> 2] |= uint32_t(data[off + j]) << (8u * (j & 3u));
-        x = make_uint4(b[0], b[1], b[2], b[3]);
-    }
-    // byte before the lane's vector: the previous lane's last byte, except in lane 0
-    uint32_t up = __shfl_up(x.w >> 24, 1);
-    if ((threadIdx.x & 63u) == 0) up = off ? (off - 1 < n ? uint32_t(data[off - 1]) : 0u) : prev0;
-    pb = up;
+    LaneIn in = load_raw(data, n, off, prev0);
+    x = in.x; nvalid = in.nvalid; pb = head_byte(in);
 }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -257,19 +270,23 @@ __global__ __launch_bounds__(E_THREADS, 8) void enc_len_kernel(LenParams p) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t wave0 = uint64_t(blockIdx.x) * E_WAVES + (threadIdx.x >> 6);
     const uint64_t nwaves = uint64_t(gridDim.x) * E_WAVES;
+    LaneIn ahead = load_raw(p.data, p.n, wave0 * E_WT + lane * E_VEC, p.prev0);
     for (uint64_t wt = wave0; wt < p.nwt; wt += nwaves) {
         uint32_t sum = 0;
-#pragma unroll 2
+#pragma unroll 1
         for (int k = 0; k < E_SUBSTEPS; ++k) {
-            uint64_t off = wt * E_WT + uint64_t(k) * E_SUB + lane * E_VEC;
-            uint4 x; uint32_t pb, nvalid;
-            load_lane(p.data, p.n, off, p.prev0, x, pb, nvalid);
+            const LaneIn in = ahead;
+            {
+                const uint64_t nwt_ = (k + 1 < E_SUBSTEPS) ? wt : wt + nwaves;
+                const uint64_t noff = nwt_ * E_WT + uint64_t((k + 1) % E_SUBSTEPS) * E_SUB + lane * E_VEC;
+                ahead = load_raw(p.data, p.n, noff, p.prev0);
+            }
             uint32_t w[16];
-            windows16(x, pb, w);
+            windows16(in.x, head_byte(in), w);
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 uint32_t l = ltab[mh::enc_slot(w[j])];
-                sum += (uint32_t(j) < nvalid) ? l : 0u;
+                sum += (uint32_t(j) < in.nvalid) ? l : 0u;
             }
         }
         sum = wave_sum(sum);
@@ -488,6 +505,8 @@ __global__ __launch_bounds__(E_THREADS) void enc_emit_kernel(EmitParams p) {
     const uint32_t S = 1u << p.chunk_shift;
     const uint64_t wave0 = uint64_t(blockIdx.x) * E_WAVES + wave;
     const uint64_t nwaves = uint64_t(gridDim.x) * E_WAVES;
+    // input runs one sub-step ahead of the work (software pipeline across sub-steps and wave-tiles)
+    LaneIn ahead = load_raw(p.data, p.n, wave0 * E_WT + lane * E_VEC, p.prev0);
     for (uint64_t wt = wave0; wt < p.nwt; wt += nwaves) {
         const uint64_t s = p.wt_start[wt];
         uint64_t gbase = s >> 5;                 // output dword under image word 0
@@ -497,8 +516,15 @@ __global__ __launch_bounds__(E_THREADS) void enc_emit_kernel(EmitParams p) {
 #pragma unroll 1
         for (int k = 0; k < E_SUBSTEPS; ++k) {
             const uint64_t off = wt * E_WT + uint64_t(k) * E_SUB + lane * E_VEC;
-            uint4 x; uint32_t pb, nvalid;
-            load_lane(p.data, p.n, off, p.prev0, x, pb, nvalid);
+            const LaneIn in = ahead;
+            {
+                const uint64_t nwt_ = (k + 1 < E_SUBSTEPS) ? wt : wt + nwaves;
+                const uint64_t noff = nwt_ * E_WT + uint64_t((k + 1) % E_SUBSTEPS) * E_SUB + lane * E_VEC;
+                ahead = load_raw(p.data, p.n, noff, p.prev0);      // past the end: zeros, nothing is read
+            }
+            const uint4 x = in.x;
+            const uint32_t nvalid = in.nvalid;
+            const uint32_t pb = head_byte(in);
             uint32_t L = 0;
             uint64_t g[4]; uint32_t gl[4];
             bool esc = false;

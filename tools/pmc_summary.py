@@ -13,7 +13,7 @@ acc = defaultdict(lambda: defaultdict(float))
 ndisp = defaultdict(lambda: defaultdict(set))
 for f in glob.glob(os.path.join(d, "p*", "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
-        k = row["Kernel_Name"].split("(")[0]
+        k = row["Kernel_Name"].split("(")[0].replace("void ", "")
         if not k.startswith("mhk::"):
             continue
         c = row["Counter_Name"]
