@@ -76,6 +76,7 @@ struct DecParams {
     uint32_t P;
     uint32_t nsec;
     uint32_t sec_lds;             // 1: prim + sec fit LDS
+    uint32_t sec_lds_entries;     // leading sec entries to keep in LDS when they do not all fit
     int *status;
 };
 

@@ -69,6 +69,19 @@ __device__ __forceinline__ void st_desc(unsigned long long *p, uint64_t v) {
     __hip_atomic_store(p, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// 16 consecutive input bytes of a lane (little-endian dwords) + the byte before them -> the 16
+// (prev, sym) windows, window = sym << 8 | prev = the raw 16-bit field of the stream.
+__device__ __forceinline__ void windows16(const uint4 &x, uint32_t pb, uint32_t (&w)[16]) {
+    w[0] = ((x.x << 8) | pb) & 0xFFFFu;
+    w[1] = x.x & 0xFFFFu;  w[2] = (x.x >> 8) & 0xFFFFu;  w[3] = x.x >> 16;
+    w[4] = __builtin_amdgcn_alignbyte(x.y, x.x, 3) & 0xFFFFu;
+    w[5] = x.y & 0xFFFFu;  w[6] = (x.y >> 8) & 0xFFFFu;  w[7] = x.y >> 16;
+    w[8] = __builtin_amdgcn_alignbyte(x.z, x.y, 3) & 0xFFFFu;
+    w[9] = x.z & 0xFFFFu;  w[10] = (x.z >> 8) & 0xFFFFu; w[11] = x.z >> 16;
+    w[12] = __builtin_amdgcn_alignbyte(x.w, x.z, 3) & 0xFFFFu;
+    w[13] = x.w & 0xFFFFu; w[14] = (x.w >> 8) & 0xFFFFu; w[15] = x.w >> 16;
+}
+
 // ------------------------------------------------------------------------------------------------
 // histogram, order 1
 // ------------------------------------------------------------------------------------------------
@@ -106,22 +119,30 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_o1_kernel(const uint8_t *__
     for (uint64_t v = uint64_t(blockIdx.x) * HIST_THREADS + threadIdx.x; v < nvec; v += uint64_t(gridDim.x) * HIST_THREADS) {
         uint4 x = vdata[v];
         uint32_t pb = v ? uint32_t(data[v * 16 - 1]) : prev0;
-        hist_add(h, counts, ((x.x << 8) | pb) & 0xFFFFu);
-        hist_add(h, counts, x.x & 0xFFFFu);
-        hist_add(h, counts, (x.x >> 8) & 0xFFFFu);
-        hist_add(h, counts, x.x >> 16);
-        hist_add(h, counts, __builtin_amdgcn_alignbyte(x.y, x.x, 3) & 0xFFFFu);
-        hist_add(h, counts, x.y & 0xFFFFu);
-        hist_add(h, counts, (x.y >> 8) & 0xFFFFu);
-        hist_add(h, counts, x.y >> 16);
-        hist_add(h, counts, __builtin_amdgcn_alignbyte(x.z, x.y, 3) & 0xFFFFu);
-        hist_add(h, counts, x.z & 0xFFFFu);
-        hist_add(h, counts, (x.z >> 8) & 0xFFFFu);
-        hist_add(h, counts, x.z >> 16);
-        hist_add(h, counts, __builtin_amdgcn_alignbyte(x.w, x.z, 3) & 0xFFFFu);
-        hist_add(h, counts, x.w & 0xFFFFu);
-        hist_add(h, counts, (x.w >> 8) & 0xFFFFu);
-        hist_add(h, counts, x.w >> 16);
+        uint32_t w[16];
+        windows16(x, pb, w);
+        // all 16 returning adds are issued back to back (their latencies overlap); the rare
+        // guard-bit fix-ups are sorted out afterwards
+        uint32_t old[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            w[j] = mh::enc_slot(w[j]);
+            old[j] = atomicAdd(&h[w[j] >> 1], (w[j] & 1u) ? 0x10000u : 1u);
+        }
+        bool ovf = false;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) ovf |= (((w[j] & 1u) ? (old[j] >> 16) : (old[j] & 0xFFFFu)) == 0x7FFFu);
+        if (ovf) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t slot = w[j], hiHalf = slot & 1u;
+                if (((hiHalf ? (old[j] >> 16) : (old[j] & 0xFFFFu)) == 0x7FFFu)) {
+                    atomicSub(&h[slot >> 1], hiHalf ? 0x80000000u : 0x8000u);
+                    uint32_t sym = slot >> 8, prev = (slot ^ sym) & 255u;
+                    atomicAdd(&counts[prev * 256u + sym], 32768ull);
+                }
+            }
+        }
     }
     // ragged tail (< 16 bytes): one lane of block 0
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -207,19 +228,6 @@ constexpr int E_STAGE_BITS = E_SUB * mh::ENC16_MAX_LEN;            // 12288 payl
 constexpr int E_STAGE_WORDS = E_STAGE_BITS / 32 + 8;               // + alignment word + pad
 constexpr int EMIT_LDS_BYTES = 131072 + E_WAVES * E_STAGE_WORDS * 4;
 constexpr int LEN_LDS_BYTES = 65536;
-
-// 16 consecutive input bytes of a lane (little-endian dwords) + the byte before them -> the 16
-// (prev, sym) windows, window = sym << 8 | prev = the raw 16-bit field of the stream.
-__device__ __forceinline__ void windows16(const uint4 &x, uint32_t pb, uint32_t (&w)[16]) {
-    w[0] = ((x.x << 8) | pb) & 0xFFFFu;
-    w[1] = x.x & 0xFFFFu;  w[2] = (x.x >> 8) & 0xFFFFu;  w[3] = x.x >> 16;
-    w[4] = __builtin_amdgcn_alignbyte(x.y, x.x, 3) & 0xFFFFu;
-    w[5] = x.y & 0xFFFFu;  w[6] = (x.y >> 8) & 0xFFFFu;  w[7] = x.y >> 16;
-    w[8] = __builtin_amdgcn_alignbyte(x.z, x.y, 3) & 0xFFFFu;
-    w[9] = x.z & 0xFFFFu;  w[10] = (x.z >> 8) & 0xFFFFu; w[11] = x.z >> 16;
-    w[12] = __builtin_amdgcn_alignbyte(x.w, x.z, 3) & 0xFFFFu;
-    w[13] = x.w & 0xFFFFu; w[14] = (x.w >> 8) & 0xFFFFu; w[15] = x.w >> 16;
-}
 
 // The lane's 16 bytes at `off` (zero past n), issued early so that the next sub-step's HBM latency
 // hides behind the current one's work.  nvalid = bytes < n.  head = the byte before the vector, loaded
@@ -632,9 +640,11 @@ struct BitCursor {
 };
 
 struct DecTables {
-    const uint16_t *sec;         // second-level tables (LDS when they fit, else HBM/L2)
+    const uint16_t *sec;         // second-level tables: LDS copy (decode_kernel) or global (index builder)
     const uint32_t *tree;        // last-resort walk (HBM/L2)
     uint32_t P;                  // primary width in bits
+    const uint16_t *gsec;        // all second-level tables in HBM/L2
+    uint32_t lim;                // entries [0, lim) of gsec are also in `sec` (hybrid mode)
 };
 
 // Decodes one symbol (sequential index builder; tables read from global memory).  Returns the symbol,
@@ -804,7 +814,7 @@ __device__ __forceinline__ bool walk_long(const DecTables &t, LaneStream &ls, ui
 // bits, so one refill covers two symbols — four when the model has no code longer than 8 bits.
 // A null table entry consumes nothing; the caller detects it because the chunk then ends at the wrong
 // bit offset.
-template <int K, bool CHECKED, bool REFILL>
+template <int K, bool CHECKED, bool REFILL, bool HYBRID>
 __device__ __forceinline__ void decode_step(const uint16_t *prim, const uint32_t *sec_base, const DecTables &t,
                                             LaneStream (&ls)[K], uint32_t (&prev)[K], bool &bad) {
     uint32_t hi[K], e[K], sb[K], len[K], sym[K];
@@ -835,7 +845,14 @@ __device__ __forceinline__ void decode_step(const uint16_t *prim, const uint32_t
             // only the lanes that need it take part in the gather: every extra quad of lanes costs the
             // vector L1 a tag lookup even when it reads a dummy address
             e2[k] = 0;
-            if (in) e2[k] = t.sec[sb[k] + (e[k] & 0xFFFu) + ((hi[k] << t.P) >> (32u - h[k]))];
+            const uint32_t idx = sb[k] + (e[k] & 0xFFFu) + ((hi[k] << t.P) >> (32u - h[k]));
+            if (HYBRID) {
+                // tables of the frequent contexts sit in LDS; only the rest goes through the vector L1
+                if (in && idx < t.lim) e2[k] = t.sec[idx];
+                if (in && idx >= t.lim) e2[k] = t.gsec[idx];
+            } else if (in) {
+                e2[k] = t.sec[idx];
+            }
         }
 #pragma unroll
         for (int k = 0; k < K; ++k) {
@@ -869,6 +886,7 @@ constexpr int DEC_LDS_MAX = 163840;
 
 // Decodes `nsym` symbols of ONE chunk that must end at bit `end_bits` (tail groups and the ragged
 // last chunk).
+template <bool HYBRID>
 __device__ __forceinline__ void decode_chunk_single(const uint16_t *lut, const uint32_t *sub_base, const DecTables &t,
                                                     const uint8_t *payload, uint64_t total_bytes, uint64_t nbits,
                                                     uint64_t entry, uint64_t end_bits, uint8_t *o, uint32_t nsym, int *status) {
@@ -880,7 +898,7 @@ __device__ __forceinline__ void decode_chunk_single(const uint16_t *lut, const u
     bool bad = false;
     uint32_t q = 0;
     for (uint32_t i = 0; i < nsym; ++i) {
-        decode_step<1, true, true>(lut, sub_base, t, ls, prev, bad);
+        decode_step<1, true, true, HYBRID>(lut, sub_base, t, ls, prev, bad);
         q |= prev[0] << (8u * (i & 3u));
         if ((i & 3u) == 3u) { *reinterpret_cast<uint32_t *>(o + i - 3u) = q; q = 0; }
     }
@@ -906,7 +924,9 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecParams p) {
     if (threadIdx.x < 256) sub_base[threadIdx.x] = p.sec_base[threadIdx.x];
     __syncthreads();
 
-    const DecTables tabs{SEC_LDS ? lsec : p.sec, p.tree, p.P};
+    // (a hybrid — tables of the frequent contexts in LDS, the rest in L2 — was measured and did not pay:
+    //  some lane still needs L2 in every round, and that latency, not the gather width, is what costs)
+    const DecTables tabs{SEC_LDS ? lsec : p.sec, p.tree, p.P, p.sec, 0xFFFFFFFFu};
     const uint32_t S = 1u << p.chunk_shift;
     const uint64_t full_chunks = p.n >> p.chunk_shift;          // chunks with exactly S symbols
     const uint64_t group = uint64_t(DEC_THREADS) * DEC_K;       // chunks per workgroup iteration
@@ -944,8 +964,8 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecParams p) {
                     for (int k = 0; k < DEC_K; ++k) d[k] = 0;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        if (j % SPR == 0) decode_step<DEC_K, false, true>(lut, sub_base, tabs, ls, prev, bad);
-                        else decode_step<DEC_K, false, false>(lut, sub_base, tabs, ls, prev, bad);
+                        if (j % SPR == 0) decode_step<DEC_K, false, true, false>(lut, sub_base, tabs, ls, prev, bad);
+                        else decode_step<DEC_K, false, false, false>(lut, sub_base, tabs, ls, prev, bad);
 #pragma unroll
                         for (int k = 0; k < DEC_K; ++k) d[k] |= prev[k] << (8 * j);
                     }
@@ -971,7 +991,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecParams p) {
                 const uint64_t first = c << p.chunk_shift;
                 const uint32_t nsym = (p.n - first) >= S ? S : uint32_t(p.n - first);
                 const uint64_t endb = (c + 1 < p.nchunks) ? (p.index[c + 1] & 0x00FFFFFFFFFFFFFFull) : p.nbits;
-                decode_chunk_single(lut, sub_base, tabs, p.payload, p.payload_bytes, p.nbits, p.index[c], endb, p.out + first, nsym, p.status);
+                decode_chunk_single<false>(lut, sub_base, tabs, p.payload, p.payload_bytes, p.nbits, p.index[c], endb, p.out + first, nsym, p.status);
             }
         }
     }
@@ -984,7 +1004,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecParams p) {
 __global__ void build_index_kernel(IdxParams p) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     const BitSrc src{p.payload, p.payload_bytes >> 2, p.payload_bytes};
-    const DecTables tabs{p.sec, p.tree, p.P};
+    const DecTables tabs{p.sec, p.tree, p.P, p.sec, 0};
     BitCursor bc;
     bc.init(src, 0);
     uint64_t bi = 0, nsym = 0;

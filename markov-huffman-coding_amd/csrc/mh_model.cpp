@@ -315,6 +315,9 @@ void Model::build_from_counts(const uint64_t *counts, int order) {
     type = order ? 1 : 0;
     ctx.assign(order ? 256 : 1, ContextCoder{});
     parallel_for(int(ctx.size()), [&](int i) { ctx[i].build_from_counts(counts + 256 * i); });  // src/markov_huffman.cpp:10-12
+    ctx_weight.fill(0);
+    for (size_t i = 0; i < ctx.size(); ++i)
+        for (int s = 0; s < 256; ++s) ctx_weight[i] += counts[256 * i + s];
 }
 
 bool Model::load_table(const uint8_t *bytes, size_t n) {
@@ -399,7 +402,12 @@ Model::Packed Model::pack() const {
         }
     });
     pk.any_escape = pk.max_len > ENC16_MAX_LEN;
-    for (int prev = 0; prev < 256; ++prev) {
+    // second-level tables of the most frequent contexts first: when not everything fits LDS, the
+    // leading part that does is still served from there
+    std::vector<int> order(256);
+    for (int i = 0; i < 256; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ctx_weight[a] > ctx_weight[b]; });
+    for (int prev : order) {
         if (type == 0 && prev > 0) {
             std::copy(pk.dec_prim.begin(), pk.dec_prim.begin() + (1 << P), pk.dec_prim.begin() + (size_t(prev) << P));
             std::copy(pk.tree.begin(), pk.tree.begin() + TREE_STRIDE, pk.tree.begin() + size_t(prev) * TREE_STRIDE);
@@ -408,6 +416,9 @@ Model::Packed Model::pack() const {
             pk.dec_sec.insert(pk.dec_sec.end(), sec_of[prev].begin(), sec_of[prev].end());
         }
     }
+    const size_t room = size_t(DEC_LDS_ENTRIES) - (size_t(256) << P);
+    pk.sec_lds_entries = uint32_t(std::min(pk.dec_sec.size(), room) & ~size_t(7));
+    if (pk.dec_lds) pk.sec_lds_entries = uint32_t(pk.dec_sec.size());
     return pk;
 }
 

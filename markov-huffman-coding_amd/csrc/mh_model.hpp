@@ -136,6 +136,7 @@ class Model {
 public:
     int type = 1;
     std::vector<ContextCoder> ctx;      // size 1 or 256
+    std::array<uint64_t, 256> ctx_weight{};   // symbols seen per context (0 for a loaded table)
     const ContextCoder &context(int prev) const { return type ? ctx[prev & 255] : ctx[0]; }
     int max_code_len() const;
     void build_from_counts(const uint64_t *counts, int order);
@@ -154,6 +155,8 @@ public:
         std::vector<uint32_t> tree;      // 256*TREE_STRIDE
         int dec_bits = 8;                // P
         bool dec_lds = true;             // prim + sec fit the LDS budget
+        uint32_t sec_lds_entries = 0;    // leading sec entries kept in LDS (all of them when dec_lds; else
+                                         // the tables of the most frequent contexts, which are laid out first)
         int max_len = 0;
         bool any_escape = false;
     };
