@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-CHUNK = int(os.environ.get("MH_BENCH_CHUNK", "1024"))
+CHUNK = int(os.environ.get("MH_BENCH_CHUNK", "0"))   # 0: 1024 symbols, 256 below 2 GiB per GPU (keeps every CU busy)
 
 
 def zipf_cdf(device, s=1.1):
@@ -42,9 +42,41 @@ def zipf_cdf(device, s=1.1):
     return cdf.to(torch.float32).to(device)
 
 
+LOREM = ("lorem ipsum dolor sit amet consectetur adipiscing elit sed do eiusmod tempor incididunt ut labore et dolore "
+         "magna aliqua enim ad minim veniam quis nostrud exercitation ullamco laboris nisi aliquip ex ea commodo "
+         "consequat duis aute irure in reprehenderit voluptate velit esse cillum eu fugiat nulla pariatur excepteur "
+         "sint occaecat cupidatat non proident sunt culpa qui officia deserunt mollit anim id est laborum at vero eos "
+         "accusamus iusto odio dignissimos ducimus blanditiis praesentium voluptatum deleniti atque corrupti quos "
+         "dolores quas molestias excepturi occaecati cupiditate provident similique mollitia animi fuga harum quidem "
+         "rerum facilis expedita distinctio nam libero tempore cum soluta nobis eligendi optio cumque nihil impedit "
+         "quo minus quod maxime placeat facere possimus omnis assumenda repellendus temporibus autem quibusdam "
+         "officiis debitis aut necessitatibus saepe eveniet voluptates repudiandae recusandae itaque earum hic "
+         "tenetur sapiente delectus reiciendis voluptatibus maiores alias perferendis doloribus asperiores repellat").split()
+
+
+def lorem_block(nbytes, seed):
+    """Lorem-Ipsum-style ASCII: sentences of 4-16 words, capitalised, '. ' terminated,
+    paragraphs of 3-8 sentences ending in a newline."""
+    rng = np.random.default_rng(seed)
+    out = bytearray()
+    while len(out) < nbytes:
+        for _ in range(int(rng.integers(3, 9))):
+            words = [LOREM[i] for i in rng.integers(0, len(LOREM), int(rng.integers(4, 17)))]
+            words[0] = words[0].capitalize()
+            out += (" ".join(words) + ". ").encode()
+        out[-1:] = b"\n"
+    return bytes(out[:nbytes])
+
+
 def generate(kind, n, seed, first_slice, device):
     """Seeded synthetic bytes, produced slice by slice (2^26 B) so any shard can be regenerated alone."""
     out = torch.empty(n, dtype=torch.uint8, device=device)
+    if kind == "text":
+        # 8 MiB of generated text, tiled (the survey tiled the repo's ipsum file the same way)
+        base = torch.frombuffer(bytearray(lorem_block(min(n, 8 << 20), seed + first_slice)), dtype=torch.uint8).to(device)
+        reps = (n + base.numel() - 1) // base.numel()
+        out.copy_(base.repeat(reps)[:n])
+        return out
     sl = 1 << 26
     cdf = zipf_cdf(device)
     g = torch.Generator(device=device)
@@ -149,7 +181,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=16 << 30, help="bytes per GPU (default 16 GiB)")
-    ap.add_argument("--kind", default="zipf", choices=["zipf", "uniform"])
+    ap.add_argument("--kind", default="zipf", choices=["zipf", "uniform", "text"])
     ap.add_argument("--cpu-sample", type=int, default=256 << 20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -167,7 +199,10 @@ def main():
     mhc = entry.load_package()
     mhc.lib()                      # fails loudly if libmhc.so is missing: there is no fallback path
     n = args.size
-    seed = 2 if args.kind == "zipf" else 3          # C3 seed 2, C4 seed 3
+    global CHUNK
+    if CHUNK == 0:
+        CHUNK = 1024 if n >= (2 << 30) else 256
+    seed = {"zipf": 2, "uniform": 3, "text": 1}[args.kind]     # C2 seed 1, C3 seed 2, C4 seed 3
     slices_per_rank = (n + (1 << 26) - 1) >> 26
     data = generate(args.kind, n, seed, rank * slices_per_rank, device)
     # context of each shard's first byte = last byte of the previous shard (' ' for rank 0)
@@ -261,7 +296,7 @@ def main():
             "ms_per_step": round(elapsed / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "order-1 Markov-Huffman round trip (histogram+tree+encode+decode), %d GiB %s per GPU, "
-                                   "chunk index every %d symbols" % (n >> 30, "Zipf(s=1.1)" if args.kind == "zipf" else "uniform", CHUNK),
+                                   "chunk index every %d symbols" % (n >> 30, {"zipf": "Zipf(s=1.1)", "uniform": "uniform", "text": "Lorem-Ipsum-style ASCII"}[args.kind], CHUNK),
                        "bytes_per_gpu": n, "sharding": "contiguous byte ranges, histogram all-reduce (RCCL)" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,

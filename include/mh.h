@@ -178,8 +178,13 @@ int mh_dev_decode(const mh_model *m, const uint8_t *d_payload, uint64_t nbits,
                   uint8_t *d_out, uint64_t n_symbols,
                   const uint64_t *d_index, uint32_t chunk_symbols,
                   void *d_ws, size_t ws_bytes, void *stream);
-/* Index-building pass for a stream without one (sequential on the device): fills d_index (capacity
- * index_cap entries) and *d_n_symbols.  chunk_symbols as above. */
+/* Index building for a stream without one (what the reference writes: src/coding.cpp:35-59 has no
+ * index): parallel fixed-point iteration over 512-byte bit segments — each segment is decoded from a
+ * guessed state and re-decoded while its predecessor's end state changes; Huffman streams
+ * re-synchronise, so a few passes converge, and a sequential pass is the fallback.  Fills d_index
+ * (capacity index_cap entries) and *d_n_symbols.  Unlike the other device calls this one synchronises
+ * `stream` between batches of passes (the pass count depends on the data). */
+size_t mh_dev_build_index_workspace(uint64_t nbits);
 int mh_dev_build_index(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, uint8_t prev0,
                        uint64_t *d_index, uint64_t index_cap, uint32_t chunk_symbols,
                        uint64_t *d_n_symbols, void *d_ws, size_t ws_bytes, void *stream);

@@ -33,7 +33,7 @@ EXPORTS = [
     "mh_stream_parse_header", "mh_decode",
     "mh_dev_histogram_workspace", "mh_dev_histogram_o1", "mh_dev_histogram_o0",
     "mh_dev_encode_workspace", "mh_dev_encode", "mh_dev_decode_workspace", "mh_dev_decode",
-    "mh_dev_build_index", "mh_dev_status",
+    "mh_dev_build_index_workspace", "mh_dev_build_index", "mh_dev_status",
 ]
 
 
@@ -89,6 +89,8 @@ def lib():
         l.mh_dev_decode_workspace.argtypes = [u64, u64, u32]
         l.mh_dev_decode_workspace.restype = sz
         l.mh_dev_decode.argtypes = [vp, vp, u64, vp, u64, vp, u32, vp, sz, vp]
+        l.mh_dev_build_index_workspace.argtypes = [u64]
+        l.mh_dev_build_index_workspace.restype = sz
         l.mh_dev_build_index.argtypes = [vp, vp, u64, u8, vp, u64, u32, vp, vp, sz, vp]
         l.mh_dev_status.argtypes = [vp, vp]
         _lib = l

@@ -270,6 +270,8 @@ int mh_dev_encode(const mh_model *m, const uint8_t *d_data, size_t n, uint8_t pr
 
 size_t mh_dev_decode_workspace(uint64_t, uint64_t, uint32_t) { return 64; }
 
+size_t mh_dev_build_index_workspace(uint64_t nbits) { return mhk::build_index_workspace_bytes(nbits); }
+
 int mh_dev_decode(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, uint8_t *d_out, uint64_t n_symbols,
                   const uint64_t *d_index, uint32_t chunk_symbols, void *d_ws, size_t ws_bytes, void *stream) {
     if (!m || !d_ws || ws_bytes < 64) return MH_ERR_ARG;
@@ -294,7 +296,8 @@ int mh_dev_decode(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, u
 
 int mh_dev_build_index(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, uint8_t prev0, uint64_t *d_index,
                        uint64_t index_cap, uint32_t chunk_symbols, uint64_t *d_n_symbols, void *d_ws, size_t ws_bytes, void *stream) {
-    if (!m || !d_index || !d_n_symbols || !d_ws || ws_bytes < 64 || (!d_payload && nbits)) return MH_ERR_ARG;
+    if (!m || !d_index || !d_n_symbols || !d_ws || (!d_payload && nbits)) return MH_ERR_ARG;
+    if (ws_bytes < mhk::build_index_workspace_bytes(nbits)) return MH_ERR_CAPACITY;
     int shift = chunk_shift_of(chunk_symbols);
     if (shift < 0 || !aligned16(d_payload)) return MH_ERR_ARG;
     if (m->packed.max_len > mh::MAX_CODE_BITS) return MH_ERR_CODE_TOO_LONG;
@@ -416,10 +419,13 @@ int mh_decode(const mh_model *m, const uint8_t *payload, uint64_t nbits, uint8_t
         uint64_t idx_cap = nbits / chunk_symbols + 2;
         HIP_TRY(d_index.alloc(size_t(idx_cap) * 8));
         HIP_TRY(d_nsym.alloc(8));
+        DevBuf d_iws;
+        const size_t iws = mh_dev_build_index_workspace(nbits);
+        HIP_TRY(d_iws.alloc(iws));
         int rc = mh_dev_build_index(m, d_payload.as<uint8_t>(), nbits, prev0, d_index.as<uint64_t>(), idx_cap, chunk_symbols,
-                                    d_nsym.as<uint64_t>(), d_ws.p, 64, st);
+                                    d_nsym.as<uint64_t>(), d_iws.p, iws, st);
         if (rc != MH_OK) return rc;
-        rc = mh_dev_status(d_ws.p, st);
+        rc = mh_dev_status(d_iws.p, st);
         if (rc != MH_OK) return rc;
         HIP_TRY(hipMemcpy(&n_symbols, d_nsym.p, 8, hipMemcpyDeviceToHost));
     }

@@ -95,6 +95,12 @@ struct IdxParams {
     const uint32_t *tree;
     uint32_t P;
     int *status;
+    // filled by launch_build_index from the workspace
+    unsigned int *changed;
+    unsigned long long *seg_end_state, *seg_used, *seg_sym_start;
+    uint32_t *seg_count;
+    uint32_t seg_shift;
+    uint64_t nseg;
 };
 
 hipError_t launch_hist_o1(const uint8_t *d_data, uint64_t n, uint32_t prev0, unsigned long long *d_counts, hipStream_t st);
@@ -102,6 +108,7 @@ hipError_t launch_hist_o0(const uint8_t *d_data, uint64_t n, unsigned long long 
 size_t encode_workspace_bytes(uint64_t n);
 hipError_t launch_encode(const EncodeArgs &a, void *d_ws, hipStream_t st);
 hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st);
+size_t build_index_workspace_bytes(uint64_t nbits);
 hipError_t launch_build_index(IdxParams p, void *d_ws, hipStream_t st);
 
 }  // namespace mhk

@@ -5,7 +5,7 @@
 //   encode_kernel      single pass: LDS codeword table, wave prefix-sum of bit lengths,
 //                      LDS bit assembly, decoupled look-back across tiles, coalesced store (a9-a12)
 //   decode_kernel      LDS 8-bit LUTs per context + tree-walk fallback, one lane per chunk (a13-a15)
-//   build_index_kernel sequential index builder for streams that come without an index    (N1)
+//   index_sync/fill    parallel index builder for streams that come without an index      (N1)
 //
 // (aN) = row of SURVEY.md §8(a).  All integer/bit work: no MFMA.  No CUDA idioms: waves are 64 wide,
 // cross-lane traffic uses __shfl_up/__ballot on 64 lanes, inter-workgroup hand-off uses single 8-byte
@@ -997,10 +997,103 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecParams p) {
     }
 }
 
-// Sequential pass over a stream that has no index (one produced by the reference: src/coding.cpp
-// has none): walks the whole payload once on one lane, recording (bit offset, context) every
-// chunk_symbols symbols and the total symbol count.  The loop condition is the reference's
-// `while(bi < length)` (src/coding.cpp:124).
+// ---- index builder for streams that come without an index ---------------------------------------
+// The reference's stream has no index (src/coding.cpp:35-59) and the decoder state is (bit position,
+// previous byte).  Parallel reconstruction by fixed-point iteration over bit segments of 2^seg_shift
+// bits: segment i's start state is segment i-1's end state; every segment starts from a guess and is
+// re-decoded whenever its predecessor's end state changes.  Segment 0 is exact after pass 0, and
+// Huffman streams re-synchronise after a few symbols, so a handful of passes converge; a pass that
+// recomputes nothing proves the fixed point (= the true decode).  Then a prefix sum of the symbol
+// counts and one more pass emit the regular chunk index.
+constexpr uint64_t ST_POS = 0x00FFFFFFFFFFFFFFull;
+__device__ __forceinline__ uint64_t st_pack(uint32_t prev, uint64_t pos) { return (uint64_t(prev) << 56) | pos; }
+
+// Decodes from `start` until the bit position reaches seg_end.  Returns the end state; *count = symbols
+// whose code starts before seg_end.  ON_SYMBOL(k, prev_before, pos_before) is called per symbol.
+// A null table entry stops the walk (*bad): speculative starts may run into one legitimately.
+template <typename F>
+__device__ __forceinline__ uint64_t walk_segment(const IdxParams &p, const DecTables &tabs, const BitSrc &src, uint64_t start,
+                                                 uint64_t seg_end, uint32_t &count, bool &bad, F on_symbol) {
+    uint64_t pos = start & ST_POS;
+    uint32_t prev = uint32_t(start >> 56);
+    count = 0;
+    bad = false;
+    if (pos >= seg_end) return start;
+    BitCursor bc;
+    bc.init(src, pos);
+    while (pos < seg_end) {
+        on_symbol(count, prev, pos);
+        uint32_t used = 0;
+        uint32_t sym = decode_one(p.prim, p.sec_base, tabs, src, bc, prev, used, bad);
+        if (bad) break;
+        prev = sym;
+        pos += used;
+        ++count;
+    }
+    return st_pack(prev, pos);
+}
+
+__global__ __launch_bounds__(256) void index_sync_kernel(IdxParams p, uint32_t iter) {
+    if (iter > 0 && p.changed[iter - 1] == 0) return;                  // already at the fixed point
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= p.nseg) return;
+    const uint64_t seg_end = ((i + 1) << p.seg_shift) < p.nbits ? ((i + 1) << p.seg_shift) : p.nbits;
+    uint64_t start;
+    if (i == 0) start = st_pack(p.prev0, 0);
+    else if (iter == 0) start = st_pack(0x20, i << p.seg_shift);
+    else start = __hip_atomic_load(&p.seg_end_state[i - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (iter > 0 && start == p.seg_used[i]) return;                    // same input as last time
+    const BitSrc src{p.payload, p.payload_bytes >> 2, p.payload_bytes};
+    const DecTables tabs{p.sec, p.tree, p.P, p.sec, 0};
+    uint32_t count;
+    bool bad;
+    uint64_t end = walk_segment(p, tabs, src, start, seg_end, count, bad, [](uint32_t, uint32_t, uint64_t) {});
+    if (bad) end = st_pack(uint32_t(end >> 56), seg_end);              // a guess that ran into nothing: park it
+    __hip_atomic_store(&p.seg_end_state[i], (unsigned long long)end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    p.seg_used[i] = start;
+    p.seg_count[i] = count;
+    atomicAdd(&p.changed[iter], 1u);
+}
+
+// adds the block offsets of the two-level scan (seg_sym_start holds block-local prefixes)
+__global__ __launch_bounds__(SCAN_THREADS) void index_scan_add_kernel(unsigned long long *seg_sym_start, const unsigned long long *blk_sum,
+                                                                      uint64_t nseg, uint64_t nblk, unsigned long long *n_symbols) {
+    const unsigned long long boff = blk_sum[blockIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_symbols = blk_sum[nblk];
+    uint64_t i0 = uint64_t(blockIdx.x) * SCAN_BLOCK + uint64_t(threadIdx.x) * SCAN_PER_THREAD;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; ++k)
+        if (i0 + k < nseg) seg_sym_start[i0 + k] += boff;
+}
+
+// final pass: true start states are known; write one index entry per chunk_symbols symbols
+__global__ __launch_bounds__(256) void index_fill_kernel(IdxParams p) {
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= p.nseg) return;
+    const uint64_t seg_end = ((i + 1) << p.seg_shift) < p.nbits ? ((i + 1) << p.seg_shift) : p.nbits;
+    const uint64_t start = i == 0 ? st_pack(p.prev0, 0) : p.seg_end_state[i - 1];
+    const uint64_t base = p.seg_sym_start[i];
+    const uint64_t smask = (1ull << p.chunk_shift) - 1;
+    const BitSrc src{p.payload, p.payload_bytes >> 2, p.payload_bytes};
+    const DecTables tabs{p.sec, p.tree, p.P, p.sec, 0};
+    uint32_t count;
+    bool bad, overflow = false;
+    uint64_t end = walk_segment(p, tabs, src, start, seg_end, count, bad, [&](uint32_t k, uint32_t prev, uint64_t pos) {
+        const uint64_t g = base + k;
+        if ((g & smask) == 0) {
+            const uint64_t ci = g >> p.chunk_shift;
+            if (ci < p.index_cap) p.index[ci] = st_pack(prev, pos); else overflow = true;
+        }
+    });
+    if (overflow) atomicExch(p.status, MHK_STATUS_CAPACITY);
+    // with true start states a null entry, a mismatch with the converged end state, or a stream that does
+    // not end exactly at nbits (src/coding.cpp:124,158) means the stream does not belong to this table
+    if (bad || end != p.seg_end_state[i] || count != p.seg_count[i] || (i + 1 == p.nseg && (end & ST_POS) != p.nbits))
+        atomicExch(p.status, MHK_STATUS_CORRUPT);
+}
+
+// Sequential fallback (one lane) for streams whose segments refuse to synchronise: walks the whole
+// payload once.  The loop condition is the reference's `while(bi < length)` (src/coding.cpp:124).
 __global__ void build_index_kernel(IdxParams p) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     const BitSrc src{p.payload, p.payload_bytes >> 2, p.payload_bytes};
@@ -1140,13 +1233,64 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
     return hipGetLastError();
 }
 
+// workspace: [0,64) status | changed u32[IDX_MAX_PASSES] | end_state u64[nseg] | used u64[nseg] |
+//            count u32[nseg] | sym_start u64[nseg] | blk_sum u64[nblk + 1]
+constexpr uint32_t IDX_SEG_SHIFT = 12;         // 4096-bit (512-byte) segments
+constexpr uint32_t IDX_MAX_PASSES = 96;
+struct IdxWs { size_t off_changed, off_end, off_used, off_count, off_start, off_blk, total; uint64_t nseg, nblk; };
+static IdxWs idx_ws_layout(uint64_t nbits) {
+    IdxWs w;
+    w.nseg = (nbits + (1ull << IDX_SEG_SHIFT) - 1) >> IDX_SEG_SHIFT;
+    w.nblk = (w.nseg + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    auto up = [](size_t v) { return (v + 63) & ~size_t(63); };
+    w.off_changed = 64;
+    w.off_end = up(w.off_changed + IDX_MAX_PASSES * 4);
+    w.off_used = up(w.off_end + size_t(w.nseg) * 8);
+    w.off_count = up(w.off_used + size_t(w.nseg) * 8);
+    w.off_start = up(w.off_count + size_t(w.nseg) * 4);
+    w.off_blk = up(w.off_start + size_t(w.nseg) * 8);
+    w.total = up(w.off_blk + size_t(w.nblk + 1) * 8);
+    return w;
+}
+size_t build_index_workspace_bytes(uint64_t nbits) { return idx_ws_layout(nbits).total; }
+
+// Synchronises `st` between batches of passes (the pass count depends on the data).
 hipError_t launch_build_index(IdxParams p, void *d_ws, hipStream_t st) {
-    p.status = reinterpret_cast<int *>(d_ws);
-    hipError_t e = hipMemsetAsync(d_ws, 0, 64, st);
+    unsigned char *ws = static_cast<unsigned char *>(d_ws);
+    const IdxWs L = idx_ws_layout(p.nbits);
+    p.status = reinterpret_cast<int *>(ws);
+    p.changed = reinterpret_cast<unsigned int *>(ws + L.off_changed);
+    p.seg_end_state = reinterpret_cast<unsigned long long *>(ws + L.off_end);
+    p.seg_used = reinterpret_cast<unsigned long long *>(ws + L.off_used);
+    p.seg_count = reinterpret_cast<uint32_t *>(ws + L.off_count);
+    p.seg_sym_start = reinterpret_cast<unsigned long long *>(ws + L.off_start);
+    p.seg_shift = IDX_SEG_SHIFT;
+    p.nseg = L.nseg;
+    hipError_t e = hipMemsetAsync(ws, 0, L.off_end, st);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(p.n_symbols, 0, 8, st);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(build_index_kernel, dim3(1), dim3(64), 0, st, p);
+    if (e != hipSuccess || p.nbits == 0) return e;
+    const unsigned grid = unsigned((L.nseg + 255) / 256);
+    bool converged = false;
+    for (uint32_t it = 0; it < IDX_MAX_PASSES && !converged;) {
+        const uint32_t batch_end = it + 8 < IDX_MAX_PASSES ? it + 8 : IDX_MAX_PASSES;
+        for (; it < batch_end; ++it) hipLaunchKernelGGL(index_sync_kernel, dim3(grid), dim3(256), 0, st, p, it);
+        unsigned int last = 1;
+        e = hipMemcpyAsync(&last, p.changed + (it - 1), 4, hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) return e;
+        e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return e;
+        converged = last == 0;
+    }
+    if (!converged) {      // segments that never re-synchronise: do it the slow, certain way
+        hipLaunchKernelGGL(build_index_kernel, dim3(1), dim3(64), 0, st, p);
+        return hipGetLastError();
+    }
+    unsigned long long *blk_sum = reinterpret_cast<unsigned long long *>(ws + L.off_blk);
+    hipLaunchKernelGGL(scan_local_kernel, dim3(unsigned(L.nblk)), dim3(SCAN_THREADS), 0, st, p.seg_count, L.nseg, p.seg_sym_start, blk_sum);
+    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, blk_sum, L.nblk);
+    hipLaunchKernelGGL(index_scan_add_kernel, dim3(unsigned(L.nblk)), dim3(SCAN_THREADS), 0, st, p.seg_sym_start, blk_sum, L.nseg, L.nblk, p.n_symbols);
+    hipLaunchKernelGGL(index_fill_kernel, dim3(grid), dim3(256), 0, st, p);
     return hipGetLastError();
 }
 

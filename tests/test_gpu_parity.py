@@ -166,7 +166,7 @@ def test_round_trip_golden_inputs_with_index(mhc, name, order):
     assert m.decompress(blob, index=idx, chunk_symbols=256, n_symbols=len(data)) == data
 
 
-@pytest.mark.parametrize("name", [n for n in golden_names() if n != "kat4"])
+@pytest.mark.parametrize("name", golden_names())
 @pytest.mark.parametrize("order", [0, 1])
 def test_decode_reference_stream_without_index(mhc, oracle, name, order):
     """Drop-in case: the stream was produced by the reference (here: the oracle, pinned to it) and has
@@ -176,6 +176,25 @@ def test_decode_reference_stream_without_index(mhc, oracle, name, order):
         pytest.skip("empty -h table")
     o = oracle.Model.from_data(data, order)
     blob, _ = o.compress(data)
+    m = mhc.Model.from_table(o.table_bytes())
+    assert m.decompress(blob) == data
+
+
+@pytest.mark.parametrize("kind", ["zipf", "text", "uniform", "skewed"])
+def test_index_free_decode_large(mhc, oracle, kind):
+    """N1: a stream as the reference writes it (no index) is decoded by the parallel segment
+    synchronisation pass + the regular chunk decoder; 8 MiB so that thousands of segments take part."""
+    n = 8 << 20
+    if kind == "zipf":
+        data = zipf_bytes(n, 21)
+    elif kind == "text":
+        data = text_like(n, 22)
+    elif kind == "uniform":
+        data = np.random.default_rng(23).integers(0, 256, n, dtype=np.uint8).tobytes()
+    else:
+        data = _skewed(n, 24)
+    o = oracle.Model.from_data(data, 1)
+    blob, _ = o.compress(data)                      # produced by the (oracle-pinned) reference path
     m = mhc.Model.from_table(o.table_bytes())
     assert m.decompress(blob) == data
 
