@@ -69,6 +69,20 @@ __device__ __forceinline__ void st_desc(unsigned long long *p, uint64_t v) {
     __hip_atomic_store(p, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave with DPP row shifts / row broadcasts (7 VALU
+// instructions; the __shfl_up form costs six LDS-crossbar round trips).
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
+    // within each row of 16 lanes
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x111, 0xF, 0xF, true));   // row_shr:1
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x112, 0xF, 0xF, true));   // row_shr:2
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x114, 0xF, 0xF, true));   // row_shr:4
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x118, 0xF, 0xF, true));   // row_shr:8
+    // carry row totals forward: lane 15 of a row into the next row, then lane 31 into rows 2 and 3
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x142, 0xA, 0xF, false));  // row_bcast:15, rows 1 and 3
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x143, 0xC, 0xF, false));  // row_bcast:31, rows 2 and 3
+    return v;
+}
+
 // 16 consecutive input bytes of a lane (little-endian dwords) + the byte before them -> the 16
 // (prev, sym) windows, window = sym << 8 | prev = the raw 16-bit field of the stream.
 __device__ __forceinline__ void windows16(const uint4 &x, uint32_t pb, uint32_t (&w)[16]) {
@@ -560,13 +574,8 @@ __global__ __launch_bounds__(E_THREADS) void enc_emit_kernel(EmitParams p) {
                 emit_substep_slow(p, tab, stage, out32, x, pb, nvalid, lane, off, abs_bits, gbase, cur, seam0, sub_bits);
             } else {
                 // exclusive wave scan of the lane totals
-                uint32_t inc = L;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    uint32_t t = __shfl_up(inc, d);
-                    if (lane >= uint32_t(d)) inc += t;
-                }
-                sub_bits = __shfl(inc, 63);
+                const uint32_t inc = wave_inclusive_sum(L);
+                sub_bits = __builtin_amdgcn_readlane(inc, 63);
                 const uint32_t exc = inc - L;
                 // chunk index: the lane whose first byte starts a chunk records (context, bit offset)
                 if (p.index && nvalid && ((uint32_t(off) & (S - 1u)) == 0u))
