@@ -305,10 +305,15 @@ __global__ __launch_bounds__(E_THREADS, 8) void enc_len_kernel(LenParams p) {
             }
             uint32_t w[16];
             windows16(in.x, head_byte(in), w);
+            if (__all(in.nvalid == E_VEC)) {             // wave-uniform: everything but the stream's last vectors
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                uint32_t l = ltab[mh::enc_slot(w[j])];
-                sum += (uint32_t(j) < in.nvalid) ? l : 0u;
+                for (int j = 0; j < 16; ++j) sum += ltab[mh::enc_slot(w[j])];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    uint32_t l = ltab[mh::enc_slot(w[j])];
+                    sum += (uint32_t(j) < in.nvalid) ? l : 0u;
+                }
             }
         }
         sum = wave_sum(sum);
@@ -413,9 +418,9 @@ __device__ __forceinline__ void deposit(uint32_t *stage, uint64_t vl, uint32_t o
         if (w1 && wi + 1u < nwords) atomicOr(&stage[wi + 1u], w1);
         if (w2 && wi + 2u < nwords) atomicOr(&stage[wi + 2u], w2);
     } else {
-        if (w0) atomicOr(&stage[wi], w0);
-        if (w1) atomicOr(&stage[wi + 1u], w1);
-        if (w2) atomicOr(&stage[wi + 2u], w2);
+        atomicOr(&stage[wi], w0);                 // OR-ing a zero is harmless and cheaper than testing for it
+        atomicOr(&stage[wi + 1u], w1);
+        if (w2) atomicOr(&stage[wi + 2u], w2);    // only groups that straddle two word boundaries
     }
 }
 
@@ -549,7 +554,7 @@ __global__ __launch_bounds__(E_THREADS) void enc_emit_kernel(EmitParams p) {
             const uint32_t pb = head_byte(in);
             uint32_t L = 0;
             uint64_t g[4]; uint32_t gl[4];
-            bool esc = false;
+            uint32_t emax = nvalid == E_VEC ? 0u : 0xFFFFu;   // ragged vectors take the symbol-by-symbol path
             {
                 uint32_t w[16];
                 windows16(x, pb, w);
@@ -558,8 +563,8 @@ __global__ __launch_bounds__(E_THREADS) void enc_emit_kernel(EmitParams p) {
                     uint32_t e[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        e[j] = (uint32_t(4 * q + j) < nvalid) ? uint32_t(tab[mh::enc_slot(w[4 * q + j])]) : 0u;
-                        esc |= e[j] >= 0xD000u;
+                        e[j] = uint32_t(tab[mh::enc_slot(w[4 * q + j])]);
+                        emax = e[j] > emax ? e[j] : emax;
                     }
                     uint32_t l0 = e[0] >> 12, l1 = e[1] >> 12, l2 = e[2] >> 12, l3 = e[3] >> 12;
                     uint32_t p01 = ((e[0] & 0xFFFu) << l1) | (e[1] & 0xFFFu);
@@ -570,7 +575,7 @@ __global__ __launch_bounds__(E_THREADS) void enc_emit_kernel(EmitParams p) {
                 }
             }
             uint32_t sub_bits;
-            if (__any(esc)) {                    // wave-uniform
+            if (__any(emax >= 0xD000u)) {        // wave-uniform: an escape code or a ragged vector somewhere
                 emit_substep_slow(p, tab, stage, out32, x, pb, nvalid, lane, off, abs_bits, gbase, cur, seam0, sub_bits);
             } else {
                 // exclusive wave scan of the lane totals
