@@ -25,6 +25,7 @@ struct mh_model {
     uint16_t *d_sec = nullptr;
     uint32_t *d_sec_base = nullptr;
     uint32_t *d_tree = nullptr;
+    void *d_block = nullptr;     // the one allocation all of the above point into
 };
 
 namespace {
@@ -83,25 +84,28 @@ int upload_model(mh_model *m) {
     if (m->packed.max_len > mh::MAX_CODE_BITS) return MH_OK;   // compute calls report MH_ERR_CODE_TOO_LONG
     HIP_TRY(hipGetDevice(&m->device));
     const mh::Model::Packed &pk = m->packed;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_enc16), 65536 * 2));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_len8), 65536));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_code64), 65536 * 8));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_tree), 256 * mh::TREE_STRIDE * 4));
-    HIP_TRY(hipMemcpy(m->d_enc16, pk.enc16.data(), 65536 * 2, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(m->d_len8, pk.len8.data(), 65536, hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_len_slot), 65536));
-    HIP_TRY(hipMemcpy(m->d_len_slot, pk.len_slot.data(), 65536, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(m->d_code64, pk.code64.data(), 65536 * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(m->d_tree, pk.tree.data(), 256 * mh::TREE_STRIDE * 4, hipMemcpyHostToDevice));
-    const size_t prim_bytes = pk.dec_prim.size() * 2;
+    // one device allocation and one upload for all images (each piece 256-byte aligned)
+    struct Piece { const void *src; size_t bytes; void **dst; };
     const size_t sec_bytes = (pk.dec_sec.size() * 2 + 15) & ~size_t(15);     // kernels copy whole uint4s
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_prim), prim_bytes));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_sec), sec_bytes ? sec_bytes : 16));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_sec_base), 256 * 4));
-    HIP_TRY(hipMemcpy(m->d_prim, pk.dec_prim.data(), prim_bytes, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(m->d_sec, 0, sec_bytes ? sec_bytes : 16));
-    if (!pk.dec_sec.empty()) HIP_TRY(hipMemcpy(m->d_sec, pk.dec_sec.data(), pk.dec_sec.size() * 2, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(m->d_sec_base, pk.sec_base.data(), 256 * 4, hipMemcpyHostToDevice));
+    const Piece pieces[] = {
+        {pk.enc16.data(), 65536 * 2, reinterpret_cast<void **>(&m->d_enc16)},
+        {pk.len8.data(), 65536, reinterpret_cast<void **>(&m->d_len8)},
+        {pk.len_slot.data(), 65536, reinterpret_cast<void **>(&m->d_len_slot)},
+        {pk.code64.data(), 65536 * 8, reinterpret_cast<void **>(&m->d_code64)},
+        {pk.tree.data(), size_t(256) * mh::TREE_STRIDE * 4, reinterpret_cast<void **>(&m->d_tree)},
+        {pk.dec_prim.data(), pk.dec_prim.size() * 2, reinterpret_cast<void **>(&m->d_prim)},
+        {pk.dec_sec.data(), pk.dec_sec.size() * 2, reinterpret_cast<void **>(&m->d_sec)},
+        {pk.sec_base.data(), 256 * 4, reinterpret_cast<void **>(&m->d_sec_base)},
+    };
+    size_t total = 0, off[8];
+    for (int i = 0; i < 8; ++i) { off[i] = total; total += ((i == 6 ? sec_bytes : pieces[i].bytes) + 255) & ~size_t(255); }
+    total += 256;
+    std::vector<unsigned char> staging(total, 0);
+    for (int i = 0; i < 8; ++i)
+        if (pieces[i].bytes) std::memcpy(staging.data() + off[i], pieces[i].src, pieces[i].bytes);
+    HIP_TRY(hipMalloc(&m->d_block, total));
+    HIP_TRY(hipMemcpy(m->d_block, staging.data(), total, hipMemcpyHostToDevice));
+    for (int i = 0; i < 8; ++i) *pieces[i].dst = static_cast<unsigned char *>(m->d_block) + off[i];
     return MH_OK;
 }
 
@@ -220,14 +224,7 @@ int mh_model_decode_layout(const mh_model *m, int *primary_bits, int *secondary_
 
 void mh_model_free(mh_model *m) {
     if (!m) return;
-    if (m->d_enc16) (void)hipFree(m->d_enc16);
-    if (m->d_len8) (void)hipFree(m->d_len8);
-    if (m->d_len_slot) (void)hipFree(m->d_len_slot);
-    if (m->d_code64) (void)hipFree(m->d_code64);
-    if (m->d_prim) (void)hipFree(m->d_prim);
-    if (m->d_sec) (void)hipFree(m->d_sec);
-    if (m->d_sec_base) (void)hipFree(m->d_sec_base);
-    if (m->d_tree) (void)hipFree(m->d_tree);
+    if (m->d_block) (void)hipFree(m->d_block);
     delete m;
 }
 
