@@ -287,6 +287,7 @@ int mh_dev_decode(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, u
     p.prim = m->d_prim; p.sec = m->d_sec; p.sec_base = m->d_sec_base; p.tree = m->d_tree;
     p.P = uint32_t(m->packed.dec_bits); p.nsec = uint32_t(m->packed.dec_sec.size()); p.sec_lds = m->packed.dec_lds ? 1u : 0u;
     p.sec_lds_entries = m->packed.sec_lds_entries;
+    p.direct = m->packed.dec_direct ? 1u : 0u; p.H = uint32_t(m->packed.dec_h);
     HIP_TRY(mhk::launch_decode(p, d_ws, static_cast<hipStream_t>(stream)));
     return MH_OK;
 }
@@ -306,6 +307,7 @@ int mh_dev_build_index(const mh_model *m, const uint8_t *d_payload, uint64_t nbi
     p.n_symbols = reinterpret_cast<unsigned long long *>(d_n_symbols);
     p.prim = m->d_prim; p.sec = m->d_sec; p.sec_base = m->d_sec_base; p.tree = m->d_tree;
     p.P = uint32_t(m->packed.dec_bits);
+    p.direct = m->packed.dec_direct ? 1u : 0u; p.H = uint32_t(m->packed.dec_h);
     HIP_TRY(mhk::launch_build_index(p, d_ws, static_cast<hipStream_t>(stream)));
     return MH_OK;
 }

@@ -77,6 +77,8 @@ struct DecParams {
     uint32_t nsec;
     uint32_t sec_lds;             // 1: prim + sec fit LDS
     uint32_t sec_lds_entries;     // leading sec entries to keep in LDS when they do not all fit
+    uint32_t direct;              // 1: uniform tables of 2^H entries, inner entry = 0x8000 | table id
+    uint32_t H;
     int *status;
 };
 
@@ -94,6 +96,7 @@ struct IdxParams {
     const uint32_t *sec_base;
     const uint32_t *tree;
     uint32_t P;
+    uint32_t direct, H;
     int *status;
     // filled by launch_build_index from the workspace
     unsigned int *changed;

@@ -659,6 +659,7 @@ struct DecTables {
     uint32_t P;                  // primary width in bits
     const uint16_t *gsec;        // all second-level tables in HBM/L2
     uint32_t lim;                // entries [0, lim) of gsec are also in `sec` (hybrid mode)
+    uint32_t direct, H;          // uniform L2 tables: inner entry = 0x8000 | table id, 2^H entries each
 };
 
 // Decodes one symbol (sequential index builder; tables read from global memory).  Returns the symbol,
@@ -675,9 +676,10 @@ __device__ __forceinline__ uint32_t decode_one(const uint16_t *prim, const uint3
         return e & 255u;
     }
     // longer code (src/coding.cpp:129-149): the node's own table, indexed by the next h bits
-    const uint32_t h = ((e >> 12) & 7u) + 1u;
+    const uint32_t h = t.direct ? t.H : ((e >> 12) & 7u) + 1u;
     bc.drop(t.P);
-    uint32_t e2 = t.sec[sec_base[prev] + (e & 0xFFFu) + uint32_t(bc.buf >> (64u - h))];
+    const uint32_t tbase = t.direct ? ((e & 0x7FFFu) << t.H) : sec_base[prev] + (e & 0xFFFu);
+    uint32_t e2 = t.sec[tbase + uint32_t(bc.buf >> (64u - h))];
     if (!(e2 & DEC16_INNER)) {
         uint32_t len = e2 >> 8;
         bad |= (e2 == 0);
@@ -828,7 +830,7 @@ __device__ __forceinline__ bool walk_long(const DecTables &t, LaneStream &ls, ui
 // bits, so one refill covers two symbols — four when the model has no code longer than 8 bits.
 // A null table entry consumes nothing; the caller detects it because the chunk then ends at the wrong
 // bit offset.
-template <int K, bool CHECKED, bool REFILL, bool HYBRID>
+template <int K, bool CHECKED, bool REFILL, bool HYBRID, bool DIRECT = false>
 __device__ __forceinline__ void decode_step(const uint16_t *prim, const uint32_t *sec_base, const DecTables &t,
                                             LaneStream (&ls)[K], uint32_t (&prev)[K], bool &bad) {
     uint32_t hi[K], e[K], sb[K], len[K], sym[K];
@@ -841,7 +843,7 @@ __device__ __forceinline__ void decode_step(const uint16_t *prim, const uint32_t
     for (int k = 0; k < K; ++k) {
         hi[k] = uint32_t(ls[k].buf >> 32);
         e[k] = prim[(prev[k] << t.P) | (hi[k] >> (32u - t.P))];
-        sb[k] = sec_base[prev[k]];                              // independent of e[k]: same latency
+        sb[k] = DIRECT ? 0u : sec_base[prev[k]];                // independent of e[k]: same latency
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -855,11 +857,12 @@ __device__ __forceinline__ void decode_step(const uint16_t *prim, const uint32_t
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const bool in = (e[k] & DEC16_INNER) != 0;
-            h[k] = ((e[k] >> 12) & 7u) + 1u;
+            h[k] = DIRECT ? t.H : ((e[k] >> 12) & 7u) + 1u;
             // only the lanes that need it take part in the gather: every extra quad of lanes costs the
             // vector L1 a tag lookup even when it reads a dummy address
             e2[k] = 0;
-            const uint32_t idx = sb[k] + (e[k] & 0xFFFu) + ((hi[k] << t.P) >> (32u - h[k]));
+            const uint32_t idx = DIRECT ? (((e[k] & 0x7FFFu) << t.H) | ((hi[k] << t.P) >> (32u - t.H)))
+                                        : sb[k] + (e[k] & 0xFFFu) + ((hi[k] << t.P) >> (32u - h[k]));
             if (HYBRID) {
                 // tables of the frequent contexts sit in LDS; only the rest goes through the vector L1
                 if (in && idx < t.lim) e2[k] = t.sec[idx];
@@ -871,7 +874,7 @@ __device__ __forceinline__ void decode_step(const uint16_t *prim, const uint32_t
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             if (e[k] & DEC16_INNER) {
-                len[k] = (e2[k] >> 8) ? t.P + (e2[k] >> 8) : 0u;        // null second-level entry -> 0
+                len[k] = t.P + (e2[k] >> 8);     // a null entry ends the chunk at the wrong bit: caught there
                 sym[k] = e2[k] & 255u;
                 deep |= (e2[k] & DEC16_INNER) != 0;
             }
@@ -900,7 +903,7 @@ constexpr int DEC_LDS_MAX = 163840;
 
 // Decodes `nsym` symbols of ONE chunk that must end at bit `end_bits` (tail groups and the ragged
 // last chunk).
-template <bool HYBRID>
+template <bool HYBRID, bool DIRECT>
 __device__ __forceinline__ void decode_chunk_single(const uint16_t *lut, const uint32_t *sub_base, const DecTables &t,
                                                     const uint8_t *payload, uint64_t total_bytes, uint64_t nbits,
                                                     uint64_t entry, uint64_t end_bits, uint8_t *o, uint32_t nsym, int *status) {
@@ -912,7 +915,7 @@ __device__ __forceinline__ void decode_chunk_single(const uint16_t *lut, const u
     bool bad = false;
     uint32_t q = 0;
     for (uint32_t i = 0; i < nsym; ++i) {
-        decode_step<1, true, true, HYBRID>(lut, sub_base, t, ls, prev, bad);
+        decode_step<1, true, true, HYBRID, DIRECT>(lut, sub_base, t, ls, prev, bad);
         q |= prev[0] << (8u * (i & 3u));
         if ((i & 3u) == 3u) { *reinterpret_cast<uint32_t *>(o + i - 3u) = q; q = 0; }
     }
@@ -920,7 +923,7 @@ __device__ __forceinline__ void decode_chunk_single(const uint16_t *lut, const u
     if (bad || bitpos + ls[0].consumed() != end_bits) atomicExch(status, MHK_STATUS_CORRUPT);
 }
 
-template <bool SEC_LDS, int SPR>   // SPR = symbols per window refill (2, or 4 when no code exceeds 8 bits)
+template <bool SEC_LDS, int SPR, bool DIRECT>   // SPR = symbols per window refill (2, or 4 when no code exceeds 8 bits)
 __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS: sec_base u32[256] | prim u16[256 << P] | sec u16[nsec] (only when the model's tables fit)
@@ -940,7 +943,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecParams p) {
 
     // (a hybrid — tables of the frequent contexts in LDS, the rest in L2 — was measured and did not pay:
     //  some lane still needs L2 in every round, and that latency, not the gather width, is what costs)
-    const DecTables tabs{SEC_LDS ? lsec : p.sec, p.tree, p.P, p.sec, 0xFFFFFFFFu};
+    const DecTables tabs{SEC_LDS ? lsec : p.sec, p.tree, p.P, p.sec, 0xFFFFFFFFu, p.direct, p.H};
     const uint32_t S = 1u << p.chunk_shift;
     const uint64_t full_chunks = p.n >> p.chunk_shift;          // chunks with exactly S symbols
     const uint64_t group = uint64_t(DEC_THREADS) * DEC_K;       // chunks per workgroup iteration
@@ -978,8 +981,8 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecParams p) {
                     for (int k = 0; k < DEC_K; ++k) d[k] = 0;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        if (j % SPR == 0) decode_step<DEC_K, false, true, false>(lut, sub_base, tabs, ls, prev, bad);
-                        else decode_step<DEC_K, false, false, false>(lut, sub_base, tabs, ls, prev, bad);
+                        if (j % SPR == 0) decode_step<DEC_K, false, true, false, DIRECT>(lut, sub_base, tabs, ls, prev, bad);
+                        else decode_step<DEC_K, false, false, false, DIRECT>(lut, sub_base, tabs, ls, prev, bad);
 #pragma unroll
                         for (int k = 0; k < DEC_K; ++k) d[k] |= prev[k] << (8 * j);
                     }
@@ -1005,7 +1008,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecParams p) {
                 const uint64_t first = c << p.chunk_shift;
                 const uint32_t nsym = (p.n - first) >= S ? S : uint32_t(p.n - first);
                 const uint64_t endb = (c + 1 < p.nchunks) ? (p.index[c + 1] & 0x00FFFFFFFFFFFFFFull) : p.nbits;
-                decode_chunk_single<false>(lut, sub_base, tabs, p.payload, p.payload_bytes, p.nbits, p.index[c], endb, p.out + first, nsym, p.status);
+                decode_chunk_single<false, DIRECT>(lut, sub_base, tabs, p.payload, p.payload_bytes, p.nbits, p.index[c], endb, p.out + first, nsym, p.status);
             }
         }
     }
@@ -1058,7 +1061,7 @@ __global__ __launch_bounds__(256) void index_sync_kernel(IdxParams p, uint32_t i
     else start = __hip_atomic_load(&p.seg_end_state[i - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (iter > 0 && start == p.seg_used[i]) return;                    // same input as last time
     const BitSrc src{p.payload, p.payload_bytes >> 2, p.payload_bytes};
-    const DecTables tabs{p.sec, p.tree, p.P, p.sec, 0};
+    const DecTables tabs{p.sec, p.tree, p.P, p.sec, 0, p.direct, p.H};
     uint32_t count;
     bool bad;
     uint64_t end = walk_segment(p, tabs, src, start, seg_end, count, bad, [](uint32_t, uint32_t, uint64_t) {});
@@ -1089,7 +1092,7 @@ __global__ __launch_bounds__(256) void index_fill_kernel(IdxParams p) {
     const uint64_t base = p.seg_sym_start[i];
     const uint64_t smask = (1ull << p.chunk_shift) - 1;
     const BitSrc src{p.payload, p.payload_bytes >> 2, p.payload_bytes};
-    const DecTables tabs{p.sec, p.tree, p.P, p.sec, 0};
+    const DecTables tabs{p.sec, p.tree, p.P, p.sec, 0, p.direct, p.H};
     uint32_t count;
     bool bad, overflow = false;
     uint64_t end = walk_segment(p, tabs, src, start, seg_end, count, bad, [&](uint32_t k, uint32_t prev, uint64_t pos) {
@@ -1111,7 +1114,7 @@ __global__ __launch_bounds__(256) void index_fill_kernel(IdxParams p) {
 __global__ void build_index_kernel(IdxParams p) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     const BitSrc src{p.payload, p.payload_bytes >> 2, p.payload_bytes};
-    const DecTables tabs{p.sec, p.tree, p.P, p.sec, 0};
+    const DecTables tabs{p.sec, p.tree, p.P, p.sec, 0, p.direct, p.H};
     BitCursor bc;
     bc.init(src, 0);
     uint64_t bi = 0, nsym = 0;
@@ -1232,18 +1235,20 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
     if (e != hipSuccess || p.nchunks == 0) return e;
     static bool once = false;
     if (!once) {
-        e = allow_lds(reinterpret_cast<const void *>(decode_kernel<true, 2>), DEC_LDS_MAX); if (e != hipSuccess) return e;
-        e = allow_lds(reinterpret_cast<const void *>(decode_kernel<true, 4>), DEC_LDS_MAX); if (e != hipSuccess) return e;
-        e = allow_lds(reinterpret_cast<const void *>(decode_kernel<false, 2>), DEC_LDS_MAX); if (e != hipSuccess) return e;
+        e = allow_lds(reinterpret_cast<const void *>(decode_kernel<true, 2, false>), DEC_LDS_MAX); if (e != hipSuccess) return e;
+        e = allow_lds(reinterpret_cast<const void *>(decode_kernel<true, 4, false>), DEC_LDS_MAX); if (e != hipSuccess) return e;
+        e = allow_lds(reinterpret_cast<const void *>(decode_kernel<false, 2, false>), DEC_LDS_MAX); if (e != hipSuccess) return e;
+        e = allow_lds(reinterpret_cast<const void *>(decode_kernel<false, 2, true>), DEC_LDS_MAX); if (e != hipSuccess) return e;
         once = true;
     }
     size_t lds = 1024 + (size_t(256) << p.P) * 2 + (p.sec_lds ? ((size_t(p.nsec) * 2 + 15) & ~size_t(15)) : 0);
     if (lds > size_t(DEC_LDS_MAX)) return hipErrorInvalidValue;
     uint64_t want = (p.nchunks + uint64_t(DEC_THREADS) * DEC_K - 1) / (uint64_t(DEC_THREADS) * DEC_K);
     int grid = int(want > uint64_t(cu_count()) ? uint64_t(cu_count()) : want);
-    if (p.sec_lds && p.nsec == 0 && p.P == 8) hipLaunchKernelGGL((decode_kernel<true, 4>), dim3(grid), dim3(DEC_THREADS), lds, st, p);
-    else if (p.sec_lds) hipLaunchKernelGGL((decode_kernel<true, 2>), dim3(grid), dim3(DEC_THREADS), lds, st, p);
-    else hipLaunchKernelGGL((decode_kernel<false, 2>), dim3(grid), dim3(DEC_THREADS), lds, st, p);
+    if (p.sec_lds && p.nsec == 0 && p.P == 8) hipLaunchKernelGGL((decode_kernel<true, 4, false>), dim3(grid), dim3(DEC_THREADS), lds, st, p);
+    else if (p.sec_lds) hipLaunchKernelGGL((decode_kernel<true, 2, false>), dim3(grid), dim3(DEC_THREADS), lds, st, p);
+    else if (p.direct) hipLaunchKernelGGL((decode_kernel<false, 2, true>), dim3(grid), dim3(DEC_THREADS), lds, st, p);
+    else hipLaunchKernelGGL((decode_kernel<false, 2, false>), dim3(grid), dim3(DEC_THREADS), lds, st, p);
     return hipGetLastError();
 }
 

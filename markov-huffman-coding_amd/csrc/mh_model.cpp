@@ -258,7 +258,7 @@ void ContextCoder::sec_profile(int hcap, size_t (&out)[9]) const {
     }
 }
 
-void ContextCoder::pack_decode(int P, int hcap, uint16_t *prim, std::vector<uint16_t> &sec, size_t sec_start,
+void ContextCoder::pack_decode(int P, int hcap, int uniform_h, uint16_t *prim, std::vector<uint16_t> &sec, size_t sec_start,
                                uint32_t *tree) const {
     for (int i = 0; i < (1 << P); ++i) prim[i] = 0;
     for (int i = 0; i < TREE_STRIDE; ++i) tree[i] = 0;
@@ -297,10 +297,11 @@ void ContextCoder::pack_decode(int P, int hcap, uint16_t *prim, std::vector<uint
         }
     };
     fill(root_, P, prim, [&](int node) -> uint16_t {
-        const int h = std::min(nodes_[node].height, hcap);          // >= 1: the node is internal
+        const int h = uniform_h > 0 ? uniform_h : std::min(nodes_[node].height, hcap);   // >= 1: the node is internal
         const size_t off = sec.size() - sec_start;
         sec.resize(sec.size() + (size_t(1) << h), 0);
         fill(node, h, sec.data() + sec_start + off, [&](int deep) -> uint16_t { return uint16_t(DEC16_INNER | id[deep]); });
+        if (uniform_h > 0) return uint16_t(DEC16_INNER | uint32_t(off >> h));       // rank within this context
         return uint16_t(DEC16_INNER | ((h - 1) << 12) | uint32_t(off));
     });
 }
@@ -377,10 +378,17 @@ Model::Packed Model::pack() const {
     for (int P = 8; P >= 4 && !pk.dec_bits; --P)
         if (worst[P] <= size_t(DEC_SEC_MAX_PER_CTX) && (size_t(256) << P) + total[P] <= size_t(DEC_LDS_ENTRIES)) pk.dec_bits = P;
     pk.dec_lds = pk.dec_bits != 0;
+    int uniform_h = 0;
     if (!pk.dec_lds) {
         pk.dec_bits = 8;
-        while (worst[8] > size_t(DEC_SEC_MAX_PER_CTX) && hcap > 1) { --hcap; profile(hcap, total, worst); }
+        // uniform tables: one per depth-8 internal node (profile with hcap = 0 counts the nodes)
+        size_t ntab[9], wtab[9];
+        profile(0, ntab, wtab);
+        if (ntab[8] <= 32767) uniform_h = std::min(std::max(pk.max_len - 8, 1), 8);
+        else while (worst[8] > size_t(DEC_SEC_MAX_PER_CTX) && hcap > 1) { --hcap; profile(hcap, total, worst); }
     }
+    pk.dec_direct = uniform_h > 0;
+    pk.dec_h = uniform_h;
     const int P = pk.dec_bits;
     pk.dec_prim.assign(size_t(256) << P, 0);
     pk.sec_base.assign(256, 0);
@@ -388,7 +396,7 @@ Model::Packed Model::pack() const {
     parallel_for(256, [&](int prev) {
         const ContextCoder &c = context(prev);
         if (type != 0 || prev == 0)
-            c.pack_decode(P, hcap, &pk.dec_prim[size_t(prev) << P], sec_of[prev], 0, &pk.tree[prev * TREE_STRIDE]);
+            c.pack_decode(P, hcap, uniform_h, &pk.dec_prim[size_t(prev) << P], sec_of[prev], 0, &pk.tree[prev * TREE_STRIDE]);
         for (int sym = 0; sym < 256; ++sym) {
             const Code &cd = c.code(sym);
             uint32_t window = uint32_t(sym) << 8 | uint32_t(prev);
@@ -408,14 +416,20 @@ Model::Packed Model::pack() const {
     for (int i = 0; i < 256; ++i) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ctx_weight[a] > ctx_weight[b]; });
     for (int prev : order) {
-        if (type == 0 && prev > 0) {
+        if (type == 0 && prev > 0) continue;
+        pk.sec_base[prev] = uint32_t(pk.dec_sec.size());
+        pk.dec_sec.insert(pk.dec_sec.end(), sec_of[prev].begin(), sec_of[prev].end());
+        if (pk.dec_direct)      // rank within the context -> global table id
+            for (int w = 0; w < (1 << P); ++w) {
+                uint16_t &e = pk.dec_prim[(size_t(prev) << P) + w];
+                if (e & DEC16_INNER) e = uint16_t(DEC16_INNER | ((pk.sec_base[prev] >> uniform_h) + (e & 0x7FFFu)));
+            }
+    }
+    if (type == 0)
+        for (int prev = 1; prev < 256; ++prev) {
             std::copy(pk.dec_prim.begin(), pk.dec_prim.begin() + (1 << P), pk.dec_prim.begin() + (size_t(prev) << P));
             std::copy(pk.tree.begin(), pk.tree.begin() + TREE_STRIDE, pk.tree.begin() + size_t(prev) * TREE_STRIDE);
-        } else {
-            pk.sec_base[prev] = uint32_t(pk.dec_sec.size());
-            pk.dec_sec.insert(pk.dec_sec.end(), sec_of[prev].begin(), sec_of[prev].end());
         }
-    }
     const size_t room = size_t(DEC_LDS_ENTRIES) - (size_t(256) << P);
     pk.sec_lds_entries = uint32_t(std::min(pk.dec_sec.size(), room) & ~size_t(7));
     if (pk.dec_lds) pk.sec_lds_entries = uint32_t(pk.dec_sec.size());

@@ -36,8 +36,10 @@ constexpr uint32_t enc_slot(uint32_t window) { return (window ^ (window >> 8)) &
 //   sec[...]   u16
 //       leaf   extra_len(1..h) << 8 | symbol
 //       inner  0x8000 | tree node id : code longer than P + h, walked bit by bit in the L2 tree (rare)
-// P is the largest width for which prim + sec fit the LDS budget; if none does (pathological models)
-// P = 8 and sec stays in HBM/L2.  P = 8 is the reference's own 8-bit LUT (src/huffman.cpp:97-123).
+// P is the largest width for which prim + sec fit the LDS budget; if none does P = 8 and sec stays in
+// HBM/L2.  In that case the tables are made uniform (2^H entries each, H = min(max_len - 8, 8)) and an
+// inner entry is just 0x8000 | global table id — no per-context base and no per-node height to decode
+// on the device (falls back to the general form above 32767 tables).  P = 8 is the reference's own 8-bit LUT (src/huffman.cpp:97-123).
 constexpr uint16_t DEC16_INNER = 0x8000;
 constexpr int DEC_LDS_ENTRIES = (163840 - 1024) / 2;   // u16 entries beside the 1 KiB sec_base array
 constexpr int DEC_SEC_MAX_PER_CTX = 4096;              // 12-bit offsets
@@ -87,7 +89,9 @@ public:
     void sec_profile(int hcap, size_t (&out)[9]) const;
     // packed device images for this context: prim (1 << P entries), this context's second-level
     // tables appended to `sec` (offsets relative to sec_start), walk tree (TREE_STRIDE entries)
-    void pack_decode(int P, int hcap, uint16_t *prim, std::vector<uint16_t> &sec, size_t sec_start, uint32_t *tree256) const;
+    // uniform_h > 0: every table has exactly 2^uniform_h entries and the inner entry holds the table's rank
+    // within this context instead of (height, offset)
+    void pack_decode(int P, int hcap, int uniform_h, uint16_t *prim, std::vector<uint16_t> &sec, size_t sec_start, uint32_t *tree256) const;
 
 private:
     void derive_tables();
@@ -155,6 +159,8 @@ public:
         std::vector<uint32_t> tree;      // 256*TREE_STRIDE
         int dec_bits = 8;                // P
         bool dec_lds = true;             // prim + sec fit the LDS budget
+        bool dec_direct = false;         // L2 mode with uniform tables: inner entry = 0x8000 | global table id,
+        int dec_h = 0;                   //   table t = sec[t << dec_h .. (t + 1) << dec_h)
         uint32_t sec_lds_entries = 0;    // leading sec entries kept in LDS (all of them when dec_lds; else
                                          // the tables of the most frequent contexts, which are laid out first)
         int max_len = 0;
