@@ -871,14 +871,16 @@ __device__ __forceinline__ void decode_step(const uint16_t *prim, const uint32_t
                 e2[k] = t.sec[idx];
             }
         }
+        // merge with plain selects (e2 is 0 in lanes that did not look anything up)
+        uint32_t any2 = 0;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            if (e[k] & DEC16_INNER) {
-                len[k] = t.P + (e2[k] >> 8);     // a null entry ends the chunk at the wrong bit: caught there
-                sym[k] = e2[k] & 255u;
-                deep |= (e2[k] & DEC16_INNER) != 0;
-            }
+            const bool in = (e[k] & DEC16_INNER) != 0;
+            len[k] = in ? t.P + (e2[k] >> 8) : len[k];   // a null entry ends the chunk at the wrong bit: caught there
+            sym[k] = in ? (e2[k] & 255u) : sym[k];
+            any2 |= e2[k];
         }
+        deep = (any2 & DEC16_INNER) != 0;
         if (__any(deep)) {
 #pragma unroll
             for (int k = 0; k < K; ++k) {

@@ -13,6 +13,9 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def mhc():
     mod = entry.load_package()
+    import os
+    if not os.path.exists(mod.LIB_PATH):
+        entry.build()          # hipcc is on the GPU box too; normally the built library travels with the repo
     mod.lib()
     assert mod.device_count() >= 1, "GPU tests need a device; the codec has no CPU fallback"
     return mod
