@@ -60,6 +60,13 @@ int mh_device_count(void);
 /* Device used by the calling thread's subsequent mh_* / mh_dev_* calls (hipSetDevice). */
 int mh_set_device(int ordinal);
 
+/* Minimal device-memory helpers for hosts that have no HIP allocator of their own (the Python tests):
+ * hipMalloc / hipFree / synchronous hipMemcpy. */
+int mh_dev_malloc(void **d_ptr, size_t bytes);
+int mh_dev_free(void *d_ptr);
+int mh_dev_upload(void *d_dst, const void *h_src, size_t bytes);
+int mh_dev_download(void *h_dst, const void *d_src, size_t bytes);
+
 /* ------------------------------------------------------------------ model */
 
 typedef struct mh_model mh_model;
@@ -73,8 +80,11 @@ typedef struct mh_model mh_model;
 int mh_model_from_counts(const uint64_t *counts, int order, mh_model **out);
 
 /* Same, counts resident in HBM (e.g. straight out of mh_dev_histogram_o1 or an RCCL all-reduce).
- * Per-context tree build, code derivation and LUT fill run in a HIP kernel on `stream`; the call
- * synchronises the stream once to pick up the (small) host mirror of the tables. */
+ * Order 1: the per-context tree build (heap emulation), code derivation and table fill run in HIP
+ * kernels on `stream` (mh_tree.hip); the counts never leave the device.  The call synchronises the
+ * stream (16 KiB of table sizes come back so that the host can pick the decode-table layout); the host
+ * copy of the trees that table files and the query calls below need is made lazily, on first use.
+ * Order 0 (one tree) takes the host route. */
 int mh_dev_model_from_counts(const uint64_t *d_counts, int order, void *stream, mh_model **out);
 
 /* Replaces the table-file constructors huffman_table(bitbuffer&) / markov_huffman_table(bitbuffer&)
@@ -101,6 +111,10 @@ int mh_model_get_lut(const mh_model *m, int prev, int w, int *present, int *is_i
  * is what makes both table levels fit LDS), *secondary_entries = second-level entries,
  * *in_lds = 1 when both levels are LDS-resident in the decode kernel. */
 int mh_model_decode_layout(const mh_model *m, int *primary_bits, int *secondary_entries, int *in_lds);
+/* Diagnostic: copies one of the model's device images to the host (tests compare the host-built and the
+ * device-built tables bit for bit).  which: 0 enc16, 1 len8, 2 len_slot, 3 code64, 4 decode prim,
+ * 5 decode sec, 6 sec_base, 7 walk tree.  *bytes = image size; copied when cap suffices. */
+int mh_model_image(const mh_model *m, int which, void *out, size_t cap, size_t *bytes);
 void mh_model_free(mh_model *m);
 
 /* ------------------------------------------------------------- chunk index */

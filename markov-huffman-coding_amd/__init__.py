@@ -26,9 +26,10 @@ INDEX_BIT_MASK = 0x00FFFFFFFFFFFFFF
 # every symbol include/mh.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "mh_strerror", "mh_last_hip_error", "mh_device_count", "mh_set_device",
+    "mh_dev_malloc", "mh_dev_free", "mh_dev_upload", "mh_dev_download",
     "mh_model_from_counts", "mh_dev_model_from_counts", "mh_model_from_table_bits", "mh_model_write_table",
     "mh_model_type", "mh_model_max_code_len", "mh_model_get_code", "mh_model_get_lut", "mh_model_decode_layout",
-    "mh_model_free",
+    "mh_model_image", "mh_model_free",
     "mh_histogram_o1", "mh_histogram_o0", "mh_encode", "mh_encode_bound", "mh_stream_header",
     "mh_stream_parse_header", "mh_decode",
     "mh_dev_histogram_workspace", "mh_dev_histogram_o1", "mh_dev_histogram_o0",
@@ -59,6 +60,10 @@ def lib():
         pi, pu64, psz = C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_size_t)
         l.mh_strerror.restype = C.c_char_p
         l.mh_strerror.argtypes = [i32]
+        l.mh_dev_malloc.argtypes = [C.POINTER(vp), sz]
+        l.mh_dev_free.argtypes = [vp]
+        l.mh_dev_upload.argtypes = [vp, vp, sz]
+        l.mh_dev_download.argtypes = [vp, vp, sz]
         l.mh_model_from_counts.argtypes = [vp, i32, C.POINTER(vp)]
         l.mh_dev_model_from_counts.argtypes = [vp, i32, vp, C.POINTER(vp)]
         l.mh_model_from_table_bits.argtypes = [vp, sz, C.POINTER(vp)]
@@ -68,6 +73,7 @@ def lib():
         l.mh_model_get_code.argtypes = [vp, i32, i32, pi, pu64]
         l.mh_model_get_lut.argtypes = [vp, i32, i32, pi, pi, pi, pi]
         l.mh_model_decode_layout.argtypes = [vp, pi, pi, pi]
+        l.mh_model_image.argtypes = [vp, i32, vp, sz, psz]
         l.mh_model_free.argtypes = [vp]
         l.mh_model_free.restype = None
         l.mh_histogram_o1.argtypes = [vp, sz, u8, vp]
@@ -114,6 +120,28 @@ def _u8(data):
 
 def _ptr(a):
     return a.ctypes.data if a.size else None
+
+
+class DeviceBuffer:
+    """A hipMalloc'ed buffer (for tests that drive the mh_dev_* calls without torch)."""
+
+    def __init__(self, nbytes, init=None):
+        self.nbytes = nbytes
+        self.ptr = C.c_void_p()
+        _check(lib().mh_dev_malloc(C.byref(self.ptr), nbytes), "mh_dev_malloc")
+        if init is not None:
+            a = np.ascontiguousarray(init)
+            _check(lib().mh_dev_upload(self.ptr, a.ctypes.data, a.nbytes), "mh_dev_upload")
+
+    def download(self, dtype=np.uint8):
+        out = np.zeros(self.nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        _check(lib().mh_dev_download(out.ctypes.data, self.ptr, out.nbytes), "mh_dev_download")
+        return out
+
+    def __del__(self):
+        if getattr(self, "ptr", None) and _lib is not None:
+            _lib.mh_dev_free(self.ptr)
+            self.ptr = None
 
 
 def histogram_o1(data, prev0=PREV0):
@@ -185,6 +213,14 @@ class Model:
         a, b, c = C.c_int(), C.c_int(), C.c_int()
         _check(lib().mh_model_decode_layout(self._h, C.byref(a), C.byref(b), C.byref(c)), "mh_model_decode_layout")
         return a.value, b.value, bool(c.value)
+
+    def image(self, which):
+        """Device image `which` (see mh.h: 0 enc16 ... 7 walk tree) as bytes."""
+        n = C.c_size_t(0)
+        _check(lib().mh_model_image(self._h, which, None, 0, C.byref(n)), "mh_model_image")
+        out = np.zeros(max(n.value, 1), dtype=np.uint8)
+        _check(lib().mh_model_image(self._h, which, out.ctypes.data, n.value, C.byref(n)), "mh_model_image")
+        return out[:n.value].tobytes()
 
     def table_bytes(self):
         n = C.c_size_t(0)

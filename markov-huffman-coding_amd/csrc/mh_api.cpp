@@ -5,7 +5,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -13,9 +15,21 @@
 #include "mh_model.hpp"
 
 struct mh_model {
-    mh::Model host;
-    mh::Model::Packed packed;
+    mh::Model host;              // host mirror of the trees (built lazily after a device build)
+    mh::Model::Packed packed;    // host-built images (empty after a device build)
     int device = -1;
+    // what the entry points need without touching the mirror
+    int type = 1, max_len = 0, dec_bits = 8, dec_h = 0;
+    bool dec_lds = true, dec_direct = false;
+    uint32_t nsec = 0;
+    // device build: node arrays stay on the device until somebody asks for the mirror
+    bool mirror_ready = true;
+    std::mutex mu;
+    void *d_build = nullptr;     // enc/dec images + node arrays + meta (device build)
+    void *d_sec_own = nullptr;   // second-level tables (device build)
+    uint16_t *d_node_left = nullptr, *d_node_right = nullptr;
+    uint8_t *d_node_sym = nullptr;
+    uint32_t *d_meta = nullptr;
     // device images (owned)
     uint16_t *d_enc16 = nullptr;
     uint8_t *d_len8 = nullptr;
@@ -80,8 +94,13 @@ struct DevBuf {
 // compute call on it returns MH_ERR_NO_DEVICE.
 int upload_model(mh_model *m) {
     m->packed = m->host.pack();
+    m->type = m->host.type;
+    m->max_len = m->packed.max_len;
+    m->dec_bits = m->packed.dec_bits; m->dec_h = m->packed.dec_h;
+    m->dec_lds = m->packed.dec_lds; m->dec_direct = m->packed.dec_direct;
+    m->nsec = uint32_t(m->packed.dec_sec.size());
     if (!have_device()) return MH_OK;
-    if (m->packed.max_len > mh::MAX_CODE_BITS) return MH_OK;   // compute calls report MH_ERR_CODE_TOO_LONG
+    if (m->max_len > mh::MAX_CODE_BITS) return MH_OK;   // compute calls report MH_ERR_CODE_TOO_LONG
     HIP_TRY(hipGetDevice(&m->device));
     const mh::Model::Packed &pk = m->packed;
     // one device allocation and one upload for all images (each piece 256-byte aligned)
@@ -106,6 +125,33 @@ int upload_model(mh_model *m) {
     HIP_TRY(hipMalloc(&m->d_block, total));
     HIP_TRY(hipMemcpy(m->d_block, staging.data(), total, hipMemcpyHostToDevice));
     for (int i = 0; i < 8; ++i) *pieces[i].dst = static_cast<unsigned char *>(m->d_block) + off[i];
+    return MH_OK;
+}
+
+// After a device build the trees live in HBM only; table files and code/LUT queries need them on the
+// host.  Built once, on demand.
+int ensure_mirror(const mh_model *cm) {
+    mh_model *m = const_cast<mh_model *>(cm);
+    std::lock_guard<std::mutex> lock(m->mu);
+    if (m->mirror_ready) return MH_OK;
+    const size_t nn = size_t(256) * mhk::TB_NODE_STRIDE;
+    std::vector<uint16_t> left(nn), right(nn);
+    std::vector<uint8_t> sym(nn);
+    std::vector<uint32_t> meta(size_t(256) * mhk::TB_META_STRIDE);
+    HIP_TRY(hipMemcpy(left.data(), m->d_node_left, nn * 2, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(right.data(), m->d_node_right, nn * 2, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(sym.data(), m->d_node_sym, nn, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(meta.data(), m->d_meta, meta.size() * 4, hipMemcpyDeviceToHost));
+    m->host.type = 1;
+    m->host.ctx.assign(256, mh::ContextCoder{});
+    for (int c = 0; c < 256; ++c) {
+        const uint32_t *mt = &meta[size_t(c) * mhk::TB_META_STRIDE];
+        const int root = mt[1] == 0xFFFFFFFFu ? -1 : int(mt[1]);
+        m->host.ctx[c].adopt(int(mt[0]), root, &left[size_t(c) * mhk::TB_NODE_STRIDE], &right[size_t(c) * mhk::TB_NODE_STRIDE],
+                             &sym[size_t(c) * mhk::TB_NODE_STRIDE]);
+        m->host.ctx_weight[c] = (uint64_t(mt[14]) << 32) | mt[13];
+    }
+    m->mirror_ready = true;
     return MH_OK;
 }
 
@@ -150,6 +196,27 @@ int mh_set_device(int ordinal) {
     return MH_OK;
 }
 
+int mh_dev_malloc(void **d_ptr, size_t bytes) {
+    if (!d_ptr) return MH_ERR_ARG;
+    if (!have_device()) return MH_ERR_NO_DEVICE;
+    HIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 16));
+    return MH_OK;
+}
+int mh_dev_free(void *d_ptr) {
+    if (d_ptr) HIP_TRY(hipFree(d_ptr));
+    return MH_OK;
+}
+int mh_dev_upload(void *d_dst, const void *h_src, size_t bytes) {
+    if ((!d_dst || !h_src) && bytes) return MH_ERR_ARG;
+    if (bytes) HIP_TRY(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+    return MH_OK;
+}
+int mh_dev_download(void *h_dst, const void *d_src, size_t bytes) {
+    if ((!h_dst || !d_src) && bytes) return MH_ERR_ARG;
+    if (bytes) HIP_TRY(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return MH_OK;
+}
+
 /* ---------------------------------------------------------------- model */
 
 int mh_model_from_counts(const uint64_t *counts, int order, mh_model **out) {
@@ -160,14 +227,105 @@ int mh_model_from_counts(const uint64_t *counts, int order, mh_model **out) {
     return finish_model(m, out);
 }
 
+static int model_from_device_counts_via_host(const uint64_t *d_counts, int order, hipStream_t st, mh_model **out) {
+    size_t ncount = order ? 65536 : 256;
+    std::vector<uint64_t> counts(ncount);
+    HIP_TRY(hipMemcpyAsync(counts.data(), d_counts, ncount * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return mh_model_from_counts(counts.data(), order, out);
+}
+
 int mh_dev_model_from_counts(const uint64_t *d_counts, int order, void *stream, mh_model **out) {
     if (!d_counts || !out || (order != 0 && order != 1)) return MH_ERR_ARG;
     if (!have_device()) return MH_ERR_NO_DEVICE;
-    size_t ncount = order ? 65536 : 256;
-    std::vector<uint64_t> counts(ncount);
-    HIP_TRY(hipMemcpyAsync(counts.data(), d_counts, ncount * 8, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
-    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
-    return mh_model_from_counts(counts.data(), order, out);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (order == 0) return model_from_device_counts_via_host(d_counts, order, st, out);   // one tree: not worth a kernel
+
+    mh_model *m = new (std::nothrow) mh_model;
+    if (!m) return MH_ERR_NOMEM;
+    m->type = 1;
+    m->mirror_ready = false;
+    auto fail = [&](int rc) { mh_model_free(m); return rc; };
+#define HIP_TRY_M(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(hip_fail(_e)); } while (0)
+    HIP_TRY_M(hipGetDevice(&m->device));
+    // one block for every fixed-size image + the node arrays
+    const size_t nn = size_t(256) * mhk::TB_NODE_STRIDE;
+    const size_t sizes[] = {65536 * 2, 65536, 65536, 65536 * 8, size_t(256) * mh::TREE_STRIDE * 4, 65536 * 2, 256 * 4,
+                            nn * 2, nn * 2, nn, nn, size_t(256) * mhk::TB_META_STRIDE * 4};
+    size_t off[12], total = 0;
+    for (int i = 0; i < 12; ++i) { off[i] = total; total += (sizes[i] + 255) & ~size_t(255); }
+    HIP_TRY_M(hipMalloc(&m->d_build, total));
+    unsigned char *b = static_cast<unsigned char *>(m->d_build);
+    m->d_enc16 = reinterpret_cast<uint16_t *>(b + off[0]);
+    m->d_len8 = b + off[1];
+    m->d_len_slot = b + off[2];
+    m->d_code64 = reinterpret_cast<uint64_t *>(b + off[3]);
+    m->d_tree = reinterpret_cast<uint32_t *>(b + off[4]);
+    m->d_prim = reinterpret_cast<uint16_t *>(b + off[5]);
+    m->d_sec_base = reinterpret_cast<uint32_t *>(b + off[6]);
+    m->d_node_left = reinterpret_cast<uint16_t *>(b + off[7]);
+    m->d_node_right = reinterpret_cast<uint16_t *>(b + off[8]);
+    m->d_node_sym = b + off[9];
+    uint8_t *d_node_height = b + off[10];
+    m->d_meta = reinterpret_cast<uint32_t *>(b + off[11]);
+
+    mhk::TreeBuildOut tb{m->d_len8, reinterpret_cast<unsigned long long *>(m->d_code64), m->d_enc16, m->d_len_slot,
+                         m->d_node_left, m->d_node_right, m->d_node_sym, d_node_height, m->d_meta};
+    HIP_TRY_M(mhk::launch_tree_build(reinterpret_cast<const unsigned long long *>(d_counts), 256, tb, st));
+    std::vector<uint32_t> meta(size_t(256) * mhk::TB_META_STRIDE);
+    HIP_TRY_M(hipMemcpyAsync(meta.data(), m->d_meta, meta.size() * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY_M(hipStreamSynchronize(st));                      // 16 KiB of sizes: the one sync of this call
+
+    // same layout rule as mh::Model::pack()
+    size_t tot[9] = {0}, worst[9] = {0}, ntab8 = 0;
+    uint64_t weight[256];
+    for (int c = 0; c < 256; ++c) {
+        const uint32_t *mt = &meta[size_t(c) * mhk::TB_META_STRIDE];
+        m->max_len = std::max(m->max_len, int(mt[2]));
+        ntab8 += mt[3];
+        for (int P = 0; P < 9; ++P) { tot[P] += mt[4 + P]; worst[P] = std::max(worst[P], size_t(mt[4 + P])); }
+        weight[c] = (uint64_t(mt[14]) << 32) | mt[13];
+    }
+    if (m->max_len > mh::MAX_CODE_BITS) { *out = m; return MH_OK; }   // compute calls report MH_ERR_CODE_TOO_LONG
+    int P = 0;
+    for (int q = 8; q >= 4 && !P; --q)
+        if (worst[q] <= size_t(mh::DEC_SEC_MAX_PER_CTX) && (size_t(256) << q) + tot[q] <= size_t(mh::DEC_LDS_ENTRIES)) P = q;
+    m->dec_lds = P != 0;
+    if (!m->dec_lds) {
+        if (ntab8 > 32767) {                                  // general L2 layout: rare; let the host do it
+            mh_model_free(m);
+            return model_from_device_counts_via_host(d_counts, order, st, out);
+        }
+        P = 8;
+        m->dec_direct = true;
+        m->dec_h = std::min(std::max(m->max_len - 8, 1), 8);
+    }
+    m->dec_bits = P;
+    int order_idx[256];
+    for (int i = 0; i < 256; ++i) order_idx[i] = i;
+    std::stable_sort(order_idx, order_idx + 256, [&](int a, int b2) { return weight[a] > weight[b2]; });
+    std::vector<uint32_t> sec_base(256, 0);
+    size_t nsec = 0;
+    for (int i = 0; i < 256; ++i) {
+        const int c = order_idx[i];
+        const uint32_t *mt = &meta[size_t(c) * mhk::TB_META_STRIDE];
+        sec_base[c] = uint32_t(nsec);
+        nsec += m->dec_direct ? (size_t(mt[3]) << m->dec_h) : size_t(mt[4 + P]);
+    }
+    m->nsec = uint32_t(nsec);
+    const size_t sec_bytes = ((nsec * 2 + 15) & ~size_t(15)) + 16;
+    HIP_TRY_M(hipMalloc(&m->d_sec_own, sec_bytes));
+    m->d_sec = static_cast<uint16_t *>(m->d_sec_own);
+    HIP_TRY_M(hipMemsetAsync(m->d_sec_own, 0, sec_bytes, st));
+    HIP_TRY_M(hipMemcpyAsync(m->d_sec_base, sec_base.data(), 256 * 4, hipMemcpyHostToDevice, st));
+    mhk::TreePackArgs pa{m->d_node_left, m->d_node_right, m->d_node_sym, d_node_height, m->d_meta, m->d_sec_base,
+                         uint32_t(P), m->dec_direct ? 1u : 0u, uint32_t(m->dec_h), 8u, m->d_prim, m->d_sec, m->d_tree};
+    HIP_TRY_M(mhk::launch_tree_pack(pa, 256, st));
+    // sec_base lives in pageable host memory: make sure the copy has been consumed before it goes away
+    HIP_TRY_M(hipStreamSynchronize(st));
+#undef HIP_TRY_M
+    *out = m;
+    return MH_OK;
 }
 
 int mh_model_from_table_bits(const uint8_t *bytes, size_t n, mh_model **out) {
@@ -180,6 +338,7 @@ int mh_model_from_table_bits(const uint8_t *bytes, size_t n, mh_model **out) {
 
 int mh_model_write_table(const mh_model *m, uint8_t *out, size_t cap, size_t *nbytes) {
     if (!m || !nbytes) return MH_ERR_ARG;
+    { int rc = ensure_mirror(m); if (rc != MH_OK) return rc; }
     std::vector<uint8_t> t = m->host.save_table();
     *nbytes = t.size();
     if (!out) return MH_OK;
@@ -188,12 +347,13 @@ int mh_model_write_table(const mh_model *m, uint8_t *out, size_t cap, size_t *nb
     return MH_OK;
 }
 
-int mh_model_type(const mh_model *m) { return m ? m->host.type : MH_ERR_ARG; }
+int mh_model_type(const mh_model *m) { return m ? m->type : MH_ERR_ARG; }
 
-int mh_model_max_code_len(const mh_model *m) { return m ? m->packed.max_len : MH_ERR_ARG; }
+int mh_model_max_code_len(const mh_model *m) { return m ? m->max_len : MH_ERR_ARG; }
 
 int mh_model_get_code(const mh_model *m, int prev, int sym, int *len, uint64_t *code) {
     if (!m || !len || !code) return MH_ERR_ARG;
+    { int rc = ensure_mirror(m); if (rc != MH_OK) return rc; }
     const mh::Code &c = m->host.context(prev).code(sym);
     *len = c.len;
     *code = c.len <= 64 ? c.right_aligned() : 0;
@@ -202,6 +362,7 @@ int mh_model_get_code(const mh_model *m, int prev, int sym, int *len, uint64_t *
 
 int mh_model_get_lut(const mh_model *m, int prev, int w, int *present, int *is_internal, int *value, int *depth) {
     if (!m || !present || !is_internal || !value || !depth) return MH_ERR_ARG;
+    { int rc = ensure_mirror(m); if (rc != MH_OK) return rc; }
     const mh::ContextCoder &c = m->host.context(prev);
     int n = c.lut(w);
     *present = n >= 0;
@@ -216,15 +377,40 @@ int mh_model_get_lut(const mh_model *m, int prev, int w, int *present, int *is_i
 
 int mh_model_decode_layout(const mh_model *m, int *primary_bits, int *secondary_entries, int *in_lds) {
     if (!m || !primary_bits || !secondary_entries || !in_lds) return MH_ERR_ARG;
-    *primary_bits = m->packed.dec_bits;
-    *secondary_entries = int(m->packed.dec_sec.size());
-    *in_lds = m->packed.dec_lds ? 1 : 0;
+    *primary_bits = m->dec_bits;
+    *secondary_entries = int(m->nsec);
+    *in_lds = m->dec_lds ? 1 : 0;
+    return MH_OK;
+}
+
+int mh_model_image(const mh_model *m, int which, void *out, size_t cap, size_t *bytes) {
+    if (!m || !bytes) return MH_ERR_ARG;
+    if (!m->d_enc16) return MH_ERR_NO_DEVICE;
+    const void *src = nullptr;
+    size_t n = 0;
+    switch (which) {
+        case 0: src = m->d_enc16; n = 65536 * 2; break;
+        case 1: src = m->d_len8; n = 65536; break;
+        case 2: src = m->d_len_slot; n = 65536; break;
+        case 3: src = m->d_code64; n = 65536 * 8; break;
+        case 4: src = m->d_prim; n = (size_t(256) << m->dec_bits) * 2; break;
+        case 5: src = m->d_sec; n = size_t(m->nsec) * 2; break;
+        case 6: src = m->d_sec_base; n = 256 * 4; break;
+        case 7: src = m->d_tree; n = size_t(256) * mh::TREE_STRIDE * 4; break;
+        default: return MH_ERR_ARG;
+    }
+    *bytes = n;
+    if (!out) return MH_OK;
+    if (cap < n) return MH_ERR_CAPACITY;
+    if (n) HIP_TRY(hipMemcpy(out, src, n, hipMemcpyDeviceToHost));
     return MH_OK;
 }
 
 void mh_model_free(mh_model *m) {
     if (!m) return;
     if (m->d_block) (void)hipFree(m->d_block);
+    if (m->d_build) (void)hipFree(m->d_build);
+    if (m->d_sec_own) (void)hipFree(m->d_sec_own);
     delete m;
 }
 
@@ -253,7 +439,7 @@ int mh_dev_encode(const mh_model *m, const uint8_t *d_data, size_t n, uint8_t pr
     int shift = chunk_shift_of(d_index ? chunk_symbols : MH_CHUNK_DEFAULT);
     if (shift < 0) return MH_ERR_ARG;
     if (ws_bytes < mhk::encode_workspace_bytes(n)) return MH_ERR_CAPACITY;
-    if (m->packed.max_len > mh::MAX_CODE_BITS) return MH_ERR_CODE_TOO_LONG;
+    if (m->max_len > mh::MAX_CODE_BITS) return MH_ERR_CODE_TOO_LONG;
     if (!m->d_enc16) return MH_ERR_NO_DEVICE;
     mhk::EncodeArgs p{};
     p.data = d_data; p.n = n; p.prev0 = prev0; p.chunk_shift = uint32_t(shift);
@@ -276,7 +462,7 @@ int mh_dev_decode(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, u
     if (!aligned16(d_payload) || !aligned16(d_out)) return MH_ERR_ARG;
     int shift = chunk_shift_of(chunk_symbols);
     if (shift < 0) return MH_ERR_ARG;
-    if (m->packed.max_len > mh::MAX_CODE_BITS) return MH_ERR_CODE_TOO_LONG;
+    if (m->max_len > mh::MAX_CODE_BITS) return MH_ERR_CODE_TOO_LONG;
     if (!m->d_prim) return MH_ERR_NO_DEVICE;
     mhk::DecParams p{};
     p.payload = d_payload; p.payload_bytes = (nbits + 7) / 8; p.nbits = nbits;
@@ -285,9 +471,9 @@ int mh_dev_decode(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, u
     p.nchunks = mh_index_entries(n_symbols, chunk_symbols);
     p.chunk_shift = uint32_t(shift);
     p.prim = m->d_prim; p.sec = m->d_sec; p.sec_base = m->d_sec_base; p.tree = m->d_tree;
-    p.P = uint32_t(m->packed.dec_bits); p.nsec = uint32_t(m->packed.dec_sec.size()); p.sec_lds = m->packed.dec_lds ? 1u : 0u;
-    p.sec_lds_entries = m->packed.sec_lds_entries;
-    p.direct = m->packed.dec_direct ? 1u : 0u; p.H = uint32_t(m->packed.dec_h);
+    p.P = uint32_t(m->dec_bits); p.nsec = m->nsec; p.sec_lds = m->dec_lds ? 1u : 0u;
+    p.sec_lds_entries = 0;
+    p.direct = m->dec_direct ? 1u : 0u; p.H = uint32_t(m->dec_h);
     HIP_TRY(mhk::launch_decode(p, d_ws, static_cast<hipStream_t>(stream)));
     return MH_OK;
 }
@@ -298,7 +484,7 @@ int mh_dev_build_index(const mh_model *m, const uint8_t *d_payload, uint64_t nbi
     if (ws_bytes < mhk::build_index_workspace_bytes(nbits)) return MH_ERR_CAPACITY;
     int shift = chunk_shift_of(chunk_symbols);
     if (shift < 0 || !aligned16(d_payload)) return MH_ERR_ARG;
-    if (m->packed.max_len > mh::MAX_CODE_BITS) return MH_ERR_CODE_TOO_LONG;
+    if (m->max_len > mh::MAX_CODE_BITS) return MH_ERR_CODE_TOO_LONG;
     if (!m->d_prim) return MH_ERR_NO_DEVICE;
     mhk::IdxParams p{};
     p.payload = d_payload; p.payload_bytes = (nbits + 7) / 8; p.nbits = nbits;
@@ -306,8 +492,8 @@ int mh_dev_build_index(const mh_model *m, const uint8_t *d_payload, uint64_t nbi
     p.index = reinterpret_cast<unsigned long long *>(d_index); p.index_cap = index_cap;
     p.n_symbols = reinterpret_cast<unsigned long long *>(d_n_symbols);
     p.prim = m->d_prim; p.sec = m->d_sec; p.sec_base = m->d_sec_base; p.tree = m->d_tree;
-    p.P = uint32_t(m->packed.dec_bits);
-    p.direct = m->packed.dec_direct ? 1u : 0u; p.H = uint32_t(m->packed.dec_h);
+    p.P = uint32_t(m->dec_bits);
+    p.direct = m->dec_direct ? 1u : 0u; p.H = uint32_t(m->dec_h);
     HIP_TRY(mhk::launch_build_index(p, d_ws, static_cast<hipStream_t>(stream)));
     return MH_OK;
 }
@@ -344,13 +530,13 @@ int mh_histogram_o1(const uint8_t *data, size_t n, uint8_t prev0, uint64_t *coun
 int mh_histogram_o0(const uint8_t *data, size_t n, uint64_t *counts) { return histogram_host(data, n, 0, counts, 0); }
 
 size_t mh_encode_bound(const mh_model *m, size_t n) {
-    size_t maxlen = m ? size_t(m->packed.max_len) : 64;
+    size_t maxlen = m ? size_t(m->max_len) : 64;
     if (maxlen < 1) maxlen = 1;
     return (n * maxlen + 7) / 8 + 16;
 }
 
 uint8_t mh_stream_header(const mh_model *m, uint64_t nbits) {
-    int type = m ? m->host.type : 1;
+    int type = m ? m->type : 1;
     int bi = int(nbits & 7u);
     return uint8_t(0x30 | ((~type & 1) << 3) | ((8 - bi) % 8));   // src/coding.cpp:88
 }
@@ -358,7 +544,7 @@ uint8_t mh_stream_header(const mh_model *m, uint64_t nbits) {
 int mh_stream_parse_header(const mh_model *m, uint8_t header, uint64_t file_bytes, uint64_t *nbits) {
     if (!m || !nbits || file_bytes < 1) return MH_ERR_ARG;
     if ((header & 0xF0) != 0x30) return MH_ERR_CORRUPT;                         // src/coding.cpp:103-106
-    if (((~(header & (1 << 3)) >> 3) & 1) != m->host.type) return MH_ERR_TYPE;  // src/coding.cpp:107-110
+    if (((~(header & (1 << 3)) >> 3) & 1) != m->type) return MH_ERR_TYPE;  // src/coding.cpp:107-110
     uint64_t total = (file_bytes - 1) * 8;
     uint64_t rem = header & 7u;                                                 // src/coding.cpp:111-115
     if (rem > total) return MH_ERR_CORRUPT;
@@ -371,7 +557,7 @@ int mh_encode(const mh_model *m, const uint8_t *data, size_t n, uint8_t prev0, u
     if (!m || (!data && n) || !nbits || (!out_payload && cap)) return MH_ERR_ARG;
     if (index && chunk_shift_of(chunk_symbols) < 0) return MH_ERR_ARG;
     if (!have_device()) return MH_ERR_NO_DEVICE;
-    if (m->packed.max_len > mh::MAX_CODE_BITS) return MH_ERR_CODE_TOO_LONG;
+    if (m->max_len > mh::MAX_CODE_BITS) return MH_ERR_CODE_TOO_LONG;
     hipStream_t st = nullptr;
     size_t dcap = mh_encode_bound(m, n);
     size_t nidx = index ? size_t(mh_index_entries(n, chunk_symbols)) : 0;

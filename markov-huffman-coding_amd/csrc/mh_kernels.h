@@ -106,6 +106,25 @@ struct IdxParams {
     uint64_t nseg;
 };
 
+// ---- device tree build (mh_tree.hip)
+constexpr int TB_NODE_STRIDE = 520;   // >= 513 nodes per context
+constexpr int TB_META_STRIDE = 16;    // per context: nnodes, root, max_len, #inner nodes at depth 8,
+                                      // second-level sizes for P = 0..8 (table heights capped at 8), weight lo/hi
+struct TreeBuildOut {
+    uint8_t *len8; unsigned long long *code64; uint16_t *enc16; uint8_t *len_slot;
+    uint16_t *node_left, *node_right; uint8_t *node_sym, *node_height;
+    uint32_t *ctx_meta;
+};
+struct TreePackArgs {
+    const uint16_t *node_left, *node_right; const uint8_t *node_sym, *node_height;
+    const uint32_t *ctx_meta;
+    const uint32_t *sec_base;     // 256, entry offsets chosen by the host
+    uint32_t P, direct, H, hcap;
+    uint16_t *prim, *sec; uint32_t *tree;
+};
+hipError_t launch_tree_build(const unsigned long long *d_counts, int nctx, const TreeBuildOut &o, hipStream_t st);
+hipError_t launch_tree_pack(const TreePackArgs &a, int nctx, hipStream_t st);
+
 hipError_t launch_hist_o1(const uint8_t *d_data, uint64_t n, uint32_t prev0, unsigned long long *d_counts, hipStream_t st);
 hipError_t launch_hist_o0(const uint8_t *d_data, uint64_t n, unsigned long long *d_counts, hipStream_t st);
 size_t encode_workspace_bytes(uint64_t n);

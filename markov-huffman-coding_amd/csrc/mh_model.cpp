@@ -115,6 +115,27 @@ void ContextCoder::build_from_counts(const uint64_t *counts) {
     derive_tables();
 }
 
+void ContextCoder::adopt(int nnodes, int root, const uint16_t *left, const uint16_t *right, const uint8_t *sym) {
+    clear();
+    if (root < 0 || nnodes <= 0) return;
+    nodes_.resize(size_t(nnodes));
+    for (int i = 0; i < nnodes; ++i) {
+        Node &n = nodes_[i];
+        n.leaf = left[i] == 0xFFFF;
+        n.child[0] = n.leaf ? int16_t(-1) : int16_t(left[i]);
+        n.child[1] = n.leaf ? int16_t(-1) : int16_t(right[i]);
+        n.sym = sym[i];
+    }
+    // subtree heights (children were created before their parent, except under a one-symbol root)
+    for (int pass = 0; pass < 2; ++pass)
+        for (int i = 0; i < nnodes; ++i) {
+            Node &n = nodes_[i];
+            n.height = n.leaf ? 0 : std::max(nodes_[n.child[0]].height, nodes_[n.child[1]].height) + 1;
+        }
+    root_ = root;
+    derive_tables();
+}
+
 // Iterative DFS, left (bit 0) before right (bit 1) — src/huffman.cpp:97-123.  A later leaf with the
 // same symbol overwrites the earlier code (:115), which is what makes the one-symbol code "1".
 void ContextCoder::derive_tables() {

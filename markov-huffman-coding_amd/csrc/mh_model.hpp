@@ -77,6 +77,8 @@ public:
     bool empty() const { return root_ < 0; }
     void build_from_counts(const uint64_t *counts256);
     bool load(BitReader &in);          // reads one serialized tree; false on a malformed stream
+    // takes over a tree built elsewhere (the device build): nodes in creation order, child = 0xFFFF on a leaf
+    void adopt(int nnodes, int root, const uint16_t *left, const uint16_t *right, const uint8_t *sym);
     void save(BitWriter &out) const;
     const Code &code(int sym) const { return codes_[sym & 255]; }
     int lut(int w) const { return lut_[w & 255]; }   // node index or -1

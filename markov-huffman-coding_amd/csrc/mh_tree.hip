@@ -1,0 +1,265 @@
+// mh_tree.hip — per-context Huffman tree build and table packing on the device.
+//
+//   tree_build_kernel   one wave per context: exact emulation of the reference's heap
+//                       (src/min_pq.tpp:4-52) and merge rule (src/huffman.cpp:131-164) by lane 0 in
+//                       LDS; then all lanes derive depths, codewords (src/huffman.cpp:97-123) and the
+//                       encode tables, and size the decode tables for every primary width.
+//   tree_pack_kernel    one workgroup per context: fills the two decode-table levels and the walk tree
+//                       for the layout the host picked from those sizes (same rule as Model::pack()).
+//
+// The result is bit-identical to the host build in mh_model.cpp (tests/test_gpu_parity.py compares the
+// images); it exists so that histogram -> tables -> encode runs without the 512 KiB of counts going to
+// the host and ~5 ms of host work in the middle of the pipeline.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mh_kernels.h"
+#include "mh_model.hpp"
+
+namespace mhk {
+
+using mh::DEC16_INNER;
+using mh::TREE_LEAF;
+using mh::TREE_STRIDE;
+
+constexpr uint16_t NONE = 0xFFFF;
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void tree_build_kernel(const unsigned long long *__restrict__ counts, TreeBuildOut o) {
+    const uint32_t c = blockIdx.x, lane = threadIdx.x;
+    __shared__ unsigned long long cnt[256];
+    __shared__ unsigned long long hkey[260];
+    __shared__ uint16_t hitem[260];
+    __shared__ uint16_t left[TB_NODE_STRIDE], right[TB_NODE_STRIDE], parent[TB_NODE_STRIDE], height[TB_NODE_STRIDE];
+    __shared__ uint8_t sym[TB_NODE_STRIDE];
+    __shared__ unsigned long long weight[TB_NODE_STRIDE];
+    __shared__ uint8_t olen[256];
+    __shared__ unsigned long long ocode[256];
+    __shared__ uint32_t prof[9];
+    __shared__ uint32_t s_nn, s_root, s_single, s_ntab8, s_maxlen;
+
+    unsigned long long wsum = 0;
+    for (uint32_t i = lane; i < 256; i += 64) {
+        cnt[i] = counts[c * 256 + i];
+        wsum += cnt[i];
+        olen[i] = 0;
+        ocode[i] = 0;
+    }
+    for (int d = 32; d >= 1; d >>= 1) wsum += __shfl_xor(wsum, d);
+    if (lane < 9) prof[lane] = 0;
+    if (lane == 0) { s_ntab8 = 0; s_maxlen = 0; s_single = 0; }
+    __syncthreads();
+
+    if (lane == 0) {
+        // ---- exact heap emulation (same comparisons in the same order as swap-based swim/sink)
+        int nn = 0, hn = 0;
+        auto push = [&](unsigned long long key, uint16_t item) {
+            int i = hn++;
+            while (i != 0) {
+                int par = (i - 1) / 2;
+                if (!(hkey[par] > key)) break;                   // strict >: equal keys do not move
+                hkey[i] = hkey[par]; hitem[i] = hitem[par];
+                i = par;
+            }
+            hkey[i] = key; hitem[i] = item;
+        };
+        auto pop = [&]() -> uint16_t {
+            const uint16_t top = hitem[0];
+            --hn;
+            const unsigned long long key = hkey[hn];
+            const uint16_t item = hitem[hn];
+            int i = 0;
+            for (;;) {
+                int l = 2 * i + 1, r = l + 1;
+                int pick = (r < hn && hkey[r] < hkey[l]) ? r : l;   // right only if strictly smaller
+                if (pick < hn && hkey[pick] < key) {
+                    hkey[i] = hkey[pick]; hitem[i] = hitem[pick];
+                    i = pick;
+                } else {
+                    break;
+                }
+            }
+            hkey[i] = key; hitem[i] = item;
+            return top;
+        };
+        for (int s = 0; s < 256; ++s) {                           // src/huffman.cpp:134-138
+            if (cnt[s]) {
+                left[nn] = right[nn] = NONE; parent[nn] = NONE; height[nn] = 0; sym[nn] = uint8_t(s); weight[nn] = cnt[s];
+                push(cnt[s], uint16_t(nn));
+                ++nn;
+            }
+        }
+        int root = -1;
+        if (hn > 0) {
+            while (hn > 1) {                                      // :143-151
+                uint16_t a = pop(), b = pop();
+                if (height[a] > height[b]) { uint16_t t = a; a = b; b = t; }   // :147-149
+                left[nn] = a; right[nn] = b; parent[nn] = NONE; sym[nn] = 0;
+                weight[nn] = weight[a] + weight[b];
+                height[nn] = uint16_t((height[a] > height[b] ? height[a] : height[b]) + 1);
+                parent[a] = parent[b] = uint16_t(nn);
+                push(weight[nn], uint16_t(nn));
+                ++nn;
+            }
+            root = pop();
+            if (left[root] == NONE) {                             // :154-162 one-symbol context
+                const uint8_t s = sym[root];
+                for (int k = 0; k < 2; ++k) {
+                    left[nn] = right[nn] = NONE; parent[nn] = uint16_t(root); height[nn] = 0; sym[nn] = s; weight[nn] = weight[root];
+                    if (k == 0) left[root] = uint16_t(nn); else right[root] = uint16_t(nn);
+                    ++nn;
+                }
+                height[root] = 1;
+                s_single = 1;
+            }
+        }
+        s_nn = uint32_t(nn);
+        s_root = root < 0 ? 0xFFFFFFFFu : uint32_t(root);
+    }
+    __syncthreads();
+
+    const uint32_t nn = s_nn, root = s_root;
+    if (root != 0xFFFFFFFFu) {
+        for (uint32_t node = lane; node < nn; node += 64) {
+            // walk up: depth, and for a leaf its codeword (last bit first)
+            uint32_t d = 0;
+            unsigned long long code = 0;
+            uint32_t cur = node;
+            while (cur != root) {
+                const uint32_t p = parent[cur];
+                if (right[p] == cur && d < 64) code |= 1ull << d;
+                ++d;
+                cur = p;
+            }
+            if (left[node] == NONE) {
+                // in the one-symbol case the right leaf is visited last and wins (src/huffman.cpp:115)
+                if (!(s_single && node == left[root])) {
+                    olen[sym[node]] = uint8_t(d > 255 ? 255 : d);
+                    ocode[sym[node]] = d <= 64 ? code : 0;
+                    atomicMax(&s_maxlen, d);
+                }
+            } else if (d <= 8) {
+                const uint32_t h = height[node] < 8 ? height[node] : 8;
+                atomicAdd(&prof[d], 1u << h);
+                if (d == 8) atomicAdd(&s_ntab8, 1u);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- outputs
+    for (uint32_t s = lane; s < 256; s += 64) {
+        const uint32_t l = olen[s];
+        const unsigned long long cd = ocode[s];
+        o.len8[c * 256 + s] = uint8_t(l);
+        o.code64[c * 256 + s] = cd;
+        const uint32_t slot = mh::enc_slot((s << 8) | c);
+        uint16_t e = 0;
+        if (l > uint32_t(mh::ENC16_MAX_LEN)) e = mh::ENC16_ESCAPE;
+        else if (l > 0) e = uint16_t((l << 12) | uint32_t(cd));
+        o.enc16[slot] = e;
+        o.len_slot[slot] = uint8_t(l);
+    }
+    for (uint32_t i = lane; i < TB_NODE_STRIDE; i += 64) {
+        const bool live = i < nn;
+        o.node_left[c * TB_NODE_STRIDE + i] = live ? left[i] : NONE;
+        o.node_right[c * TB_NODE_STRIDE + i] = live ? right[i] : NONE;
+        o.node_sym[c * TB_NODE_STRIDE + i] = live ? sym[i] : 0;
+        o.node_height[c * TB_NODE_STRIDE + i] = live ? uint8_t(height[i] > 255 ? 255 : height[i]) : 0;
+    }
+    if (lane == 0) {
+        uint32_t *m = o.ctx_meta + c * TB_META_STRIDE;
+        m[0] = nn; m[1] = root; m[2] = s_maxlen; m[3] = s_ntab8;
+        for (int d = 0; d < 9; ++d) m[4 + d] = prof[d];
+        m[13] = uint32_t(wsum); m[14] = uint32_t(wsum >> 32);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tree_pack_kernel(TreePackArgs a) {
+    const uint32_t c = blockIdx.x, tid = threadIdx.x;
+    __shared__ uint16_t left[TB_NODE_STRIDE], right[TB_NODE_STRIDE], nid[TB_NODE_STRIDE];
+    __shared__ uint8_t sym[TB_NODE_STRIDE], height[TB_NODE_STRIDE];
+    __shared__ uint32_t tr[TREE_STRIDE];
+    __shared__ uint32_t scan[256];
+    const uint32_t *meta = a.ctx_meta + c * TB_META_STRIDE;
+    const uint32_t nn = meta[0], root = meta[1];
+    for (uint32_t i = tid; i < TB_NODE_STRIDE; i += 256) {
+        left[i] = a.node_left[c * TB_NODE_STRIDE + i];
+        right[i] = a.node_right[c * TB_NODE_STRIDE + i];
+        sym[i] = a.node_sym[c * TB_NODE_STRIDE + i];
+        height[i] = a.node_height[c * TB_NODE_STRIDE + i];
+    }
+    tr[tid] = 0;
+    __syncthreads();
+    const uint32_t P = a.P, nprim = 1u << P;
+    if (root == 0xFFFFFFFFu) {                       // empty context: null tables
+        if (tid < nprim) a.prim[(c << P) | tid] = 0;
+        a.tree[c * TREE_STRIDE + tid] = 0;
+        return;
+    }
+    if (tid == 0) {                                   // inner-node ids for the walk: root = 0, the rest in node order
+        uint32_t next = 1;
+        for (uint32_t i = 0; i < nn; ++i) nid[i] = (left[i] == NONE) ? NONE : (i == root ? 0 : uint16_t(next++));
+    }
+    __syncthreads();
+    auto enc_child = [&](uint32_t ch) -> uint32_t { return left[ch] == NONE ? (TREE_LEAF | sym[ch]) : uint32_t(nid[ch]); };
+    for (uint32_t i = tid; i < nn; i += 256)
+        if (left[i] != NONE) tr[nid[i]] = (enc_child(right[i]) << 16) | enc_child(left[i]);
+
+    // first level: thread w follows the P bits of w from the root
+    uint32_t node = root, depth = 0, tabsize = 0, h = 0;
+    if (tid < nprim) {
+        while (depth < P && left[node] != NONE) {
+            const uint32_t bit = (tid >> (P - 1 - depth)) & 1u;
+            node = bit ? right[node] : left[node];
+            ++depth;
+        }
+        if (left[node] != NONE) {                     // internal node at depth P
+            h = a.direct ? a.H : (height[node] < a.hcap ? height[node] : a.hcap);
+            tabsize = 1u << h;
+        }
+    }
+    // exclusive prefix of the table sizes in w order (tables are laid out by increasing w)
+    scan[tid] = tabsize;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        uint32_t v = tid >= d ? scan[tid - d] : 0;
+        __syncthreads();
+        scan[tid] += v;
+        __syncthreads();
+    }
+    const uint32_t off = scan[tid] - tabsize;
+    const uint32_t base = a.sec_base[c];
+    if (tid < nprim) {
+        uint16_t e;
+        if (left[node] == NONE) e = uint16_t((depth << 8) | sym[node]);      // a leaf reached at depth <= P fills its whole range
+        else if (a.direct) e = uint16_t(DEC16_INNER | ((base >> a.H) + (off >> a.H)));
+        else e = uint16_t(DEC16_INNER | ((h - 1) << 12) | off);
+        a.prim[(c << P) | tid] = e;
+        // second level: this thread fills its own table
+        for (uint32_t x = 0; x < tabsize; ++x) {
+            uint32_t n2 = node, d2 = 0;
+            while (d2 < h && left[n2] != NONE) {
+                const uint32_t bit = (x >> (h - 1 - d2)) & 1u;
+                n2 = bit ? right[n2] : left[n2];
+                ++d2;
+            }
+            a.sec[base + off + x] = left[n2] == NONE ? uint16_t((d2 << 8) | sym[n2]) : uint16_t(DEC16_INNER | nid[n2]);
+        }
+    }
+    __syncthreads();
+    a.tree[c * TREE_STRIDE + tid] = tr[tid];
+}
+
+hipError_t launch_tree_build(const unsigned long long *d_counts, int nctx, const TreeBuildOut &o, hipStream_t st) {
+    hipLaunchKernelGGL(tree_build_kernel, dim3(nctx), dim3(64), 0, st, d_counts, o);
+    return hipGetLastError();
+}
+
+hipError_t launch_tree_pack(const TreePackArgs &a, int nctx, hipStream_t st) {
+    hipLaunchKernelGGL(tree_pack_kernel, dim3(nctx), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace mhk

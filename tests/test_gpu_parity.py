@@ -68,6 +68,46 @@ def test_histogram_prev0(mhc, oracle):
         assert np.array_equal(mhc.histogram_o1(data, prev0), oracle.histogram_o1(data, prev0))
 
 
+# ------------------------------------------------------------------ device tree build
+
+@pytest.mark.parametrize("kind", ["zipf", "text", "uniform", "skewed", "ipsum", "wiki_html", "kat3", "one_Z", "empty"])
+def test_device_tree_build_equals_host_build(mhc, oracle, kind):
+    """mh_dev_model_from_counts (tree_build_kernel + tree_pack_kernel) must produce, bit for bit, the
+    images the host build produces from the same counts — and through its lazy host mirror the same
+    table file and codes as the reference."""
+    if kind == "zipf":
+        data = zipf_bytes(1 << 22, 31)
+    elif kind == "text":
+        data = text_like(1 << 20, 32)
+    elif kind == "uniform":
+        data = np.random.default_rng(33).integers(0, 256, 1 << 22, dtype=np.uint8).tobytes()
+    elif kind == "skewed":
+        data = _skewed(1 << 21, 34)
+    elif kind == "ipsum":
+        data = golden()["input_ipsum.txt"]["data"]
+    elif kind == "wiki_html":
+        data = golden()["input_wiki_cpp.html"]["data"]
+    else:
+        data = golden()[kind]["data"]
+    counts = oracle.histogram_o1(data)
+    host = mhc.Model.from_counts(counts, 1)
+    d_counts = mhc.DeviceBuffer(65536 * 8, counts)
+    dev = mhc.Model.from_device_counts(d_counts.ptr, 1)
+    assert dev.decode_layout() == host.decode_layout()
+    assert dev.max_code_len == host.max_code_len
+    for which in range(8):
+        assert dev.image(which) == host.image(which), "image %d differs" % which
+    o = oracle.Model.from_counts(counts, 1)
+    assert dev.table_bytes() == o.table_bytes()          # through the lazily built host mirror
+    ld, cd = dev.codes()
+    lo, co = o.codes()
+    assert np.array_equal(ld, lo) and np.array_equal(cd, co)
+    if data:
+        blob, nbits, idx = dev.compress(data, chunk_symbols=256)
+        assert blob == o.compress(data)[0]
+        assert dev.decompress(blob, index=idx, chunk_symbols=256, n_symbols=len(data)) == data
+
+
 # ------------------------------------------------------------------ encode
 
 @pytest.mark.parametrize("name", golden_names())
