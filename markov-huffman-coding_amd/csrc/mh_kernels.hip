@@ -104,7 +104,7 @@ __device__ __forceinline__ void windows16(const uint4 &x, uint32_t pb, uint32_t 
 // took a counter from 0x7FFF to 0x8000; that lane subtracts the guard bit again and credits 32768 to
 // the 64-bit counter in HBM.  A guard bit never carries into the neighbour because fewer than 32768
 // adds can be in flight between the add that sets it and the subtract that clears it (the workgroup
-// has 1024 lanes x 16 adds).  Slot order = enc_slot(window): the symbol is folded into the low bits so
+// has 1024 lanes x 16 adds).  Slot order = enc_slot(window): a hash of (prev, sym) in the low byte so
 // that skewed contexts spread over LDS banks.
 constexpr int HIST_THREADS = 1024;
 constexpr int HIST_LDS_BYTES = 32768 * 4;
@@ -116,7 +116,7 @@ __device__ __forceinline__ void hist_add(uint32_t *h, unsigned long long *counts
     uint32_t field = hiHalf ? (old >> 16) : (old & 0xFFFFu);
     if (field == 0x7FFFu) {
         atomicSub(&h[slot >> 1], hiHalf ? 0x80000000u : 0x8000u);
-        uint32_t sym = slot >> 8, prev = (slot ^ sym) & 255u;
+        uint32_t sym = slot >> 8, prev = mh::enc_slot_prev(slot);
         atomicAdd(&counts[prev * 256u + sym], 32768ull);
     }
 }
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_o1_kernel(const uint8_t *__
                 const uint32_t slot = w[j], hiHalf = slot & 1u;
                 if (((hiHalf ? (old[j] >> 16) : (old[j] & 0xFFFFu)) == 0x7FFFu)) {
                     atomicSub(&h[slot >> 1], hiHalf ? 0x80000000u : 0x8000u);
-                    uint32_t sym = slot >> 8, prev = (slot ^ sym) & 255u;
+                    uint32_t sym = slot >> 8, prev = mh::enc_slot_prev(slot);
                     atomicAdd(&counts[prev * 256u + sym], 32768ull);
                 }
             }
@@ -175,12 +175,12 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_o1_kernel(const uint8_t *__
         uint32_t lo = v & 0xFFFFu, hi = v >> 16;
         uint32_t slot = w << 1;
         if (lo) {
-            uint32_t sym = slot >> 8, prev = (slot ^ sym) & 255u;
+            uint32_t sym = slot >> 8, prev = mh::enc_slot_prev(slot);
             atomicAdd(&counts[prev * 256u + sym], (unsigned long long)lo);
         }
         if (hi) {
             uint32_t s1 = slot | 1u;
-            uint32_t sym = s1 >> 8, prev = (s1 ^ sym) & 255u;
+            uint32_t sym = s1 >> 8, prev = mh::enc_slot_prev(s1);
             atomicAdd(&counts[prev * 256u + sym], (unsigned long long)hi);
         }
     }

@@ -21,10 +21,17 @@ namespace mh {
 // 0 = "no code" (symbol skipped, src/coding.cpp:72 under NDEBUG), ENC16_ESCAPE = look the
 // codeword up in the full (len8, code64) tables in HBM/L2.
 // Index = enc_slot(window) where window = sym << 8 | prev is the raw little-endian 16-bit field
-// read straight out of the byte stream; the XOR folds the symbol into the bank-selecting low bits.
+// read straight out of the byte stream.  The low byte is hashed, (3 * prev + 37 * sym) mod 256, so
+// that the few very frequent (prev, sym) pairs of a skewed source land in different LDS banks AND in
+// different 32-bit words (the histogram packs two counters per word): with a plain or XOR-ed low
+// byte, Zipf-like data puts ~80 % of all accesses into four banks.  3 is odd, so the map is a
+// bijection of prev for every sym; enc_slot_prev() inverts it (171 = 3^-1 mod 256).
 constexpr uint16_t ENC16_ESCAPE = 0xFFFF;
 constexpr int ENC16_MAX_LEN = 12;
-constexpr uint32_t enc_slot(uint32_t window) { return (window ^ (window >> 8)) & 0xFFFFu; }
+constexpr uint32_t enc_slot(uint32_t window) {
+    return (window & 0xFF00u) | ((3u * (window & 0xFFu) + 37u * (window >> 8)) & 0xFFu);
+}
+constexpr uint32_t enc_slot_prev(uint32_t slot) { return (((slot & 0xFFu) - 37u * (slot >> 8)) * 171u) & 0xFFu; }
 
 // Decode tables: two levels, BOTH LDS-resident whenever they fit (a code that needs an L2 gather per
 // symbol costs the whole wave ~10x an LDS lookup, and with 64 lanes some lane always needs it).
