@@ -18,7 +18,7 @@
 
 namespace mhk {
 
-using mh::DEC16_INNER;
+using mh::DEC16_LEAF;
 using mh::TREE_LEAF;
 using mh::TREE_STRIDE;
 
@@ -659,7 +659,7 @@ struct DecTables {
     uint32_t P;                  // primary width in bits
     const uint16_t *gsec;        // all second-level tables in HBM/L2
     uint32_t lim;                // entries [0, lim) of gsec are also in `sec` (hybrid mode)
-    uint32_t direct, H;          // uniform L2 tables: inner entry = 0x8000 | table id, 2^H entries each
+    uint32_t direct, H;          // uniform L2 tables: inner entry = table id, 2^H entries each
 };
 
 // Decodes one symbol (sequential index builder; tables read from global memory).  Returns the symbol,
@@ -669,21 +669,21 @@ __device__ __forceinline__ uint32_t decode_one(const uint16_t *prim, const uint3
                                                const BitSrc &src, BitCursor &bc, uint32_t prev, uint32_t &used, bool &bad) {
     bc.refill(src);                                        // >= 33 bits: enough for P + 8
     uint32_t e = prim[(prev << t.P) | uint32_t(bc.buf >> (64u - t.P))];
-    if (!(e & DEC16_INNER)) {                              // code of <= P bits (src/coding.cpp:150-156)
-        uint32_t len = e >> 8;
-        bad |= (e == 0);
+    if (e & DEC16_LEAF) {                                  // code of <= P bits (src/coding.cpp:150-156)
+        uint32_t len = (e >> 8) & 31u;
+        bad |= (len == 0);
         bc.drop(len); used += len;
         return e & 255u;
     }
     // longer code (src/coding.cpp:129-149): the node's own table, indexed by the next h bits
     const uint32_t h = t.direct ? t.H : ((e >> 12) & 7u) + 1u;
     bc.drop(t.P);
-    const uint32_t tbase = t.direct ? ((e & 0x7FFFu) << t.H) : sec_base[prev] + (e & 0xFFFu);
+    const uint32_t tbase = t.direct ? (e << t.H) : sec_base[prev] + (e & 0xFFFu);
     uint32_t e2 = t.sec[tbase + uint32_t(bc.buf >> (64u - h))];
-    if (!(e2 & DEC16_INNER)) {
-        uint32_t len = e2 >> 8;
-        bad |= (e2 == 0);
-        bc.drop(len); used += t.P + len;
+    if (e2 & DEC16_LEAF) {
+        uint32_t len = (e2 >> 8) & 31u;                     // total length, P included
+        bad |= (len == 0);
+        if (len) { bc.drop(len - t.P); used += len; }
         return e2 & 255u;
     }
     // longer than P + h: walk the context's tree bit by bit from that node
@@ -734,8 +734,7 @@ struct LaneStream {
     uint32_t pre[GW];     // the one after, possibly still in flight
     uint64_t buf;         // next bits, first at bit 63
     uint32_t cnt;         // valid bits in buf
-    uint32_t taken;       // dwords moved into buf
-    uint32_t sh0;         // bit offset of the stream start inside its first dword
+    uint32_t sh0;         // bit offset of the stream start inside its first granule
 
     __device__ __forceinline__ void issue_pre() {
         const uint32_t g = gnext < gmax ? gnext : gmax;
@@ -811,21 +810,24 @@ struct LaneStream {
         for (uint32_t skip = uint32_t(w % GW); skip; --skip) (void)pop_word<true>();
         const uint32_t hi = __builtin_bswap32(pop_word<true>());
         const uint32_t lo = __builtin_bswap32(pop_word<true>());
-        sh0 = uint32_t(bitpos & 31u);
-        buf = ((uint64_t(hi) << 32) | lo) << sh0;
-        cnt = 64u - sh0;
-        taken = 2;
+        const uint32_t sh = uint32_t(bitpos & 31u);
+        buf = ((uint64_t(hi) << 32) | lo) << sh;
+        cnt = 64u - sh;
+        sh0 = uint32_t(bitpos & (GW * 32u - 1u));
     }
     template <bool CHECKED>
     __device__ __forceinline__ void refill() {               // afterwards cnt >= 33
         if (cnt <= 32u) {
             buf |= uint64_t(__builtin_bswap32(pop_word<CHECKED>())) << (32u - cnt);
             cnt += 32u;
-            ++taken;
         }
     }
-    // stream bits consumed since init()
-    __device__ __forceinline__ uint32_t consumed() const { return taken * 32u - cnt - sh0; }
+    // stream bits consumed since init(): `cur` holds granule gnext - 3 (gnext - 2 while `nxt` is empty),
+    // GW - ccnt of its dwords have gone into the window, cnt bits of the window are still unread
+    __device__ __forceinline__ uint32_t consumed() const {
+        const uint32_t gran = gnext - (nxt_full ? 3u : 2u);
+        return (gran * GW + (GW - ccnt)) * 32u - cnt - sh0;
+    }
 };
 
 // Walk for codes longer than P + h (rare).  `skip` = P + h bits of the window have NOT been consumed.
@@ -859,36 +861,32 @@ __device__ __forceinline__ bool walk_long(const DecTables &t, LS &ls, uint32_t p
 template <int K, bool CHECKED, bool REFILL, bool HYBRID, bool DIRECT, typename LS>
 __device__ __forceinline__ void decode_step(const uint16_t *prim, const uint32_t *sec_base, const DecTables &t,
                                             LS (&ls)[K], uint32_t (&prev)[K], bool &bad) {
-    uint32_t hi[K], e[K], sb[K], len[K], sym[K];
-    bool inner = false;
+    uint32_t hi[K], e[K], sb[K], ef[K];
     if (REFILL) {
 #pragma unroll
         for (int k = 0; k < K; ++k) ls[k].template refill<CHECKED>();
     }
+    uint32_t all = DEC16_LEAF;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         hi[k] = uint32_t(ls[k].buf >> 32);
-        e[k] = prim[(prev[k] << t.P) | (hi[k] >> (32u - t.P))];
+        e[k] = prim[(prev[k] << t.P) + __builtin_amdgcn_ubfe(hi[k], 32u - t.P, t.P)];
         sb[k] = DIRECT ? 0u : sec_base[prev[k]];                // independent of e[k]: same latency
     }
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        len[k] = e[k] >> 8;
-        sym[k] = e[k] & 255u;
-        inner |= (e[k] & DEC16_INNER) != 0;
-    }
-    if (__any(inner)) {                                         // wave-uniform
-        uint32_t e2[K], h[K];
-        bool deep = false;
+    for (int k = 0; k < K; ++k) { ef[k] = e[k]; all &= e[k]; }
+    bool walked = false;
+    if (__any(all == 0)) {                                      // wave-uniform: some stream hit an inner entry
+        uint32_t e2[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const bool in = (e[k] & DEC16_INNER) != 0;
-            h[k] = DIRECT ? t.H : ((e[k] >> 12) & 7u) + 1u;
+            const bool in = (e[k] & DEC16_LEAF) == 0;
+            const uint32_t h = DIRECT ? t.H : ((e[k] >> 12) & 7u) + 1u;
             // only the lanes that need it take part in the gather: every extra quad of lanes costs the
             // vector L1 a tag lookup even when it reads a dummy address
             e2[k] = 0;
-            const uint32_t idx = DIRECT ? (((e[k] & 0x7FFFu) << t.H) | ((hi[k] << t.P) >> (32u - t.H)))
-                                        : sb[k] + (e[k] & 0xFFFu) + ((hi[k] << t.P) >> (32u - h[k]));
+            const uint32_t bits = __builtin_amdgcn_ubfe(hi[k], 32u - t.P - h, h);
+            const uint32_t idx = DIRECT ? ((e[k] << t.H) | bits) : sb[k] + (e[k] & 0xFFFu) + bits;
             if (HYBRID) {
                 // tables of the frequent contexts sit in LDS; only the rest goes through the vector L1
                 if (in && idx < t.lim) e2[k] = t.sec[idx];
@@ -897,31 +895,33 @@ __device__ __forceinline__ void decode_step(const uint16_t *prim, const uint32_t
                 e2[k] = t.sec[idx];
             }
         }
-        // merge with plain selects (e2 is 0 in lanes that did not look anything up)
-        uint32_t any2 = 0;
+        // leaves carry bit 15 and lanes without a second level hold 0: the larger one is the entry that
+        // resolves the symbol; if both are inner the result has no leaf flag and the code is walked
+        uint32_t all2 = DEC16_LEAF;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const bool in = (e[k] & DEC16_INNER) != 0;
-            len[k] = in ? t.P + (e2[k] >> 8) : len[k];   // a null entry ends the chunk at the wrong bit: caught there
-            sym[k] = in ? (e2[k] & 255u) : sym[k];
-            any2 |= e2[k];
+            ef[k] = e[k] > e2[k] ? e[k] : e2[k];
+            all2 &= ef[k];
         }
-        deep = (any2 & DEC16_INNER) != 0;
-        if (__any(deep)) {
+        if (__any(all2 == 0)) {
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                if ((e[k] & DEC16_INNER) && (e2[k] & DEC16_INNER)) {
-                    if (!walk_long(t, ls[k], prev[k], e2[k], t.P + h[k], sym[k])) bad = true;
-                    len[k] = 0;                                 // already consumed
+                if (!(ef[k] & DEC16_LEAF)) {
+                    const uint32_t h = DIRECT ? t.H : ((e[k] >> 12) & 7u) + 1u;
+                    uint32_t s = 0;
+                    if (!walk_long(t, ls[k], prev[k], e2[k], t.P + h, s)) bad = true;
+                    ef[k] = DEC16_LEAF | s;                      // length 0: already consumed
                 }
             }
         }
     }
+    (void)walked;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        ls[k].buf <<= len[k];
-        ls[k].cnt -= len[k];
-        prev[k] = sym[k];
+        const uint32_t len = (ef[k] >> 8) & 31u;    // a null entry consumes nothing: the chunk then ends at the wrong bit
+        ls[k].buf <<= len;
+        ls[k].cnt -= len;
+        prev[k] = ef[k] & 255u;
     }
 }
 

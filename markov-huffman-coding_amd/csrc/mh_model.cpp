@@ -281,7 +281,7 @@ void ContextCoder::sec_profile(int hcap, size_t (&out)[9]) const {
 
 void ContextCoder::pack_decode(int P, int hcap, int uniform_h, uint16_t *prim, std::vector<uint16_t> &sec, size_t sec_start,
                                uint32_t *tree) const {
-    for (int i = 0; i < (1 << P); ++i) prim[i] = 0;
+    for (int i = 0; i < (1 << P); ++i) prim[i] = DEC16_NULL;
     for (int i = 0; i < TREE_STRIDE; ++i) tree[i] = 0;
     if (root_ < 0) return;
     // inner-node ids for the last-resort walk, root = 0
@@ -297,9 +297,10 @@ void ContextCoder::pack_decode(int P, int hcap, int uniform_h, uint16_t *prim, s
             tree[id[i]] = (enc_child(nodes_[i].child[1]) << 16) | enc_child(nodes_[i].child[0]);
 
     struct Item { int node; int depth; uint32_t path; };
-    // fills a 2^width table (dst) with the subtree under `top`: leaves -> len << 8 | sym for every
-    // completion of their path, internal nodes at depth `width` -> inner_entry(node)
-    auto fill = [&](int top, int width, uint16_t *dst, auto inner_entry) {
+    // fills a 2^width table (dst) with the subtree under `top` (itself at depth `above`): leaves ->
+    // LEAF | total len << 8 | sym for every completion of their path, internal nodes at depth `width`
+    // -> inner_entry(node)
+    auto fill = [&](int top, int width, int above, uint16_t *dst, auto inner_entry) {
         std::vector<Item> st{{top, 0, 0}};
         while (!st.empty()) {
             Item it = st.back();
@@ -308,7 +309,7 @@ void ContextCoder::pack_decode(int P, int hcap, int uniform_h, uint16_t *prim, s
             if (nd.leaf) {
                 uint32_t lo = it.path << (width - it.depth);
                 for (uint32_t k = 0; k < (1u << (width - it.depth)); ++k)
-                    dst[lo + k] = uint16_t((it.depth << 8) | nd.sym);
+                    dst[lo + k] = uint16_t(DEC16_LEAF | ((above + it.depth) << 8) | nd.sym);
             } else if (it.depth == width) {
                 dst[it.path] = inner_entry(it.node);
             } else {
@@ -317,13 +318,13 @@ void ContextCoder::pack_decode(int P, int hcap, int uniform_h, uint16_t *prim, s
             }
         }
     };
-    fill(root_, P, prim, [&](int node) -> uint16_t {
+    fill(root_, P, 0, prim, [&](int node) -> uint16_t {
         const int h = uniform_h > 0 ? uniform_h : std::min(nodes_[node].height, hcap);   // >= 1: the node is internal
         const size_t off = sec.size() - sec_start;
-        sec.resize(sec.size() + (size_t(1) << h), 0);
-        fill(node, h, sec.data() + sec_start + off, [&](int deep) -> uint16_t { return uint16_t(DEC16_INNER | id[deep]); });
-        if (uniform_h > 0) return uint16_t(DEC16_INNER | uint32_t(off >> h));       // rank within this context
-        return uint16_t(DEC16_INNER | ((h - 1) << 12) | uint32_t(off));
+        sec.resize(sec.size() + (size_t(1) << h), DEC16_NULL);
+        fill(node, h, P, sec.data() + sec_start + off, [&](int deep) -> uint16_t { return uint16_t(id[deep]); });
+        if (uniform_h > 0) return uint16_t(off >> h);                               // rank within this context
+        return uint16_t(((h - 1) << 12) | uint32_t(off));
     });
 }
 
@@ -443,7 +444,7 @@ Model::Packed Model::pack() const {
         if (pk.dec_direct)      // rank within the context -> global table id
             for (int w = 0; w < (1 << P); ++w) {
                 uint16_t &e = pk.dec_prim[(size_t(prev) << P) + w];
-                if (e & DEC16_INNER) e = uint16_t(DEC16_INNER | ((pk.sec_base[prev] >> uniform_h) + (e & 0x7FFFu)));
+                if (!(e & DEC16_LEAF)) e = uint16_t((pk.sec_base[prev] >> uniform_h) + e);
             }
     }
     if (type == 0)

@@ -37,17 +37,21 @@ constexpr uint32_t enc_slot_prev(uint32_t slot) { return (((slot & 0xFFu) - 37u 
 // symbol costs the whole wave ~10x an LDS lookup, and with 64 lanes some lane always needs it).
 //   prim[ctx << P | first P stream bits]   u16, P = dec_bits, model-wide, 4..8
 //       0      null (empty context)
-//       leaf   len(1..P) << 8 | symbol
-//       inner  0x8000 | (h - 1) << 12 | off : the internal node at depth P; its 2^h-entry table starts
+//       leaf   0x8000 | len(1..P) << 8 | symbol          (0x8000 alone = null: no code has this prefix)
+//       inner  (h - 1) << 12 | off : the internal node at depth P; its 2^h-entry table starts
 //              at sec[sec_base[ctx] + off] and is indexed by the next h stream bits (1 <= h <= 8)
 //   sec[...]   u16
-//       leaf   extra_len(1..h) << 8 | symbol
-//       inner  0x8000 | tree node id : code longer than P + h, walked bit by bit in the L2 tree (rare)
+//       leaf   0x8000 | total_len(P+1..P+h) << 8 | symbol  (5-bit length field, bits 8..12)
+//       inner  tree node id : code longer than P + h, walked bit by bit in the L2 tree (rare)
+// Leaves carry the flag so that (a) max(first-level entry, second-level entry) IS the resolving entry
+// when lanes that need no second level read 0 there, and (b) a leaf used as a table id indexes past
+// the end of `sec`, which a range-checked buffer load turns into that 0 without touching memory.
 // P is the largest width for which prim + sec fit the LDS budget; if none does P = 8 and sec stays in
 // HBM/L2.  In that case the tables are made uniform (2^H entries each, H = min(max_len - 8, 8)) and an
-// inner entry is just 0x8000 | global table id — no per-context base and no per-node height to decode
+// inner entry is just the global table id — no per-context base and no per-node height to decode
 // on the device (falls back to the general form above 32767 tables).  P = 8 is the reference's own 8-bit LUT (src/huffman.cpp:97-123).
-constexpr uint16_t DEC16_INNER = 0x8000;
+constexpr uint16_t DEC16_LEAF = 0x8000;
+constexpr uint16_t DEC16_NULL = DEC16_LEAF;           // leaf of length 0: consumes nothing, the chunk then ends at the wrong bit
 constexpr int DEC_LDS_ENTRIES = (163840 - 1024) / 2;   // u16 entries beside the 1 KiB sec_base array
 constexpr int DEC_SEC_MAX_PER_CTX = 4096;              // 12-bit offsets
 // Last-resort tree in HBM/L2: per context 256 x u32 = right << 16 | left; a child is

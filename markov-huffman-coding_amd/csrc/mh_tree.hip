@@ -18,7 +18,8 @@
 
 namespace mhk {
 
-using mh::DEC16_INNER;
+using mh::DEC16_LEAF;
+using mh::DEC16_NULL;
 using mh::TREE_LEAF;
 using mh::TREE_STRIDE;
 
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(256) void tree_pack_kernel(TreePackArgs a) {
     __syncthreads();
     const uint32_t P = a.P, nprim = 1u << P;
     if (root == 0xFFFFFFFFu) {                       // empty context: null tables
-        if (tid < nprim) a.prim[(c << P) | tid] = 0;
+        if (tid < nprim) a.prim[(c << P) | tid] = DEC16_NULL;
         a.tree[c * TREE_STRIDE + tid] = 0;
         return;
     }
@@ -233,9 +234,9 @@ __global__ __launch_bounds__(256) void tree_pack_kernel(TreePackArgs a) {
     const uint32_t base = a.sec_base[c];
     if (tid < nprim) {
         uint16_t e;
-        if (left[node] == NONE) e = uint16_t((depth << 8) | sym[node]);      // a leaf reached at depth <= P fills its whole range
-        else if (a.direct) e = uint16_t(DEC16_INNER | ((base >> a.H) + (off >> a.H)));
-        else e = uint16_t(DEC16_INNER | ((h - 1) << 12) | off);
+        if (left[node] == NONE) e = uint16_t(DEC16_LEAF | (depth << 8) | sym[node]);      // a leaf reached at depth <= P fills its whole range
+        else if (a.direct) e = uint16_t((base >> a.H) + (off >> a.H));
+        else e = uint16_t(((h - 1) << 12) | off);
         a.prim[(c << P) | tid] = e;
         // second level: this thread fills its own table
         for (uint32_t x = 0; x < tabsize; ++x) {
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(256) void tree_pack_kernel(TreePackArgs a) {
                 n2 = bit ? right[n2] : left[n2];
                 ++d2;
             }
-            a.sec[base + off + x] = left[n2] == NONE ? uint16_t((d2 << 8) | sym[n2]) : uint16_t(DEC16_INNER | nid[n2]);
+            a.sec[base + off + x] = left[n2] == NONE ? uint16_t(DEC16_LEAF | ((P + d2) << 8) | sym[n2]) : uint16_t(nid[n2]);
         }
     }
     __syncthreads();
