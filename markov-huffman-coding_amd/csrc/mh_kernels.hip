@@ -858,9 +858,25 @@ __device__ __forceinline__ bool walk_long(const DecTables &t, LS &ls, uint32_t p
 // bits, so one refill covers two symbols — four when the model has no code longer than 8 bits.
 // A null table entry consumes nothing; the caller detects it because the chunk then ends at the wrong
 // bit offset.
-template <int K, bool CHECKED, bool REFILL, bool HYBRID, bool DIRECT, typename LS>
+// pe[k] is the entry that resolved the stream's previous symbol: only its low byte (the symbol) is
+// defined.  PC / HC: P and H when they are known at compile time (8), 0 = read them from `t`.  With
+// both widths at 8 bits the table indices are byte shuffles (one v_perm each).
+template <int PC>
+__device__ __forceinline__ uint32_t prim_index(uint32_t pe, uint32_t hi, uint32_t P) {
+    if (PC == 8) return __builtin_amdgcn_perm(pe, hi, 0x0C0C0403u);             // sym << 8 | hi >> 24
+    return ((pe & 255u) << P) + __builtin_amdgcn_ubfe(hi, 32u - P, P);
+}
+// inserts the low byte of `e` as byte j of `d` (j is a constant after unrolling)
+__device__ __forceinline__ uint32_t put_byte(uint32_t d, uint32_t e, int j) {
+    const uint32_t sel = j == 0 ? 0x03020104u : j == 1 ? 0x03020400u : j == 2 ? 0x03040100u : 0x04020100u;
+    return __builtin_amdgcn_perm(e, d, sel);
+}
+
+template <int K, bool CHECKED, bool REFILL, bool HYBRID, bool DIRECT, int PC, int HC, typename LS>
 __device__ __forceinline__ void decode_step(const uint16_t *prim, const uint32_t *sec_base, const DecTables &t,
-                                            LS (&ls)[K], uint32_t (&prev)[K], bool &bad) {
+                                            LS (&ls)[K], uint32_t (&pe)[K], bool &bad) {
+    const uint32_t P = PC ? uint32_t(PC) : t.P;
+    const uint32_t H = HC ? uint32_t(HC) : t.H;
     uint32_t hi[K], e[K], sb[K], ef[K];
     if (REFILL) {
 #pragma unroll
@@ -870,23 +886,24 @@ __device__ __forceinline__ void decode_step(const uint16_t *prim, const uint32_t
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         hi[k] = uint32_t(ls[k].buf >> 32);
-        e[k] = prim[(prev[k] << t.P) + __builtin_amdgcn_ubfe(hi[k], 32u - t.P, t.P)];
-        sb[k] = DIRECT ? 0u : sec_base[prev[k]];                // independent of e[k]: same latency
+        e[k] = prim[prim_index<PC>(pe[k], hi[k], P)];
+        sb[k] = DIRECT ? 0u : sec_base[pe[k] & 255u];           // independent of e[k]: same latency
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) { ef[k] = e[k]; all &= e[k]; }
-    bool walked = false;
     if (__any(all == 0)) {                                      // wave-uniform: some stream hit an inner entry
         uint32_t e2[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const bool in = (e[k] & DEC16_LEAF) == 0;
-            const uint32_t h = DIRECT ? t.H : ((e[k] >> 12) & 7u) + 1u;
+            const uint32_t h = DIRECT ? H : ((e[k] >> 12) & 7u) + 1u;
             // only the lanes that need it take part in the gather: every extra quad of lanes costs the
             // vector L1 a tag lookup even when it reads a dummy address
             e2[k] = 0;
-            const uint32_t bits = __builtin_amdgcn_ubfe(hi[k], 32u - t.P - h, h);
-            const uint32_t idx = DIRECT ? ((e[k] << t.H) | bits) : sb[k] + (e[k] & 0xFFFu) + bits;
+            uint32_t idx;
+            if (DIRECT && PC == 8 && HC == 8) idx = __builtin_amdgcn_perm(e[k], hi[k], 0x0C050402u);   // e << 8 | byte 2 of hi
+            else if (DIRECT) idx = (e[k] << H) | __builtin_amdgcn_ubfe(hi[k], 32u - P - H, H);
+            else idx = sb[k] + (e[k] & 0xFFFu) + __builtin_amdgcn_ubfe(hi[k], 32u - P - h, h);
             if (HYBRID) {
                 // tables of the frequent contexts sit in LDS; only the rest goes through the vector L1
                 if (in && idx < t.lim) e2[k] = t.sec[idx];
@@ -907,21 +924,20 @@ __device__ __forceinline__ void decode_step(const uint16_t *prim, const uint32_t
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 if (!(ef[k] & DEC16_LEAF)) {
-                    const uint32_t h = DIRECT ? t.H : ((e[k] >> 12) & 7u) + 1u;
+                    const uint32_t h = DIRECT ? H : ((e[k] >> 12) & 7u) + 1u;
                     uint32_t s = 0;
-                    if (!walk_long(t, ls[k], prev[k], e2[k], t.P + h, s)) bad = true;
+                    if (!walk_long(t, ls[k], pe[k] & 255u, e2[k], P + h, s)) bad = true;
                     ef[k] = DEC16_LEAF | s;                      // length 0: already consumed
                 }
             }
         }
     }
-    (void)walked;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const uint32_t len = (ef[k] >> 8) & 31u;    // a null entry consumes nothing: the chunk then ends at the wrong bit
+        const uint32_t len = __builtin_amdgcn_ubfe(ef[k], 8, 5);   // a null entry consumes nothing: the chunk then ends at the wrong bit
         ls[k].buf <<= len;
         ls[k].cnt -= len;
-        prev[k] = ef[k] & 255u;
+        pe[k] = ef[k];
     }
 }
 
@@ -942,8 +958,8 @@ __device__ __forceinline__ void decode_chunk_single(const uint16_t *lut, const u
     bool bad = false;
     uint32_t q = 0;
     for (uint32_t i = 0; i < nsym; ++i) {
-        decode_step<1, true, true, false, DIRECT>(lut, sub_base, t, ls, prev, bad);
-        q |= prev[0] << (8u * (i & 3u));
+        decode_step<1, true, true, false, DIRECT, 0, 0>(lut, sub_base, t, ls, prev, bad);
+        q |= (prev[0] & 255u) << (8u * (i & 3u));
         if ((i & 3u) == 3u) { *reinterpret_cast<uint32_t *>(o + i - 3u) = q; q = 0; }
     }
     for (uint32_t i = nsym & ~3u; i < nsym; ++i) o[i] = uint8_t(q >> (8u * (i & 3u)));
@@ -960,7 +976,7 @@ __device__ __forceinline__ void decode_chunk_single(const uint16_t *lut, const u
 // re-fetch every 128-byte line four times, 16-byte stores double the write traffic), so they run
 // K = 2 with 64-byte granules and 64-byte store bursts; models that gather from L2 are bound by that
 // latency and run K = 4 with the lighter 32-byte / 16-byte streams.
-template <bool SEC_LDS, int SPR, bool DIRECT, int K, int GW, int OUTB>
+template <bool SEC_LDS, int SPR, bool DIRECT, int K, int GW, int OUTB, int PC, int HC>
 __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS: sec_base u32[256] | prim u16[256 << P] | sec u16[nsec] (only when the model's tables fit)
@@ -1024,10 +1040,10 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecParams p) {
                         for (int k = 0; k < K; ++k) d[k] = 0;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            if (j % SPR == 0) decode_step<K, false, true, false, DIRECT>(lut, sub_base, tabs, ls, prev, bad);
-                            else decode_step<K, false, false, false, DIRECT>(lut, sub_base, tabs, ls, prev, bad);
+                            if (j % SPR == 0) decode_step<K, false, true, false, DIRECT, PC, HC>(lut, sub_base, tabs, ls, prev, bad);
+                            else decode_step<K, false, false, false, DIRECT, PC, HC>(lut, sub_base, tabs, ls, prev, bad);
 #pragma unroll
-                            for (int k = 0; k < K; ++k) d[k] |= prev[k] << (8 * j);
+                            for (int k = 0; k < K; ++k) d[k] = put_byte(d[k], prev[k], j);
                         }
 #pragma unroll
                         for (int k = 0; k < K; ++k) { q[k][0] = q[k][1]; q[k][1] = q[k][2]; q[k][2] = q[k][3]; q[k][3] = d[k]; }
@@ -1280,23 +1296,25 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
     p.status = reinterpret_cast<int *>(d_ws);
     hipError_t e = hipMemsetAsync(d_ws, 0, 64, st);
     if (e != hipSuccess || p.nchunks == 0) return e;
-    // instantiations: tables in LDS -> 2 streams, 64-byte granules and store bursts; L2 gathers -> 4 light streams
-    auto k_lds2 = decode_kernel<true, 2, false, 2, 16, 4>;
-    auto k_lds4 = decode_kernel<true, 4, false, 2, 16, 4>;
-    auto k_lds2_light = decode_kernel<true, 2, false, 4, 8, 1>;
-    auto k_lds4_light = decode_kernel<true, 4, false, 4, 8, 1>;
-    auto k_l2 = decode_kernel<false, 2, false, 4, 8, 1>;
-    auto k_l2d = decode_kernel<false, 2, true, 4, 8, 1>;
+    // instantiations: <SEC_LDS, SPR, DIRECT, K, GW, OUTB, PC, HC>
+    // tables in LDS -> wide (2 streams, 64-byte granules and store bursts) or light (4 streams); L2 gathers -> light
+    void (*k_lds2[2])(DecParams) = {decode_kernel<true, 2, false, 2, 16, 4, 0, 0>, decode_kernel<true, 2, false, 2, 16, 4, 8, 0>};
+    void (*k_lds2_light[2])(DecParams) = {decode_kernel<true, 2, false, 4, 8, 1, 0, 0>, decode_kernel<true, 2, false, 4, 8, 1, 8, 0>};
+    auto k_lds4 = decode_kernel<true, 4, false, 2, 16, 4, 8, 0>;
+    auto k_lds4_light = decode_kernel<true, 4, false, 4, 8, 1, 8, 0>;
+    auto k_l2 = decode_kernel<false, 2, false, 4, 8, 1, 8, 0>;
+    void (*k_l2d[2])(DecParams) = {decode_kernel<false, 2, true, 4, 8, 1, 8, 0>, decode_kernel<false, 2, true, 4, 8, 1, 8, 8>};
     static bool once = false;
     if (!once) {
-        e = allow_lds(reinterpret_cast<const void *>(k_lds2), DEC_LDS_MAX); if (e != hipSuccess) return e;
-        e = allow_lds(reinterpret_cast<const void *>(k_lds4), DEC_LDS_MAX); if (e != hipSuccess) return e;
-        e = allow_lds(reinterpret_cast<const void *>(k_lds2_light), DEC_LDS_MAX); if (e != hipSuccess) return e;
-        e = allow_lds(reinterpret_cast<const void *>(k_lds4_light), DEC_LDS_MAX); if (e != hipSuccess) return e;
-        e = allow_lds(reinterpret_cast<const void *>(k_l2), DEC_LDS_MAX); if (e != hipSuccess) return e;
-        e = allow_lds(reinterpret_cast<const void *>(k_l2d), DEC_LDS_MAX); if (e != hipSuccess) return e;
+        const void *all[] = {(const void *)k_lds2[0], (const void *)k_lds2[1], (const void *)k_lds2_light[0], (const void *)k_lds2_light[1],
+                             (const void *)k_lds4, (const void *)k_lds4_light, (const void *)k_l2, (const void *)k_l2d[0], (const void *)k_l2d[1]};
+        for (const void *f : all) {
+            e = allow_lds(f, DEC_LDS_MAX);
+            if (e != hipSuccess) return e;
+        }
         once = true;
     }
+    if (!p.sec_lds && p.P != 8) return hipErrorInvalidValue;       // the L2 layouts are built with P = 8
     size_t lds = 1024 + (size_t(256) << p.P) * 2 + (p.sec_lds ? ((size_t(p.nsec) * 2 + 15) & ~size_t(15)) : 0);
     if (lds > size_t(DEC_LDS_MAX)) return hipErrorInvalidValue;
     // with the tables in LDS the kernel is bound by how the streams touch HBM once the payload is a
@@ -1307,9 +1325,10 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
     uint64_t want = (p.nchunks + per_block - 1) / per_block;
     int grid = int(want > uint64_t(cu_count()) ? uint64_t(cu_count()) : want);
     const bool short_codes = p.nsec == 0 && p.P == 8;
-    if (p.sec_lds && wide) hipLaunchKernelGGL(short_codes ? k_lds4 : k_lds2, dim3(grid), dim3(DEC_THREADS), lds, st, p);
-    else if (p.sec_lds) hipLaunchKernelGGL(short_codes ? k_lds4_light : k_lds2_light, dim3(grid), dim3(DEC_THREADS), lds, st, p);
-    else if (p.direct) hipLaunchKernelGGL(k_l2d, dim3(grid), dim3(DEC_THREADS), lds, st, p);
+    const int p8 = p.P == 8;
+    if (p.sec_lds && wide) hipLaunchKernelGGL(short_codes ? k_lds4 : k_lds2[p8], dim3(grid), dim3(DEC_THREADS), lds, st, p);
+    else if (p.sec_lds) hipLaunchKernelGGL(short_codes ? k_lds4_light : k_lds2_light[p8], dim3(grid), dim3(DEC_THREADS), lds, st, p);
+    else if (p.direct) hipLaunchKernelGGL(k_l2d[p.H == 8], dim3(grid), dim3(DEC_THREADS), lds, st, p);
     else hipLaunchKernelGGL(k_l2, dim3(grid), dim3(DEC_THREADS), lds, st, p);
     return hipGetLastError();
 }
