@@ -107,7 +107,8 @@ class Codec:
         self.nbits = torch.zeros(2, dtype=torch.int64, device=device)
         self.enc_ws_bytes = self.lib.mh_dev_encode_workspace(n)
         self.enc_ws = torch.empty(self.enc_ws_bytes + 64, dtype=torch.uint8, device=device)
-        self.dec_ws = torch.empty(256, dtype=torch.uint8, device=device)
+        self.dec_ws_bytes = int(self.lib.mh_dev_decode_workspace(0, n, CHUNK))
+        self.dec_ws = torch.empty(self.dec_ws_bytes, dtype=torch.uint8, device=device)
 
     def check(self, rc, what):
         if rc != 0:
@@ -130,7 +131,7 @@ class Codec:
 
     def decode(self, model, nbits):
         self.check(self.lib.mh_dev_decode(model.handle, self.payload.data_ptr(), nbits, self.decoded.data_ptr(), self.n,
-                                          self.index.data_ptr(), CHUNK, self.dec_ws.data_ptr(), 256, self.stream()), "decode")
+                                          self.index.data_ptr(), CHUNK, self.dec_ws.data_ptr(), self.dec_ws_bytes, self.stream()), "decode")
 
 
 def cpu_baseline(mhc, model, sample, gpu_payload_prefix_check):

@@ -451,13 +451,18 @@ int mh_dev_encode(const mh_model *m, const uint8_t *d_data, size_t n, uint8_t pr
     return MH_OK;
 }
 
-size_t mh_dev_decode_workspace(uint64_t, uint64_t, uint32_t) { return 64; }
+size_t mh_dev_decode_workspace(uint64_t, uint64_t n_symbols, uint32_t chunk_symbols) {
+    // status block + the redo list (a count and up to one u32 per chunk)
+    if (chunk_shift_of(chunk_symbols) < 0) return 0;
+    return (64 + 4 * (size_t(mh_index_entries(n_symbols, chunk_symbols)) + 1) + 15) & ~size_t(15);
+}
 
 size_t mh_dev_build_index_workspace(uint64_t nbits) { return mhk::build_index_workspace_bytes(nbits); }
 
 int mh_dev_decode(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, uint8_t *d_out, uint64_t n_symbols,
                   const uint64_t *d_index, uint32_t chunk_symbols, void *d_ws, size_t ws_bytes, void *stream) {
     if (!m || !d_ws || ws_bytes < 64) return MH_ERR_ARG;
+    if (ws_bytes < mh_dev_decode_workspace(nbits, n_symbols, chunk_symbols)) return MH_ERR_ARG;
     if (n_symbols && (!d_payload || !d_out || !d_index)) return MH_ERR_ARG;
     if (!aligned16(d_payload) || !aligned16(d_out)) return MH_ERR_ARG;
     int shift = chunk_shift_of(chunk_symbols);
@@ -592,7 +597,6 @@ int mh_decode(const mh_model *m, const uint8_t *payload, uint64_t nbits, uint8_t
     size_t pbytes = size_t((nbits + 7) / 8);
     DevBuf d_payload, d_index, d_ws, d_nsym, d_out;
     HIP_TRY(d_payload.alloc(pbytes));
-    HIP_TRY(d_ws.alloc(64));
     if (pbytes) HIP_TRY(hipMemcpy(d_payload.p, payload, pbytes, hipMemcpyHostToDevice));
     size_t nidx;
     if (index) {
@@ -617,8 +621,10 @@ int mh_decode(const mh_model *m, const uint8_t *payload, uint64_t nbits, uint8_t
     *nbytes = size_t(n_symbols);
     if (n_symbols > cap) return MH_ERR_CAPACITY;
     HIP_TRY(d_out.alloc(size_t(n_symbols)));
+    const size_t dws = mh_dev_decode_workspace(nbits, n_symbols, chunk_symbols);
+    HIP_TRY(d_ws.alloc(dws));
     int rc = mh_dev_decode(m, d_payload.as<uint8_t>(), nbits, d_out.as<uint8_t>(), n_symbols, d_index.as<uint64_t>(),
-                           chunk_symbols, d_ws.p, 64, st);
+                           chunk_symbols, d_ws.p, dws, st);
     if (rc != MH_OK) return rc;
     rc = mh_dev_status(d_ws.p, st);
     if (rc != MH_OK) return rc;

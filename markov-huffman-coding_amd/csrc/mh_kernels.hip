@@ -724,9 +724,9 @@ __device__ __forceinline__ uint32_t decode_one(const uint16_t *prim, const uint3
 template <int GW>
 struct LaneStream {
     static constexpr int NQ = GW / 4;      // uint4 loads per granule
-    const uint4 *g0;      // granule 0 of this lane (GW*4-byte aligned)
-    uint32_t gmax;        // last readable granule, relative to g0
-    uint32_t gnext;       // granule that goes into `pre` next
+    const uint4 *base;    // payload (wave-uniform: lives in SGPRs)
+    uint32_t glast;       // last readable granule of the payload (wave-uniform)
+    uint32_t gnext;       // granule (counted from the payload start) that goes into `pre` next
     uint32_t cur[GW];     // granule feeding the window, cur[0] is next
     uint32_t ccnt;        // dwords left in cur
     uint32_t nxt[GW];     // following granule, resident
@@ -734,13 +734,13 @@ struct LaneStream {
     uint32_t pre[GW];     // the one after, possibly still in flight
     uint64_t buf;         // next bits, first at bit 63
     uint32_t cnt;         // valid bits in buf
-    uint32_t sh0;         // bit offset of the stream start inside its first granule
 
     __device__ __forceinline__ void issue_pre() {
-        const uint32_t g = gnext < gmax ? gnext : gmax;
+        const uint32_t g = gnext < glast ? gnext : glast;
+        const uint4 *src = base + uint64_t(NQ) * g;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const uint4 a = g0[NQ * g + q];
+            const uint4 a = src[q];
             pre[4 * q] = a.x; pre[4 * q + 1] = a.y; pre[4 * q + 2] = a.z; pre[4 * q + 3] = a.w;
         }
         ++gnext;
@@ -793,11 +793,9 @@ struct LaneStream {
     // total_bytes > 0 and bitpos < 8 * total_bytes (checked by the caller)
     __device__ __forceinline__ void init(const uint8_t *payload, uint64_t total_bytes, uint64_t bitpos) {
         const uint64_t w = bitpos >> 5;                      // first stream dword
-        const uint64_t gran = w / GW;
-        g0 = reinterpret_cast<const uint4 *>(payload) + NQ * gran;
-        const uint64_t left = ((total_bytes - 1) / (GW * 4)) - gran;
-        gmax = left > 0xFFFFFFFFull ? 0xFFFFFFFFu : uint32_t(left);
-        gnext = 0;
+        base = reinterpret_cast<const uint4 *>(payload);
+        glast = uint32_t((total_bytes - 1) / (GW * 4));       // payloads stay below 2^32 granules (128 GiB)
+        gnext = uint32_t(w / GW);
         issue_pre();
 #pragma unroll
         for (int i = 0; i < GW; ++i) cur[i] = pre[i];
@@ -813,7 +811,6 @@ struct LaneStream {
         const uint32_t sh = uint32_t(bitpos & 31u);
         buf = ((uint64_t(hi) << 32) | lo) << sh;
         cnt = 64u - sh;
-        sh0 = uint32_t(bitpos & (GW * 32u - 1u));
     }
     template <bool CHECKED>
     __device__ __forceinline__ void refill() {               // afterwards cnt >= 33
@@ -822,11 +819,12 @@ struct LaneStream {
             cnt += 32u;
         }
     }
-    // stream bits consumed since init(): `cur` holds granule gnext - 3 (gnext - 2 while `nxt` is empty),
-    // GW - ccnt of its dwords have gone into the window, cnt bits of the window are still unread
-    __device__ __forceinline__ uint32_t consumed() const {
+    // position of the next unread bit in the payload, modulo 2^32: `cur` holds granule gnext - 3
+    // (gnext - 2 while `nxt` is empty), GW - ccnt of its dwords have gone into the window, cnt bits of
+    // the window are still unread
+    __device__ __forceinline__ uint32_t position() const {
         const uint32_t gran = gnext - (nxt_full ? 3u : 2u);
-        return (gran * GW + (GW - ccnt)) * 32u - cnt - sh0;
+        return (gran * GW + (GW - ccnt)) * 32u - cnt;
     }
 };
 
@@ -872,9 +870,12 @@ __device__ __forceinline__ uint32_t put_byte(uint32_t d, uint32_t e, int j) {
     return __builtin_amdgcn_perm(e, d, sel);
 }
 
-template <int K, bool CHECKED, bool REFILL, bool HYBRID, bool DIRECT, int PC, int HC, typename LS>
+// WALK: codes longer than both table levels are walked in place.  The K-stream hot loop runs without
+// it (K inlined copies of the walk cost 13 % of the decode time in registers and code): such a stream
+// sets its bit in `redo`, and the kernel hands the chunk to the redo pass.
+template <int K, bool CHECKED, bool REFILL, bool HYBRID, bool DIRECT, int PC, int HC, bool WALK, typename LS>
 __device__ __forceinline__ void decode_step(const uint16_t *prim, const uint32_t *sec_base, const DecTables &t,
-                                            LS (&ls)[K], uint32_t (&pe)[K], bool &bad) {
+                                            LS (&ls)[K], uint32_t (&pe)[K], bool &bad, uint32_t &redo) {
     const uint32_t P = PC ? uint32_t(PC) : t.P;
     const uint32_t H = HC ? uint32_t(HC) : t.H;
     uint32_t hi[K], e[K], sb[K], ef[K];
@@ -924,10 +925,15 @@ __device__ __forceinline__ void decode_step(const uint16_t *prim, const uint32_t
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 if (!(ef[k] & DEC16_LEAF)) {
-                    const uint32_t h = DIRECT ? H : ((e[k] >> 12) & 7u) + 1u;
-                    uint32_t s = 0;
-                    if (!walk_long(t, ls[k], pe[k] & 255u, e2[k], P + h, s)) bad = true;
-                    ef[k] = DEC16_LEAF | s;                      // length 0: already consumed
+                    if (WALK) {
+                        const uint32_t h = DIRECT ? H : ((e[k] >> 12) & 7u) + 1u;
+                        uint32_t s = 0;
+                        if (!walk_long(t, ls[k], pe[k] & 255u, e2[k], P + h, s)) bad = true;
+                        ef[k] = DEC16_LEAF | s;                  // length 0: already consumed
+                    } else {
+                        redo |= 1u << k;                         // the rest of this chunk decodes to nothing
+                        ef[k] = DEC16_LEAF;
+                    }
                 }
             }
         }
@@ -956,14 +962,14 @@ __device__ __forceinline__ void decode_chunk_single(const uint16_t *lut, const u
     uint32_t prev[1] = {uint32_t(entry >> 56)};
     ls[0].init(payload, total_bytes, bitpos);
     bool bad = false;
-    uint32_t q = 0;
+    uint32_t q = 0, redo = 0;
     for (uint32_t i = 0; i < nsym; ++i) {
-        decode_step<1, true, true, false, DIRECT, 0, 0>(lut, sub_base, t, ls, prev, bad);
+        decode_step<1, true, true, false, DIRECT, 0, 0, true>(lut, sub_base, t, ls, prev, bad, redo);
         q |= (prev[0] & 255u) << (8u * (i & 3u));
         if ((i & 3u) == 3u) { *reinterpret_cast<uint32_t *>(o + i - 3u) = q; q = 0; }
     }
     for (uint32_t i = nsym & ~3u; i < nsym; ++i) o[i] = uint8_t(q >> (8u * (i & 3u)));
-    if (bad || bitpos + ls[0].consumed() != end_bits) atomicExch(status, MHK_STATUS_CORRUPT);
+    if (bad || ls[0].position() != uint32_t(end_bits)) atomicExch(status, MHK_STATUS_CORRUPT);
 }
 
 // SEC_LDS  both table levels in LDS (else the second level is gathered from L2)
@@ -976,19 +982,20 @@ __device__ __forceinline__ void decode_chunk_single(const uint16_t *lut, const u
 // re-fetch every 128-byte line four times, 16-byte stores double the write traffic), so they run
 // K = 2 with 64-byte granules and 64-byte store bursts; models that gather from L2 are bound by that
 // latency and run K = 4 with the lighter 32-byte / 16-byte streams.
-template <bool SEC_LDS, int SPR, bool DIRECT, int K, int GW, int OUTB, int PC, int HC>
-__global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecParams p) {
+template <bool SEC_LDS, int SPR, bool DIRECT, int K, int GW, int OUTB, int PC, int HC, bool REDO = false, int NT = 512>
+__global__ __launch_bounds__(NT) void decode_kernel(DecParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (REDO && p.redo[0] == 0) return;                         // the usual case: nothing was handed over
     // LDS: sec_base u32[256] | prim u16[256 << P] | sec u16[nsec] (only when the model's tables fit)
     uint32_t *sub_base = reinterpret_cast<uint32_t *>(smem);
     uint16_t *lut = reinterpret_cast<uint16_t *>(smem + 1024);
     const uint32_t nprim16 = (256u << p.P) / 8u;                // uint4 units
-    for (uint32_t i = threadIdx.x; i < nprim16; i += DEC_THREADS)
+    for (uint32_t i = threadIdx.x; i < nprim16; i += NT)
         reinterpret_cast<uint4 *>(lut)[i] = reinterpret_cast<const uint4 *>(p.prim)[i];
     uint16_t *lsec = lut + (256u << p.P);
     if (SEC_LDS) {
         const uint32_t nsec16 = (p.nsec + 7u) / 8u;             // the buffer is padded to 16 bytes
-        for (uint32_t i = threadIdx.x; i < nsec16; i += DEC_THREADS)
+        for (uint32_t i = threadIdx.x; i < nsec16; i += NT)
             reinterpret_cast<uint4 *>(lsec)[i] = reinterpret_cast<const uint4 *>(p.sec)[i];
     }
     if (threadIdx.x < 256) sub_base[threadIdx.x] = p.sec_base[threadIdx.x];
@@ -999,30 +1006,42 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecParams p) {
     const DecTables tabs{SEC_LDS ? lsec : p.sec, p.tree, p.P, p.sec, 0xFFFFFFFFu, p.direct, p.H};
     const uint32_t S = 1u << p.chunk_shift;
     const uint64_t full_chunks = p.n >> p.chunk_shift;          // chunks with exactly S symbols
-    const uint64_t group = uint64_t(DEC_THREADS) * K;           // chunks per workgroup iteration
+    if (REDO) {
+        // ---- redo pass: the chunks the hot loop gave up on (a code longer than both table levels),
+        // one lane per chunk, with the walk
+        const uint32_t count = p.redo[0];
+        for (uint32_t i = blockIdx.x * NT + threadIdx.x; i < count; i += gridDim.x * NT) {
+            const uint64_t c = p.redo[1 + i];
+            const uint64_t first = c << p.chunk_shift;
+            const uint32_t nsym = (p.n - first) >= S ? S : uint32_t(p.n - first);
+            const uint64_t endb = (c + 1 < p.nchunks) ? (p.index[c + 1] & 0x00FFFFFFFFFFFFFFull) : p.nbits;
+            decode_chunk_single<DIRECT>(lut, sub_base, tabs, p.payload, p.payload_bytes, p.nbits, p.index[c], endb, p.out + first, nsym, p.status);
+        }
+        return;
+    }
+    const uint64_t group = uint64_t(NT) * K;           // chunks per workgroup iteration
     constexpr int BLK16 = (2 * GW) / 16;                        // 16-symbol groups per refill block
     for (uint64_t g0 = uint64_t(blockIdx.x) * group; g0 < p.nchunks; g0 += uint64_t(gridDim.x) * group) {
-        const uint64_t c0 = g0 + threadIdx.x;                   // stream k -> chunk c0 + k * DEC_THREADS
-        if (c0 + uint64_t(K - 1) * DEC_THREADS < full_chunks) {
+        const uint64_t c0 = g0 + threadIdx.x;                   // stream k -> chunk c0 + k * NT
+        if (c0 + uint64_t(K - 1) * NT < full_chunks) {
             // ---- K full chunks: interleaved decode
             LaneStream<GW> ls[K];
             uint32_t prev[K];
-            uint32_t expect[K];                                  // bits each chunk must consume
             bool ok = true;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                const uint64_t c = c0 + uint64_t(k) * DEC_THREADS;
+                const uint64_t c = c0 + uint64_t(k) * NT;
                 const uint64_t entry = p.index[c];
                 const uint64_t bitpos = entry & 0x00FFFFFFFFFFFFFFull;
                 const uint64_t endpos = (c + 1 < p.nchunks) ? (p.index[c + 1] & 0x00FFFFFFFFFFFFFFull) : p.nbits;
                 prev[k] = uint32_t(entry >> 56);
                 const bool fine = bitpos < p.nbits && endpos >= bitpos && endpos - bitpos <= (uint64_t(S) << 6);
                 ok = ok && fine;
-                expect[k] = uint32_t(endpos - bitpos);
                 if (fine) ls[k].init(p.payload, p.payload_bytes, bitpos);
             }
             if (!ok) { atomicExch(p.status, MHK_STATUS_CORRUPT); continue; }
             bool bad = false;
+            uint32_t redo = 0;                                   // bit k: stream k met a code the tables do not resolve
             for (uint32_t burst = 0; burst < (S >> 4) / OUTB; ++burst) {
                 uint32_t Q[K][OUTB][4];
 #pragma unroll
@@ -1040,8 +1059,8 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecParams p) {
                         for (int k = 0; k < K; ++k) d[k] = 0;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            if (j % SPR == 0) decode_step<K, false, true, false, DIRECT, PC, HC>(lut, sub_base, tabs, ls, prev, bad);
-                            else decode_step<K, false, false, false, DIRECT, PC, HC>(lut, sub_base, tabs, ls, prev, bad);
+                            if (j % SPR == 0) decode_step<K, false, true, false, DIRECT, PC, HC, false>(lut, sub_base, tabs, ls, prev, bad, redo);
+                            else decode_step<K, false, false, false, DIRECT, PC, HC, false>(lut, sub_base, tabs, ls, prev, bad, redo);
 #pragma unroll
                             for (int k = 0; k < K; ++k) d[k] = put_byte(d[k], prev[k], j);
                         }
@@ -1053,7 +1072,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecParams p) {
                 }
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
-                    uint4 *o16 = reinterpret_cast<uint4 *>(p.out + ((c0 + uint64_t(k) * DEC_THREADS) << p.chunk_shift)) + burst * OUTB;
+                    uint4 *o16 = reinterpret_cast<uint4 *>(p.out + ((c0 + uint64_t(k) * NT) << p.chunk_shift)) + burst * OUTB;
 #pragma unroll
                     for (int u = 0; u < OUTB; ++u) o16[u] = make_uint4(Q[k][u][0], Q[k][u][1], Q[k][u][2], Q[k][u][3]);
                 }
@@ -1061,12 +1080,17 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(DecParams p) {
             // every chunk must end exactly where the next one starts (null entries, a wrong table or a
             // damaged stream all miss it)
 #pragma unroll
-            for (int k = 0; k < K; ++k) bad |= ls[k].consumed() != expect[k];
+            for (int k = 0; k < K; ++k) {
+                const uint64_t c = c0 + uint64_t(k) * NT;
+                const uint64_t endpos = (c + 1 < p.nchunks) ? (p.index[c + 1] & 0x00FFFFFFFFFFFFFFull) : p.nbits;
+                if (redo & (1u << k)) p.redo[1u + atomicAdd(p.redo, 1u)] = uint32_t(c);    // its output is rewritten by the redo pass
+                else bad |= ls[k].position() != uint32_t(endpos);
+            }
             if (bad) atomicExch(p.status, MHK_STATUS_CORRUPT);
         } else {
             // ---- end of the stream: whatever chunks exist, one at a time
             for (int k = 0; k < K; ++k) {
-                const uint64_t c = c0 + uint64_t(k) * DEC_THREADS;
+                const uint64_t c = c0 + uint64_t(k) * NT;
                 if (c >= p.nchunks) break;
                 const uint64_t first = c << p.chunk_shift;
                 const uint32_t nsym = (p.n - first) >= S ? S : uint32_t(p.n - first);
@@ -1294,7 +1318,8 @@ hipError_t launch_encode(const EncodeArgs &a, void *d_ws, hipStream_t st) {
 
 hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
     p.status = reinterpret_cast<int *>(d_ws);
-    hipError_t e = hipMemsetAsync(d_ws, 0, 64, st);
+    p.redo = reinterpret_cast<uint32_t *>(static_cast<char *>(d_ws) + 64);      // [0] = count, then chunk numbers
+    hipError_t e = hipMemsetAsync(d_ws, 0, 64 + 16, st);
     if (e != hipSuccess || p.nchunks == 0) return e;
     // instantiations: <SEC_LDS, SPR, DIRECT, K, GW, OUTB, PC, HC>
     // tables in LDS -> wide (2 streams, 64-byte granules and store bursts) or light (4 streams); L2 gathers -> light
@@ -1304,10 +1329,15 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
     auto k_lds4_light = decode_kernel<true, 4, false, 4, 8, 1, 8, 0>;
     auto k_l2 = decode_kernel<false, 2, false, 4, 8, 1, 8, 0>;
     void (*k_l2d[2])(DecParams) = {decode_kernel<false, 2, true, 4, 8, 1, 8, 0>, decode_kernel<false, 2, true, 4, 8, 1, 8, 8>};
+    // redo pass (one lane per handed-over chunk, runtime table widths)
+    auto r_lds = decode_kernel<true, 2, false, 1, 8, 1, 0, 0, true>;
+    auto r_l2 = decode_kernel<false, 2, false, 1, 8, 1, 0, 0, true>;
+    auto r_l2d = decode_kernel<false, 2, true, 1, 8, 1, 0, 0, true>;
     static bool once = false;
     if (!once) {
         const void *all[] = {(const void *)k_lds2[0], (const void *)k_lds2[1], (const void *)k_lds2_light[0], (const void *)k_lds2_light[1],
-                             (const void *)k_lds4, (const void *)k_lds4_light, (const void *)k_l2, (const void *)k_l2d[0], (const void *)k_l2d[1]};
+                             (const void *)k_lds4, (const void *)k_lds4_light, (const void *)k_l2, (const void *)k_l2d[0], (const void *)k_l2d[1],
+                             (const void *)r_lds, (const void *)r_l2, (const void *)r_l2d};
         for (const void *f : all) {
             e = allow_lds(f, DEC_LDS_MAX);
             if (e != hipSuccess) return e;
@@ -1330,6 +1360,12 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
     else if (p.sec_lds) hipLaunchKernelGGL(short_codes ? k_lds4_light : k_lds2_light[p8], dim3(grid), dim3(DEC_THREADS), lds, st, p);
     else if (p.direct) hipLaunchKernelGGL(k_l2d[p.H == 8], dim3(grid), dim3(DEC_THREADS), lds, st, p);
     else hipLaunchKernelGGL(k_l2, dim3(grid), dim3(DEC_THREADS), lds, st, p);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    // chunks with a code longer than both table levels: normally none, and the pass returns at once
+    const uint64_t rwant = (p.nchunks + DEC_THREADS - 1) / DEC_THREADS;
+    const int rgrid = int(rwant > uint64_t(cu_count()) ? uint64_t(cu_count()) : rwant);
+    hipLaunchKernelGGL(p.sec_lds ? r_lds : p.direct ? r_l2d : r_l2, dim3(rgrid), dim3(DEC_THREADS), lds, st, p);
     return hipGetLastError();
 }
 

@@ -125,8 +125,9 @@ class HipBackend:
 
     def decode(self, model, payload, nbits, index, n):
         out = torch.empty(max(n, 1), dtype=torch.uint8, device=payload.device)
-        ws = torch.empty(256, dtype=torch.uint8, device=payload.device)
+        wsb = int(self.lib.mh_dev_decode_workspace(nbits, n, self.chunk))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=payload.device)
         self._check(self.lib.mh_dev_decode(model.handle, payload.data_ptr(), nbits, out.data_ptr(), n, index.data_ptr(),
-                                           self.chunk, ws.data_ptr(), 256, self._stream()), "mh_dev_decode")
+                                           self.chunk, ws.data_ptr(), wsb, self._stream()), "mh_dev_decode")
         self._check(self.lib.mh_dev_status(ws.data_ptr(), self._stream()), "decode status")
         return out[:n]

@@ -196,6 +196,35 @@ def test_encode_multi_round_tiles(mhc, oracle):
     assert m.decompress(blob, index=idx, chunk_symbols=256, n_symbols=len(data)) == data
 
 
+def test_decode_codes_longer_than_both_table_levels(mhc, oracle):
+    """Codes of more than P + h = 16 bits are not resolved by the decode tables.  With enough chunks for
+    the K-stream hot loop (which carries no tree walk) such chunks go through the redo pass; here a
+    third of the chunks contain one."""
+    train = _skewed(1 << 21, 11)
+    table = oracle.Model.from_data(train, 0).table_bytes()
+    o = oracle.Model.from_table(table)
+    m = mhc.Model.from_table(table)
+    lens, _ = o.codes()
+    rare = [s for s in range(256) if lens[s] > 17]
+    assert rare
+    data = bytearray(_skewed(1 << 20, 5))
+    data = bytearray(bytes(b if lens[b] else 0 for b in data))  # only symbols the table knows
+    rng = np.random.default_rng(8)
+    for pos in rng.integers(0, len(data), 1500):
+        data[pos] = rare[pos % len(rare)]
+    data = bytes(data)
+    blob, nbits, idx = m.compress(data, chunk_symbols=256)
+    ref, ref_bits = o.compress(data)
+    assert (nbits, blob) == (ref_bits, ref)
+    assert m.decompress(blob, index=idx, chunk_symbols=256, n_symbols=len(data)) == data
+    assert m.decompress(blob) == data                           # index rebuilt on the device
+    # order 1, model of the data itself: the rare pairs carry the long codes
+    m1 = mhc.Model.from_data(data, 1)
+    blob1, _, idx1 = m1.compress(data, chunk_symbols=256)
+    assert blob1 == oracle.Model.from_data(data, 1).compress(data)[0]
+    assert m1.decompress(blob1, index=idx1, chunk_symbols=256, n_symbols=len(data)) == data
+
+
 # ------------------------------------------------------------------ decode
 
 @pytest.mark.parametrize("name", golden_names())

@@ -21,6 +21,8 @@ a = ap.parse_args()
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
 mhc = entry.load_package()
+if bench.CHUNK == 0:
+    bench.CHUNK = 1024 if a.size >= (2 << 30) else 256
 data = bench.generate(a.kind, a.size, 2, 0, dev)
 codec = bench.Codec(mhc, a.size, dev)
 for _ in range(a.reps):
