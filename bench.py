@@ -185,6 +185,8 @@ def main():
     ap.add_argument("--kind", default="zipf", choices=["zipf", "uniform", "text"])
     ap.add_argument("--cpu-sample", type=int, default=256 << 20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo (collectives staged through host memory) is only for rehearsing the N>1 path on one GPU")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -192,10 +194,32 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node N" % (args.gpus, world))
+    if "MH_BENCH_DEVICE" in os.environ:          # rehearsal: several ranks on one card
+        local = int(os.environ["MH_BENCH_DEVICE"])
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
+    staged = world > 1 and args.backend == "gloo"
+
+    def all_reduce(t, op=dist.ReduceOp.SUM):
+        if staged:
+            c = t.cpu()
+            dist.all_reduce(c, op=op)
+            t.copy_(c)
+        else:
+            dist.all_reduce(t, op=op)
+
+    def all_gather(out, t):
+        if staged:
+            co, ct = out.cpu(), t.cpu()
+            dist.all_gather_into_tensor(co, ct)
+            out.copy_(co)
+        else:
+            dist.all_gather_into_tensor(out, t)
 
     mhc = entry.load_package()
     mhc.lib()                      # fails loudly if libmhc.so is missing: there is no fallback path
@@ -210,7 +234,7 @@ def main():
     prev0 = 0x20
     if world > 1:
         last = torch.zeros(world, dtype=torch.uint8, device=device)
-        dist.all_gather_into_tensor(last, data[-1:].clone())
+        all_gather(last, data[-1:].clone())
         if rank > 0:
             prev0 = int(last[rank - 1].item())
     codec = Codec(mhc, n, device)
@@ -228,7 +252,7 @@ def main():
         codec.histogram(data, prev0)
         e[1].record()
         if world > 1:
-            dist.all_reduce(codec.counts)             # the one collective: 512 KiB sum over xGMI
+            all_reduce(codec.counts)                  # the one collective: 512 KiB sum over xGMI
         e[2].record()
         model = codec.build_model()                   # syncs the stream once (small D2H of the counts)
         e[3].record()
@@ -236,7 +260,7 @@ def main():
         e[4].record()
         nbits = int(codec.nbits[0].item())            # payload length feeds the decoder's bounds
         if world > 1:
-            dist.all_gather_into_tensor(all_bits, codec.nbits[:1])   # shard bit lengths for placement
+            all_gather(all_bits, codec.nbits[:1])     # shard bit lengths for placement
         codec.decode(model, nbits)
         e[5].record()
         torch.cuda.synchronize()
@@ -258,7 +282,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # ---- correctness of what was timed (outside the timed region)
@@ -267,7 +291,7 @@ def main():
     round_trip = bool(rc == 0 and rc2 == 0 and torch.equal(codec.decoded, data))
     ok = torch.tensor([1 if round_trip else 0], device=device)
     if world > 1:
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        all_reduce(ok, op=dist.ReduceOp.MIN)
     round_trip_all = bool(ok.item())
 
     if rank == 0:
