@@ -1322,13 +1322,14 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
     hipError_t e = hipMemsetAsync(d_ws, 0, 64 + 16, st);
     if (e != hipSuccess || p.nchunks == 0) return e;
     // instantiations: <SEC_LDS, SPR, DIRECT, K, GW, OUTB, PC, HC>
-    // tables in LDS -> wide (2 streams, 64-byte granules and store bursts) or light (4 streams); L2 gathers -> light
+    // tables in LDS -> wide (2 streams, 64-byte granules and store bursts) or light (4 streams, 32-byte
+    // granules and store bursts: 16-byte stores reach HBM as 32-byte writes, measured -14 %); L2 gathers -> light
     void (*k_lds2[2])(DecParams) = {decode_kernel<true, 2, false, 2, 16, 4, 0, 0>, decode_kernel<true, 2, false, 2, 16, 4, 8, 0>};
-    void (*k_lds2_light[2])(DecParams) = {decode_kernel<true, 2, false, 4, 8, 1, 0, 0>, decode_kernel<true, 2, false, 4, 8, 1, 8, 0>};
+    void (*k_lds2_light[2])(DecParams) = {decode_kernel<true, 2, false, 4, 8, 2, 0, 0>, decode_kernel<true, 2, false, 4, 8, 2, 8, 0>};
     auto k_lds4 = decode_kernel<true, 4, false, 2, 16, 4, 8, 0>;
-    auto k_lds4_light = decode_kernel<true, 4, false, 4, 8, 1, 8, 0>;
-    auto k_l2 = decode_kernel<false, 2, false, 4, 8, 1, 8, 0>;
-    void (*k_l2d[2])(DecParams) = {decode_kernel<false, 2, true, 4, 8, 1, 8, 0>, decode_kernel<false, 2, true, 4, 8, 1, 8, 8>};
+    auto k_lds4_light = decode_kernel<true, 4, false, 4, 8, 2, 8, 0>;
+    auto k_l2 = decode_kernel<false, 2, false, 4, 8, 2, 8, 0>;
+    void (*k_l2d[2])(DecParams) = {decode_kernel<false, 2, true, 4, 8, 2, 8, 0>, decode_kernel<false, 2, true, 4, 8, 2, 8, 8>};
     // redo pass (one lane per handed-over chunk, runtime table widths)
     auto r_lds = decode_kernel<true, 2, false, 1, 8, 1, 0, 0, true>;
     auto r_l2 = decode_kernel<false, 2, false, 1, 8, 1, 0, 0, true>;
