@@ -124,10 +124,17 @@ class Codec:
     def build_model(self):
         return self.mhc.Model.from_device_counts(self.counts.data_ptr(), 1, self.stream())
 
-    def encode(self, model, data, prev0):
-        self.check(self.lib.mh_dev_encode(model.handle, data.data_ptr(), self.n, prev0, self.payload.data_ptr(), self.cap,
-                                          self.nbits.data_ptr(), self.index.data_ptr(), CHUNK, self.enc_ws.data_ptr(),
-                                          self.enc_ws_bytes, self.stream()), "encode")
+    def payload_bits(self, model, counts, out):
+        self.check(self.lib.mh_dev_payload_bits(model.handle, counts.data_ptr(), out.data_ptr(), self.stream()), "payload_bits")
+
+    def encode(self, model, data, prev0, start_bit=None):
+        """start_bit: device int64 tensor holding this shard's global start bit (the payload is emitted
+        pre-shifted by its low 3 bits so that shards concatenate with one OR-merged seam byte), or None."""
+        self.check(self.lib.mh_dev_encode_at(model.handle, data.data_ptr(), self.n, prev0,
+                                             start_bit.data_ptr() if start_bit is not None else None,
+                                             self.payload.data_ptr(), self.cap,
+                                             self.nbits.data_ptr(), self.index.data_ptr(), CHUNK, self.enc_ws.data_ptr(),
+                                             self.enc_ws_bytes, self.stream()), "encode")
 
     def decode(self, model, nbits):
         self.check(self.lib.mh_dev_decode(model.handle, self.payload.data_ptr(), nbits, self.decoded.data_ptr(), self.n,
@@ -239,6 +246,9 @@ def main():
             prev0 = int(last[rank - 1].item())
     codec = Codec(mhc, n, device)
     all_bits = torch.zeros(world, dtype=torch.int64, device=device)
+    my_bits = torch.zeros(1, dtype=torch.int64, device=device)
+    start_bit = torch.zeros(1, dtype=torch.int64, device=device)
+    local_counts = torch.zeros(65536, dtype=torch.int64, device=device)
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
     stage_ms = {"hist": 0.0, "allreduce": 0.0, "tree": 0.0, "encode": 0.0, "decode": 0.0}
@@ -252,15 +262,22 @@ def main():
         codec.histogram(data, prev0)
         e[1].record()
         if world > 1:
+            local_counts.copy_(codec.counts)          # the shard's own histogram fixes its payload length
             all_reduce(codec.counts)                  # the one collective: 512 KiB sum over xGMI
         e[2].record()
         model = codec.build_model()                   # syncs the stream once (small D2H of the counts)
         e[3].record()
-        codec.encode(model, data, prev0)
-        e[4].record()
-        nbits = int(codec.nbits[0].item())            # payload length feeds the decoder's bounds
         if world > 1:
-            all_gather(all_bits, codec.nbits[:1])     # shard bit lengths for placement
+            # placement before encoding: shard bits = local histogram . code lengths, all-gather,
+            # exclusive sum -> global start bit; the shard is emitted pre-shifted by start % 8
+            codec.payload_bits(model, local_counts, my_bits)
+            all_gather(all_bits, my_bits)
+            torch.sum(all_bits[:rank], dim=0, keepdim=True, out=start_bit)
+            codec.encode(model, data, prev0, start_bit)
+        else:
+            codec.encode(model, data, prev0)
+        e[4].record()
+        nbits = int(codec.nbits[0].item())            # end position in the rank's buffer: the decoder's bound
         codec.decode(model, nbits)
         e[5].record()
         torch.cuda.synchronize()
@@ -289,6 +306,8 @@ def main():
     rc = codec.lib.mh_dev_status(codec.enc_ws.data_ptr(), codec.stream())
     rc2 = codec.lib.mh_dev_status(codec.dec_ws.data_ptr(), codec.stream())
     round_trip = bool(rc == 0 and rc2 == 0 and torch.equal(codec.decoded, data))
+    if world > 1:     # the shard ended where its histogram said it would: the ranks' payloads tile the global stream
+        round_trip = round_trip and int(codec.nbits[0].item()) == (int(start_bit.item()) & 7) + int(my_bits.item())
     ok = torch.tensor([1 if round_trip else 0], device=device)
     if world > 1:
         all_reduce(ok, op=dist.ReduceOp.MIN)

@@ -185,6 +185,23 @@ int mh_dev_encode(const mh_model *m, const uint8_t *d_data, size_t n, uint8_t pr
                   uint64_t *d_index, uint32_t chunk_symbols,
                   void *d_ws, size_t ws_bytes, void *stream);
 
+/* Sharded encode (contiguous byte ranges, one rank per shard).  A shard's payload length
+ * is known before it is encoded: it is the dot product of the shard's LOCAL histogram with the code
+ * lengths of the (global) model.  d_counts: 65536 (order 1) or 256 (order 0) uint64 counts on the
+ * device; *d_nbits receives the bits. */
+int mh_dev_payload_bits(const mh_model *m, const uint64_t *d_counts, uint64_t *d_nbits, void *stream);
+/* mh_dev_encode with the payload emitted pre-shifted: *d_start_bit (device memory, may be NULL = 0) is
+ * the global bit position at which this shard starts; its first code is written at bit
+ * (*d_start_bit & 7) of d_payload[0], the bits before it are zero, so consecutive shards concatenate at
+ * byte offset start_bit / 8 with ONE OR-merged seam byte.  *d_nbits = (*d_start_bit & 7) + payload bits,
+ * i.e. the end position inside d_payload; index entries are positions inside d_payload as well, so the
+ * shard decodes from its own buffer with mh_dev_decode(nbits = *d_nbits). */
+int mh_dev_encode_at(const mh_model *m, const uint8_t *d_data, size_t n, uint8_t prev0,
+                     const uint64_t *d_start_bit,
+                     uint8_t *d_payload, size_t cap, uint64_t *d_nbits,
+                     uint64_t *d_index, uint32_t chunk_symbols,
+                     void *d_ws, size_t ws_bytes, void *stream);
+
 /* 64-byte status block + one uint32 per chunk (list of the chunks whose codes exceed the decode
  * tables and are decoded by a second launch); 0 for an invalid chunk size. */
 size_t mh_dev_decode_workspace(uint64_t nbits, uint64_t n_symbols, uint32_t chunk_symbols);

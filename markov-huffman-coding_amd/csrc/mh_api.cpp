@@ -434,6 +434,20 @@ size_t mh_dev_encode_workspace(size_t n) { return mhk::encode_workspace_bytes(n)
 
 int mh_dev_encode(const mh_model *m, const uint8_t *d_data, size_t n, uint8_t prev0, uint8_t *d_payload, size_t cap,
                   uint64_t *d_nbits, uint64_t *d_index, uint32_t chunk_symbols, void *d_ws, size_t ws_bytes, void *stream) {
+    return mh_dev_encode_at(m, d_data, n, prev0, nullptr, d_payload, cap, d_nbits, d_index, chunk_symbols, d_ws, ws_bytes, stream);
+}
+
+int mh_dev_payload_bits(const mh_model *m, const uint64_t *d_counts, uint64_t *d_nbits, void *stream) {
+    if (!m || !d_counts || !d_nbits) return MH_ERR_ARG;
+    if (!m->d_len8) return MH_ERR_NO_DEVICE;
+    HIP_TRY(mhk::launch_payload_bits(reinterpret_cast<const unsigned long long *>(d_counts), m->d_len8, m->type ? 65536u : 256u,
+                                     reinterpret_cast<unsigned long long *>(d_nbits), static_cast<hipStream_t>(stream)));
+    return MH_OK;
+}
+
+int mh_dev_encode_at(const mh_model *m, const uint8_t *d_data, size_t n, uint8_t prev0, const uint64_t *d_start_bit,
+                     uint8_t *d_payload, size_t cap, uint64_t *d_nbits, uint64_t *d_index, uint32_t chunk_symbols,
+                     void *d_ws, size_t ws_bytes, void *stream) {
     if (!m || (!d_data && n) || !d_payload || !d_nbits || !d_ws) return MH_ERR_ARG;
     if (!aligned16(d_data) || !aligned16(d_payload) || !aligned16(d_ws)) return MH_ERR_ARG;
     int shift = chunk_shift_of(d_index ? chunk_symbols : MH_CHUNK_DEFAULT);
@@ -447,6 +461,7 @@ int mh_dev_encode(const mh_model *m, const uint8_t *d_data, size_t n, uint8_t pr
     p.enc16 = m->d_enc16; p.len_slot = m->d_len_slot; p.len8 = m->d_len8; p.code64 = m->d_code64;
     p.nbits = reinterpret_cast<unsigned long long *>(d_nbits);
     p.index = reinterpret_cast<unsigned long long *>(d_index);
+    p.start_bit = reinterpret_cast<const unsigned long long *>(d_start_bit);
     HIP_TRY(mhk::launch_encode(p, d_ws, static_cast<hipStream_t>(stream)));
     return MH_OK;
 }

@@ -24,6 +24,7 @@ struct EncodeArgs {
     const uint64_t *code64;       // 65536, prev*256+sym
     unsigned long long *nbits;    // out: payload bits
     unsigned long long *index;    // out: chunk index or nullptr
+    const unsigned long long *start_bit;   // device: global bit position of this payload (low 3 bits used) or nullptr
 };
 
 struct LenParams {
@@ -130,6 +131,8 @@ hipError_t launch_hist_o1(const uint8_t *d_data, uint64_t n, uint32_t prev0, uns
 hipError_t launch_hist_o0(const uint8_t *d_data, uint64_t n, unsigned long long *d_counts, hipStream_t st);
 size_t encode_workspace_bytes(uint64_t n);
 hipError_t launch_encode(const EncodeArgs &a, void *d_ws, hipStream_t st);
+hipError_t launch_payload_bits(const unsigned long long *d_counts, const uint8_t *d_len8, uint32_t entries, unsigned long long *d_out,
+                               hipStream_t st);
 hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st);
 size_t build_index_workspace_bytes(uint64_t nbits);
 hipError_t launch_build_index(IdxParams p, void *d_ws, hipStream_t st);

@@ -363,9 +363,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_local_kernel(const uint32_t
 }
 
 // one block: exclusive scan of the block totals in place; writes the grand total after the last entry
-__global__ __launch_bounds__(SCAN_THREADS) void scan_top_kernel(unsigned long long *blk_sum, uint64_t nblk) {
+// carry0: device pointer to the global bit position this payload starts at (only its low 3 bits are
+// used: the payload is emitted pre-shifted so that shards concatenate with one OR-merged seam byte), or
+// nullptr.
+__global__ __launch_bounds__(SCAN_THREADS) void scan_top_kernel(unsigned long long *blk_sum, uint64_t nblk,
+                                                                const unsigned long long *carry0) {
     __shared__ uint64_t lds[SCAN_THREADS / 64];
-    uint64_t carry = 0;
+    uint64_t carry = carry0 ? (*carry0 & 7ull) : 0;
     for (uint64_t base = 0; base < nblk; base += SCAN_THREADS) {
         uint64_t i = base + threadIdx.x;
         uint64_t v = i < nblk ? blk_sum[i] : 0;
@@ -1282,13 +1286,44 @@ static EncWs enc_ws_layout(uint64_t n) {
 }
 size_t encode_workspace_bytes(uint64_t n) { return enc_ws_layout(n).total; }
 
+__global__ void empty_payload_kernel(const unsigned long long *start_bit, unsigned long long *nbits, uint8_t *out, uint64_t cap) {
+    const unsigned long long b0 = start_bit ? (*start_bit & 7ull) : 0;
+    *nbits = b0;
+    if (b0 && cap) out[0] = 0;
+}
+
+// sum over the histogram of count x code length = the payload bits this model produces for data with
+// that histogram (a shard's LOCAL histogram: its start offset is known before it is encoded)
+__global__ __launch_bounds__(256) void payload_bits_kernel(const unsigned long long *counts, const uint8_t *len8, uint32_t entries,
+                                                           unsigned long long *out) {
+    __shared__ unsigned long long part[256];
+    unsigned long long acc = 0;
+    for (uint32_t i = threadIdx.x; i < entries; i += 256) acc += counts[i] * len8[i];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if (int(threadIdx.x) < d) part[threadIdx.x] += part[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = part[0];
+}
+
+hipError_t launch_payload_bits(const unsigned long long *d_counts, const uint8_t *d_len8, uint32_t entries, unsigned long long *d_out,
+                               hipStream_t st) {
+    hipLaunchKernelGGL(payload_bits_kernel, dim3(1), dim3(256), 0, st, d_counts, d_len8, entries, d_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_encode(const EncodeArgs &a, void *d_ws, hipStream_t st) {
     unsigned char *ws = static_cast<unsigned char *>(d_ws);
     const EncWs L = enc_ws_layout(a.n);
     int *status = reinterpret_cast<int *>(ws);
     hipError_t e = hipMemsetAsync(ws, 0, 64, st);
     if (e != hipSuccess) return e;
-    if (a.n == 0) return hipMemsetAsync(a.nbits, 0, 8, st);
+    if (a.n == 0) {                                          // nothing to emit: the payload "ends" at its start offset
+        hipLaunchKernelGGL(empty_payload_kernel, dim3(1), dim3(1), 0, st, a.start_bit, a.nbits, a.out, a.cap);
+        return hipGetLastError();
+    }
     static bool once = false;
     if (!once) {
         e = allow_lds(reinterpret_cast<const void *>(enc_len_kernel), LEN_LDS_BYTES); if (e != hipSuccess) return e;
@@ -1305,7 +1340,7 @@ hipError_t launch_encode(const EncodeArgs &a, void *d_ws, hipStream_t st) {
     hipLaunchKernelGGL(enc_len_kernel, dim3(grid), dim3(E_THREADS), LEN_LDS_BYTES, st, lp);
 
     hipLaunchKernelGGL(scan_local_kernel, dim3(unsigned(L.nblk)), dim3(SCAN_THREADS), 0, st, wt_bits, L.nwt, wt_start, blk_sum);
-    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, blk_sum, L.nblk);
+    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, blk_sum, L.nblk, a.start_bit);
     // the emit pass stores whole dwords: only the 4-byte-aligned part of the buffer counts as capacity
     ScanParams sp{wt_start, blk_sum, L.nwt, L.nblk, a.out, a.cap & ~uint64_t(3), a.nbits, status};
     hipLaunchKernelGGL(scan_apply_kernel, dim3(unsigned(L.nblk)), dim3(SCAN_THREADS), 0, st, sp);
@@ -1425,7 +1460,7 @@ hipError_t launch_build_index(IdxParams p, void *d_ws, hipStream_t st) {
     }
     unsigned long long *blk_sum = reinterpret_cast<unsigned long long *>(ws + L.off_blk);
     hipLaunchKernelGGL(scan_local_kernel, dim3(unsigned(L.nblk)), dim3(SCAN_THREADS), 0, st, p.seg_count, L.nseg, p.seg_sym_start, blk_sum);
-    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, blk_sum, L.nblk);
+    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, blk_sum, L.nblk, static_cast<const unsigned long long *>(nullptr));
     hipLaunchKernelGGL(index_scan_add_kernel, dim3(unsigned(L.nblk)), dim3(SCAN_THREADS), 0, st, p.seg_sym_start, blk_sum, L.nseg, L.nblk, p.n_symbols);
     hipLaunchKernelGGL(index_fill_kernel, dim3(grid), dim3(256), 0, st, p);
     return hipGetLastError();

@@ -3,7 +3,10 @@
 The data path has exactly one exchange step: a sum-all-reduce of the 65 536-entry
 conditional histogram (512 KiB of uint64, RCCL over xGMI on the GPU box), after which every rank
 builds the identical model deterministically (integer-only tree build, no broadcast).  A second tiny
-collective — an all-gather of one uint64 per rank — gives each shard payload's global bit offset.
+collective — an all-gather of one uint64 per rank — gives each shard payload's global bit offset
+BEFORE the shard is encoded (a shard's payload length is its local histogram dotted with the model's
+code lengths), so every rank emits its payload pre-shifted by (start bit mod 8) and the shards
+concatenate at byte offset start // 8 with one OR-merged seam byte (`stitch`).
 
 This module holds only the orchestration.  The per-shard compute comes from a `backend`:
 `HipBackend` (below) drives libmhc.so on the rank's GPU and is the only backend the product ships;
@@ -68,16 +71,32 @@ def global_bit_offsets(local_nbits, group=None):
 
 def compress_shard(backend, shard, last_byte, group=None):
     """One rank's part of a sharded compress.  Returns dict(model, payload, nbits, index, prev0,
-    start_bit, total_bits)."""
+    start_bit, total_bits): `payload` holds the shard's codes from bit (start_bit % 8) of its first
+    byte on (zero bits before), `nbits` counts the shard's own payload bits."""
     n = backend.length(shard)
     prev0 = exchange_prev0(last_byte, n > 0, group)
-    counts = backend.histogram(shard, prev0)
-    merged_histogram(counts, group)
-    model = backend.build_model(counts)
-    payload, nbits, index = backend.encode(model, shard, prev0)
+    local = backend.histogram(shard, prev0)
+    merged = merged_histogram(local.clone(), group)
+    model = backend.build_model(merged)
+    nbits = backend.payload_bits(model, local)               # known before encoding: placement first
     start, total, _ = global_bit_offsets(nbits, group)
+    payload, end_bits, index = backend.encode(model, shard, prev0, start)
+    if end_bits != (start & 7) + nbits:
+        raise RuntimeError("shard payload is %d bits, its histogram predicted %d" % (end_bits - (start & 7), nbits))
     return {"model": model, "payload": payload, "nbits": nbits, "index": index, "prev0": prev0,
             "start_bit": start, "total_bits": total}
+
+
+def stitch(parts, total_bits):
+    """parts: iterable of (start_bit, payload bytes as produced by compress_shard).  Returns the single
+    stream's payload: every shard is OR-ed in at byte start_bit // 8 (its leading start_bit % 8 bits
+    are zero, so the seam byte it shares with its predecessor merges without shifting anything)."""
+    out = bytearray((total_bits + 7) // 8)
+    for start, payload in parts:
+        off = start // 8
+        for i, b in enumerate(bytes(payload)):
+            out[off + i] |= b
+    return bytes(out)
 
 
 class HipBackend:
@@ -108,17 +127,24 @@ class HipBackend:
     def build_model(self, counts):
         return self.mhc.Model.from_device_counts(counts.data_ptr(), 1, self._stream())
 
-    def encode(self, model, shard, prev0):
+    def payload_bits(self, model, counts):
+        out = torch.zeros(1, dtype=torch.int64, device=counts.device)
+        self._check(self.lib.mh_dev_payload_bits(model.handle, counts.data_ptr(), out.data_ptr(), self._stream()),
+                    "mh_dev_payload_bits")
+        return int(out.item())
+
+    def encode(self, model, shard, prev0, start_bit=0):
         n = shard.numel()
-        cap = self.lib.mh_encode_bound(model.handle, n)
+        cap = self.lib.mh_encode_bound(model.handle, n) + 16
         payload = torch.empty(cap, dtype=torch.uint8, device=shard.device)
         nbits = torch.zeros(1, dtype=torch.int64, device=shard.device)
+        start = torch.tensor([int(start_bit)], dtype=torch.int64, device=shard.device)
         index = torch.empty(max((n + self.chunk - 1) // self.chunk, 1), dtype=torch.int64, device=shard.device)
         wsb = self.lib.mh_dev_encode_workspace(n)
         ws = torch.empty(wsb + 64, dtype=torch.uint8, device=shard.device)
-        self._check(self.lib.mh_dev_encode(model.handle, shard.data_ptr(), n, prev0, payload.data_ptr(), cap,
-                                           nbits.data_ptr(), index.data_ptr(), self.chunk, ws.data_ptr(), wsb,
-                                           self._stream()), "mh_dev_encode")
+        self._check(self.lib.mh_dev_encode_at(model.handle, shard.data_ptr(), n, prev0, start.data_ptr(), payload.data_ptr(), cap,
+                                              nbits.data_ptr(), index.data_ptr(), self.chunk, ws.data_ptr(), wsb,
+                                              self._stream()), "mh_dev_encode_at")
         self._check(self.lib.mh_dev_status(ws.data_ptr(), self._stream()), "encode status")
         nb = int(nbits.item())
         return payload[:(nb + 7) // 8], nb, index[:(n + self.chunk - 1) // self.chunk]

@@ -225,6 +225,69 @@ def test_decode_codes_longer_than_both_table_levels(mhc, oracle):
     assert m1.decompress(blob1, index=idx1, chunk_symbols=256, n_symbols=len(data)) == data
 
 
+@pytest.mark.parametrize("cuts", [(0.5,), (0.31, 0.7), (0.0, 0.5, 0.5)])
+def test_sharded_encode_preshifted_shards_or_into_the_reference_stream(mhc, oracle, cuts):
+    """SURVEY.md 8e on one card: contiguous shards, local histograms summed, each shard's start bit known
+    from its local histogram BEFORE it is encoded, payload emitted pre-shifted (mh_dev_encode_at).  The
+    shards OR together into exactly the stream the reference writes for the whole input, and every
+    shard decodes from its own buffer."""
+    import ctypes as C
+    lib = mhc.lib()
+    data = zipf_bytes(300000 + 7, 21)
+    n = len(data)
+    bounds = [0] + [min(n, int(n * c) // 16 * 16) for c in cuts] + [n]
+    shards = [(bounds[i], bounds[i + 1]) for i in range(len(bounds) - 1)]
+    d_data = mhc.DeviceBuffer(n + 16, init=np.frombuffer(data + bytes(16), dtype=np.uint8))
+    base = d_data.ptr.value
+    local = []
+    for lo, hi in shards:
+        prev0 = data[lo - 1] if lo else 0x20
+        d_counts = mhc.DeviceBuffer(65536 * 8, init=np.zeros(65536, dtype=np.uint64))
+        mhc._check(lib.mh_dev_histogram_o1(C.c_void_p(base + lo), hi - lo, prev0, d_counts.ptr, None, 0, None), "hist")
+        local.append(d_counts)
+    total_counts = sum(c.download(np.uint64) for c in local)
+    assert np.array_equal(total_counts, oracle.histogram_o1(data, 0x20))
+    m = mhc.Model.from_counts(total_counts, 1)
+    whole = oracle.Model.from_data(data, 1)
+    ref_blob, ref_bits = whole.compress(data)
+    start = 0
+    parts = []
+    for (lo, hi), d_counts in zip(shards, local):
+        d_bits = mhc.DeviceBuffer(8, init=np.zeros(1, dtype=np.uint64))
+        mhc._check(lib.mh_dev_payload_bits(m.handle, d_counts.ptr, d_bits.ptr, None), "payload_bits")
+        my_bits = int(d_bits.download(np.uint64)[0])
+        ns = hi - lo
+        cap = lib.mh_encode_bound(m.handle, ns) + 16
+        d_payload = mhc.DeviceBuffer(cap, init=np.full(cap, 0xEE, dtype=np.uint8))
+        d_start = mhc.DeviceBuffer(8, init=np.array([start], dtype=np.uint64))
+        d_nbits = mhc.DeviceBuffer(8, init=np.zeros(1, dtype=np.uint64))
+        nidx = max((ns + 255) // 256, 1)
+        d_index = mhc.DeviceBuffer(nidx * 8, init=np.zeros(nidx, dtype=np.uint64))
+        wsb = lib.mh_dev_encode_workspace(ns)
+        d_ws = mhc.DeviceBuffer(wsb + 64)
+        prev0 = data[lo - 1] if lo else 0x20
+        mhc._check(lib.mh_dev_encode_at(m.handle, C.c_void_p(base + lo), ns, prev0, d_start.ptr, d_payload.ptr, cap,
+                                        d_nbits.ptr, d_index.ptr, 256, d_ws.ptr, wsb, None), "encode_at")
+        mhc._check(lib.mh_dev_status(d_ws.ptr, None), "status")
+        end = int(d_nbits.download(np.uint64)[0])
+        assert end == (start & 7) + my_bits                       # the histogram predicted the length
+        payload = d_payload.download()[:(end + 7) // 8].tobytes()
+        if start & 7 and payload:
+            assert payload[0] >> (8 - (start & 7)) == 0           # room for the predecessor's tail bits
+        parts.append((start, payload))
+        if ns:                                                     # the shard decodes from its own buffer
+            idx = d_index.download(np.uint64)[:(ns + 255) // 256]
+            assert int(idx[0]) == (prev0 << 56) | (start & 7)
+            assert m.decode(payload, end, prev0, index=idx, chunk_symbols=256, n_symbols=ns) == data[lo:hi]
+        start += my_bits
+    assert start == ref_bits
+    out = bytearray((ref_bits + 7) // 8)
+    for s0, payload in parts:
+        for i, b in enumerate(payload):
+            out[s0 // 8 + i] |= b
+    assert bytes(out) == ref_blob[1:]
+
+
 # ------------------------------------------------------------------ decode
 
 @pytest.mark.parametrize("name", golden_names())

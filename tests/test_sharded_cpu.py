@@ -32,7 +32,11 @@ class OracleBackend:
     def build_model(self, counts):
         return self.o.Model.from_counts(counts.numpy().astype(np.uint64), 1)
 
-    def encode(self, model, shard, prev0):
+    def payload_bits(self, model, counts):
+        lens, _ = model.codes()
+        return int((counts.numpy().astype(np.int64) * np.asarray(lens, dtype=np.int64)).sum())
+
+    def encode(self, model, shard, prev0, start_bit=0):
         # the oracle's compress starts at context ' '; emulate an arbitrary first context by
         # prepending that byte and dropping its code afterwards
         lens, _ = model.codes()
@@ -43,7 +47,9 @@ class OracleBackend:
             blob, nbits = model.compress(bytes([prev0]) + shard)
             skip = int(lens[0x20 * 256 + prev0])
             bits = np.unpackbits(np.frombuffer(blob[1:], dtype=np.uint8))[skip:nbits]
-        return bits, len(bits), None
+        lead = np.zeros(start_bit & 7, dtype=np.uint8)            # pre-shifted like mh_dev_encode_at
+        shifted = np.concatenate([lead, bits])
+        return np.packbits(shifted).tobytes(), len(shifted), None
 
 
 def _free_port():
@@ -70,7 +76,7 @@ def _worker(rank, world, port, data, q):
         shard = data[lo:hi]
         res = sharded.compress_shard(OracleBackend(mh_oracle), shard, shard[-1] if shard else 0)
         q.put((rank, lo, hi, res["prev0"], res["start_bit"], res["total_bits"], res["nbits"],
-               res["model"].table_bytes(), np.packbits(res["payload"]).tobytes()))
+               res["model"].table_bytes(), res["payload"]))
     finally:
         dist.destroy_process_group()
 
@@ -99,16 +105,22 @@ def test_sharded_compress_equals_whole_stream(oracle, world, n):
     ref_blob, ref_bits = whole.compress(data)
     ref_bitarr = np.unpackbits(np.frombuffer(ref_blob[1:], dtype=np.uint8))[:ref_bits]
     pos = 0
-    cat = []
+    parts = []
     for rank, lo, hi, prev0, start, total, nbits, table, packed in res:
         assert table == whole.table_bytes()                      # identical model on every rank
         assert prev0 == (0x20 if lo == 0 or n == 0 else data[lo - 1]) or lo == hi
-        assert start == pos and total == ref_bits                # all-gathered placement
-        cat.append(np.unpackbits(np.frombuffer(packed, dtype=np.uint8))[:nbits])
+        assert start == pos and total == ref_bits                # placement known before encoding
+        assert len(packed) == ((start & 7) + nbits + 7) // 8
+        parts.append((start, packed))
         pos += nbits
-    got = np.concatenate(cat) if cat else np.zeros(0, dtype=np.uint8)
     assert pos == ref_bits
-    assert np.array_equal(got, ref_bitarr)                       # shards concatenate to THE stream
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as entry
+    entry.load_package()
+    import importlib
+    sharded = importlib.import_module("mhc_amd.sharded")
+    assert sharded.stitch(parts, ref_bits) == ref_blob[1:]       # pre-shifted shards OR together into THE stream
+    del ref_bitarr
     bounds = [(lo, hi) for _, lo, hi, *_ in res]
     assert bounds[0][0] == 0 and bounds[-1][1] == n
     assert all(a[1] == b[0] for a, b in zip(bounds, bounds[1:]))
