@@ -528,18 +528,42 @@ int mh_dev_status(const void *d_ws, void *stream) {
 
 /* ------------------------------------------------------- host-buffer calls */
 
+// Host-buffer calls stage their data through HBM in segments, so their device footprint is bounded
+// whatever the input size (a 16 GiB file does not need 16 GiB + its worst-case payload on the card).
+// MH_SEGMENT_BYTES overrides the 256 MiB default (tests use small values to put seams everywhere).
+// The segment size is a multiple of the largest chunk size, so chunk boundaries fall on segment
+// boundaries.
+static size_t segment_bytes() {
+    size_t s = size_t(256) << 20;
+    if (const char *e = getenv("MH_SEGMENT_BYTES")) {
+        const unsigned long long v = strtoull(e, nullptr, 10);
+        if (v) s = size_t(v);
+    }
+    s &= ~size_t(MH_CHUNK_MAX - 1);
+    return s < MH_CHUNK_MAX ? size_t(MH_CHUNK_MAX) : s;
+}
+
 static int histogram_host(const uint8_t *data, size_t n, uint8_t prev0, uint64_t *counts, int order) {
     if ((!data && n) || !counts) return MH_ERR_ARG;
     if (!have_device()) return MH_ERR_NO_DEVICE;
-    size_t nc = order ? 65536 : 256;
+    const size_t nc = order ? 65536 : 256;
+    const size_t seg = segment_bytes();
     DevBuf d_data, d_counts;
-    HIP_TRY(d_data.alloc(n));
+    HIP_TRY(d_data.alloc(n < seg ? n : seg));
     HIP_TRY(d_counts.alloc(nc * 8));
-    if (n) HIP_TRY(hipMemcpy(d_data.p, data, n, hipMemcpyHostToDevice));
-    int rc = order ? mh_dev_histogram_o1(d_data.as<uint8_t>(), n, prev0, d_counts.as<uint64_t>(), nullptr, 0, nullptr)
-                   : mh_dev_histogram_o0(d_data.as<uint8_t>(), n, d_counts.as<uint64_t>(), nullptr, 0, nullptr);
-    if (rc != MH_OK) return rc;
-    HIP_TRY(hipMemcpy(counts, d_counts.p, nc * 8, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> part(nc);
+    for (size_t i = 0; i < nc; ++i) counts[i] = 0;
+    for (size_t off = 0; off < n || off == 0; off += seg) {
+        const size_t len = n - off < seg ? n - off : seg;
+        if (len) HIP_TRY(hipMemcpy(d_data.p, data + off, len, hipMemcpyHostToDevice));
+        const uint8_t p0 = off ? data[off - 1] : prev0;            // context carried across the seam (src/main.cpp:32,36)
+        int rc = order ? mh_dev_histogram_o1(d_data.as<uint8_t>(), len, p0, d_counts.as<uint64_t>(), nullptr, 0, nullptr)
+                       : mh_dev_histogram_o0(d_data.as<uint8_t>(), len, d_counts.as<uint64_t>(), nullptr, 0, nullptr);
+        if (rc != MH_OK) return rc;
+        HIP_TRY(hipMemcpy(part.data(), d_counts.p, nc * 8, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < nc; ++i) counts[i] += part[i];
+        if (n == 0) break;
+    }
     return MH_OK;
 }
 
@@ -579,26 +603,58 @@ int mh_encode(const mh_model *m, const uint8_t *data, size_t n, uint8_t prev0, u
     if (!have_device()) return MH_ERR_NO_DEVICE;
     if (m->max_len > mh::MAX_CODE_BITS) return MH_ERR_CODE_TOO_LONG;
     hipStream_t st = nullptr;
-    size_t dcap = mh_encode_bound(m, n);
-    size_t nidx = index ? size_t(mh_index_entries(n, chunk_symbols)) : 0;
-    size_t wsb = mh_dev_encode_workspace(n);
-    DevBuf d_data, d_out, d_nbits, d_index, d_ws;
-    HIP_TRY(d_data.alloc(n));
+    // Segment by segment: each one is encoded pre-shifted to the bit where the previous one ended
+    // (mh_dev_encode_at), so its bytes drop into the output with one OR-merged seam byte.
+    const size_t seg = segment_bytes();
+    const size_t slen = n < seg ? n : seg;
+    const size_t dcap = mh_encode_bound(m, slen) + 16;
+    const size_t sidx = index ? size_t(mh_index_entries(slen, chunk_symbols)) : 0;
+    const size_t wsb = mh_dev_encode_workspace(slen);
+    DevBuf d_data, d_out, d_nbits, d_start, d_index, d_ws;
+    HIP_TRY(d_data.alloc(slen));
     HIP_TRY(d_out.alloc(dcap));
     HIP_TRY(d_nbits.alloc(8));
-    HIP_TRY(d_index.alloc(nidx * 8));
+    HIP_TRY(d_start.alloc(8));
+    HIP_TRY(d_index.alloc(sidx * 8));
     HIP_TRY(d_ws.alloc(wsb));
-    if (n) HIP_TRY(hipMemcpy(d_data.p, data, n, hipMemcpyHostToDevice));
-    int rc = mh_dev_encode(m, d_data.as<uint8_t>(), n, prev0, d_out.as<uint8_t>(), dcap, d_nbits.as<uint64_t>(),
-                           index ? d_index.as<uint64_t>() : nullptr, chunk_symbols, d_ws.p, wsb, st);
-    if (rc != MH_OK) return rc;
-    rc = mh_dev_status(d_ws.p, st);
-    if (rc != MH_OK) return rc;
-    HIP_TRY(hipMemcpy(nbits, d_nbits.p, 8, hipMemcpyDeviceToHost));
-    size_t nbytes = size_t((*nbits + 7) / 8);
-    if (nbytes > cap) return MH_ERR_CAPACITY;
-    if (nbytes) HIP_TRY(hipMemcpy(out_payload, d_out.p, nbytes, hipMemcpyDeviceToHost));
-    if (nidx) HIP_TRY(hipMemcpy(index, d_index.p, nidx * 8, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> seg_index(sidx);
+    uint64_t start = 0;                                          // global bit position of the next segment
+    for (size_t off = 0; off < n; off += seg) {
+        const size_t len = n - off < seg ? n - off : seg;
+        HIP_TRY(hipMemcpy(d_data.p, data + off, len, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_start.p, &start, 8, hipMemcpyHostToDevice));
+        const uint8_t p0 = off ? data[off - 1] : prev0;
+        int rc = mh_dev_encode_at(m, d_data.as<uint8_t>(), len, p0, d_start.as<uint64_t>(), d_out.as<uint8_t>(), dcap,
+                                  d_nbits.as<uint64_t>(), index ? d_index.as<uint64_t>() : nullptr, chunk_symbols, d_ws.p, wsb, st);
+        if (rc != MH_OK) return rc;
+        rc = mh_dev_status(d_ws.p, st);
+        if (rc != MH_OK) return rc;
+        uint64_t end = 0;                                        // end position inside the segment's buffer
+        HIP_TRY(hipMemcpy(&end, d_nbits.p, 8, hipMemcpyDeviceToHost));
+        const uint64_t lead = start & 7u;
+        const size_t obyte = size_t(start >> 3);                 // output byte the segment's buffer starts at
+        const size_t nbytes = size_t((end + 7) / 8);
+        if (obyte + nbytes > cap) return MH_ERR_CAPACITY;
+        if (nbytes) {
+            size_t skip = 0;
+            if (lead) {                                          // seam byte shared with the previous segment
+                uint8_t first = 0;
+                HIP_TRY(hipMemcpy(&first, d_out.p, 1, hipMemcpyDeviceToHost));
+                out_payload[obyte] |= first;
+                skip = 1;
+            }
+            if (nbytes > skip)
+                HIP_TRY(hipMemcpy(out_payload + obyte + skip, d_out.as<uint8_t>() + skip, nbytes - skip, hipMemcpyDeviceToHost));
+        }
+        if (index) {
+            const size_t ne = size_t(mh_index_entries(len, chunk_symbols));
+            HIP_TRY(hipMemcpy(seg_index.data(), d_index.p, ne * 8, hipMemcpyDeviceToHost));
+            uint64_t *dst = index + off / chunk_symbols;         // seg is a multiple of every chunk size
+            for (size_t i = 0; i < ne; ++i) dst[i] = seg_index[i] + uint64_t(obyte) * 8;   // buffer position -> stream position
+        }
+        start += end - lead;
+    }
+    *nbits = start;
     return MH_OK;
 }
 
@@ -610,19 +666,64 @@ int mh_decode(const mh_model *m, const uint8_t *payload, uint64_t nbits, uint8_t
     if (chunk_shift_of(chunk_symbols) < 0) return MH_ERR_ARG;
     hipStream_t st = nullptr;
     size_t pbytes = size_t((nbits + 7) / 8);
+    if (index) {
+        // With an index the stream is decoded segment by segment: a run of whole chunks needs only the
+        // payload bytes between its first and its following index entry.
+        *nbytes = size_t(n_symbols);
+        if (n_symbols > cap) return MH_ERR_CAPACITY;
+        const uint64_t MASK = MH_INDEX_BIT_MASK;
+        const size_t seg = segment_bytes();
+        const uint64_t nchunks = mh_index_entries(n_symbols, chunk_symbols);
+        const size_t slen = n_symbols < seg ? size_t(n_symbols) : seg;
+        const size_t sidx = size_t(mh_index_entries(slen, chunk_symbols));
+        const size_t dws = mh_dev_decode_workspace(0, slen, chunk_symbols);
+        DevBuf d_pl, d_idx, d_dws, d_o;
+        size_t pl_cap = 0;
+        HIP_TRY(d_idx.alloc(sidx * 8));
+        HIP_TRY(d_dws.alloc(dws));
+        HIP_TRY(d_o.alloc(slen));
+        std::vector<uint64_t> seg_index(sidx);
+        for (uint64_t off = 0; off < n_symbols; off += seg) {
+            const size_t len = n_symbols - off < seg ? size_t(n_symbols - off) : seg;
+            const uint64_t c0 = off / chunk_symbols;
+            const size_t ne = size_t(mh_index_entries(len, chunk_symbols));
+            const uint64_t pos0 = index[c0] & MASK;
+            const uint64_t pos1 = c0 + ne < nchunks ? (index[c0 + ne] & MASK) : nbits;
+            if (pos0 > pos1 || pos1 > nbits) return MH_ERR_CORRUPT;
+            const uint64_t hb0 = (pos0 >> 3) & ~uint64_t(15);    // the device wants the payload 16-byte aligned
+            const uint64_t hb1 = (pos1 + 7) >> 3;
+            const size_t need = size_t(hb1 - hb0);
+            if (need > pl_cap) {
+                if (d_pl.p) { (void)hipFree(d_pl.p); d_pl.p = nullptr; }
+                pl_cap = need + (need >> 2) + 64;
+                HIP_TRY(d_pl.alloc(pl_cap));
+            }
+            if (need) HIP_TRY(hipMemcpy(d_pl.p, payload + hb0, need, hipMemcpyHostToDevice));
+            for (size_t i = 0; i < ne; ++i) {
+                const uint64_t e = index[c0 + i];
+                if ((e & MASK) < pos0) return MH_ERR_CORRUPT;
+                seg_index[i] = (e & ~MASK) | ((e & MASK) - hb0 * 8);
+            }
+            HIP_TRY(hipMemcpy(d_idx.p, seg_index.data(), ne * 8, hipMemcpyHostToDevice));
+            int rc = mh_dev_decode(m, d_pl.as<uint8_t>(), pos1 - hb0 * 8, d_o.as<uint8_t>(), len, d_idx.as<uint64_t>(), chunk_symbols,
+                                   d_dws.p, dws, st);
+            if (rc != MH_OK) return rc;
+            rc = mh_dev_status(d_dws.p, st);
+            if (rc != MH_OK) return rc;
+            HIP_TRY(hipMemcpy(out + off, d_o.p, len, hipMemcpyDeviceToHost));
+        }
+        return MH_OK;
+    }
+    // No index (what the reference writes): the whole payload goes to the card, the index is rebuilt
+    // there, and the output comes back segment by segment.
     DevBuf d_payload, d_index, d_ws, d_nsym, d_out;
     HIP_TRY(d_payload.alloc(pbytes));
     if (pbytes) HIP_TRY(hipMemcpy(d_payload.p, payload, pbytes, hipMemcpyHostToDevice));
-    size_t nidx;
-    if (index) {
-        nidx = size_t(mh_index_entries(n_symbols, chunk_symbols));
-        HIP_TRY(d_index.alloc(nidx * 8));
-        if (nidx) HIP_TRY(hipMemcpy(d_index.p, index, nidx * 8, hipMemcpyHostToDevice));
-    } else {
-        // every code is at least one bit: the stream holds at most nbits symbols
-        uint64_t idx_cap = nbits / chunk_symbols + 2;
-        HIP_TRY(d_index.alloc(size_t(idx_cap) * 8));
-        HIP_TRY(d_nsym.alloc(8));
+    // every code is at least one bit: the stream holds at most nbits symbols
+    const uint64_t idx_cap = nbits / chunk_symbols + 2;
+    HIP_TRY(d_index.alloc(size_t(idx_cap) * 8));
+    HIP_TRY(d_nsym.alloc(8));
+    {
         DevBuf d_iws;
         const size_t iws = mh_dev_build_index_workspace(nbits);
         HIP_TRY(d_iws.alloc(iws));
@@ -631,19 +732,32 @@ int mh_decode(const mh_model *m, const uint8_t *payload, uint64_t nbits, uint8_t
         if (rc != MH_OK) return rc;
         rc = mh_dev_status(d_iws.p, st);
         if (rc != MH_OK) return rc;
-        HIP_TRY(hipMemcpy(&n_symbols, d_nsym.p, 8, hipMemcpyDeviceToHost));
     }
+    HIP_TRY(hipMemcpy(&n_symbols, d_nsym.p, 8, hipMemcpyDeviceToHost));
     *nbytes = size_t(n_symbols);
     if (n_symbols > cap) return MH_ERR_CAPACITY;
-    HIP_TRY(d_out.alloc(size_t(n_symbols)));
-    const size_t dws = mh_dev_decode_workspace(nbits, n_symbols, chunk_symbols);
+    const size_t seg = segment_bytes();
+    const size_t slen = n_symbols < seg ? size_t(n_symbols) : seg;
+    const uint64_t nchunks = mh_index_entries(n_symbols, chunk_symbols);
+    HIP_TRY(d_out.alloc(slen));
+    const size_t dws = mh_dev_decode_workspace(nbits, slen, chunk_symbols);
     HIP_TRY(d_ws.alloc(dws));
-    int rc = mh_dev_decode(m, d_payload.as<uint8_t>(), nbits, d_out.as<uint8_t>(), n_symbols, d_index.as<uint64_t>(),
-                           chunk_symbols, d_ws.p, dws, st);
-    if (rc != MH_OK) return rc;
-    rc = mh_dev_status(d_ws.p, st);
-    if (rc != MH_OK) return rc;
-    if (n_symbols) HIP_TRY(hipMemcpy(out, d_out.p, size_t(n_symbols), hipMemcpyDeviceToHost));
+    for (uint64_t off = 0; off < n_symbols; off += seg) {
+        const size_t len = n_symbols - off < seg ? size_t(n_symbols - off) : seg;
+        const uint64_t c0 = off / chunk_symbols;
+        const uint64_t ne = mh_index_entries(len, chunk_symbols);
+        uint64_t end_bits = nbits;                               // a segment ends where the next one's first chunk starts
+        if (c0 + ne < nchunks) {
+            HIP_TRY(hipMemcpy(&end_bits, d_index.as<uint64_t>() + c0 + ne, 8, hipMemcpyDeviceToHost));
+            end_bits &= MH_INDEX_BIT_MASK;
+        }
+        int rc = mh_dev_decode(m, d_payload.as<uint8_t>(), end_bits, d_out.as<uint8_t>(), len, d_index.as<uint64_t>() + c0,
+                               chunk_symbols, d_ws.p, dws, st);
+        if (rc != MH_OK) return rc;
+        rc = mh_dev_status(d_ws.p, st);
+        if (rc != MH_OK) return rc;
+        HIP_TRY(hipMemcpy(out + off, d_out.p, len, hipMemcpyDeviceToHost));
+    }
     return MH_OK;
 }
 

@@ -288,6 +288,31 @@ def test_sharded_encode_preshifted_shards_or_into_the_reference_stream(mhc, orac
     assert bytes(out) == ref_blob[1:]
 
 
+@pytest.mark.parametrize("seg", [8192, 24576])
+@pytest.mark.parametrize("kind", ["zipf", "text", "skewed"])
+def test_host_buffer_calls_in_segments(mhc, oracle, monkeypatch, seg, kind):
+    """The host-pointer entry points stage their data through the card in segments (bounded device
+    footprint).  With tiny segments every few KiB is a seam: the context is carried across it, each
+    segment is emitted pre-shifted and OR-merged into the output, index entries are rebased."""
+    monkeypatch.setenv("MH_SEGMENT_BYTES", str(seg))
+    n = 5 * seg + 4097
+    data = {"zipf": lambda: zipf_bytes(n, 33), "text": lambda: text_like(n, 7), "skewed": lambda: _skewed(n, 13)}[kind]()
+    for order in (1, 0):
+        assert np.array_equal(mhc.histogram_o1(data) if order else mhc.histogram_o0(data),
+                              oracle.histogram_o1(data, 0x20) if order else oracle.histogram_o0(data))
+        m = mhc.Model.from_data(data, order)
+        o = oracle.Model.from_data(data, order)
+        blob, nbits, idx = m.compress(data, chunk_symbols=256)
+        ref, ref_bits = o.compress(data)
+        assert (nbits, blob) == (ref_bits, ref)
+        monkeypatch.setenv("MH_SEGMENT_BYTES", str(1 << 28))
+        blob_whole, _, idx_whole = m.compress(data, chunk_symbols=256)
+        monkeypatch.setenv("MH_SEGMENT_BYTES", str(seg))
+        assert blob_whole == blob and np.array_equal(idx_whole, idx)      # same stream, same index
+        assert m.decompress(blob, index=idx, chunk_symbols=256, n_symbols=len(data)) == data
+        assert m.decompress(blob) == data
+
+
 # ------------------------------------------------------------------ decode
 
 @pytest.mark.parametrize("name", golden_names())
