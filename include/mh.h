@@ -166,6 +166,18 @@ int mh_decode(const mh_model *m, const uint8_t *payload, uint64_t nbits, uint8_t
               uint8_t *out, size_t cap, size_t *nbytes,
               const uint64_t *index, uint32_t chunk_symbols, uint64_t n_symbols);
 
+/* mh_decode for callers that cannot know the output size beforehand (a stream without an index):
+ * get_out(ctx, n) is called exactly once, when the symbol count n is known, and returns where the n
+ * bytes go (NULL -> MH_ERR_CAPACITY).  The CLI maps its output file there. */
+typedef uint8_t *(*mh_output_fn)(void *ctx, size_t n);
+int mh_decode_to(const mh_model *m, const uint8_t *payload, uint64_t nbits, uint8_t prev0,
+                 mh_output_fn get_out, void *ctx, size_t *nbytes,
+                 const uint64_t *index, uint32_t chunk_symbols, uint64_t n_symbols);
+
+/* Payload bits this model produces for data with the given histogram (host counts: 65536 entries for a
+ * Markov model, 256 for a Huffman model): the exact size of the compressed file before encoding. */
+int mh_model_payload_bits(const mh_model *m, const uint64_t *counts, uint64_t *nbits);
+
 /* ------------------------------------------------------------ device calls */
 /* Device pointers, stream-ordered, no allocation, no synchronisation.  d_data / d_payload / d_out must
  * be 16-byte aligned.  Workspaces: query the size, allocate once, reuse. */

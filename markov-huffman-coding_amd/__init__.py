@@ -33,7 +33,7 @@ EXPORTS = [
     "mh_histogram_o1", "mh_histogram_o0", "mh_encode", "mh_encode_bound", "mh_stream_header",
     "mh_stream_parse_header", "mh_decode",
     "mh_dev_histogram_workspace", "mh_dev_histogram_o1", "mh_dev_histogram_o0",
-    "mh_dev_encode_workspace", "mh_dev_encode", "mh_dev_payload_bits", "mh_dev_encode_at", "mh_dev_decode_workspace", "mh_dev_decode",
+    "mh_decode_to", "mh_model_payload_bits", "mh_dev_encode_workspace", "mh_dev_encode", "mh_dev_payload_bits", "mh_dev_encode_at", "mh_dev_decode_workspace", "mh_dev_decode",
     "mh_dev_build_index_workspace", "mh_dev_build_index", "mh_dev_status",
 ]
 

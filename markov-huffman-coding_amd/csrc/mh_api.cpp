@@ -658,10 +658,11 @@ int mh_encode(const mh_model *m, const uint8_t *data, size_t n, uint8_t prev0, u
     return MH_OK;
 }
 
-int mh_decode(const mh_model *m, const uint8_t *payload, uint64_t nbits, uint8_t prev0, uint8_t *out, size_t cap,
-              size_t *nbytes, const uint64_t *index, uint32_t chunk_symbols, uint64_t n_symbols) {
-    if (!m || (!payload && nbits) || !nbytes || (!out && cap)) return MH_ERR_ARG;
+int mh_decode_to(const mh_model *m, const uint8_t *payload, uint64_t nbits, uint8_t prev0, mh_output_fn get_out, void *ctx,
+                 size_t *nbytes, const uint64_t *index, uint32_t chunk_symbols, uint64_t n_symbols) {
+    if (!m || (!payload && nbits) || !nbytes || !get_out) return MH_ERR_ARG;
     if (!have_device()) return MH_ERR_NO_DEVICE;
+    uint8_t *out = nullptr;
     if (!index) chunk_symbols = MH_CHUNK_DEFAULT;
     if (chunk_shift_of(chunk_symbols) < 0) return MH_ERR_ARG;
     hipStream_t st = nullptr;
@@ -670,7 +671,8 @@ int mh_decode(const mh_model *m, const uint8_t *payload, uint64_t nbits, uint8_t
         // With an index the stream is decoded segment by segment: a run of whole chunks needs only the
         // payload bytes between its first and its following index entry.
         *nbytes = size_t(n_symbols);
-        if (n_symbols > cap) return MH_ERR_CAPACITY;
+        out = get_out(ctx, size_t(n_symbols));
+        if (!out && n_symbols) return MH_ERR_CAPACITY;
         const uint64_t MASK = MH_INDEX_BIT_MASK;
         const size_t seg = segment_bytes();
         const uint64_t nchunks = mh_index_entries(n_symbols, chunk_symbols);
@@ -735,7 +737,8 @@ int mh_decode(const mh_model *m, const uint8_t *payload, uint64_t nbits, uint8_t
     }
     HIP_TRY(hipMemcpy(&n_symbols, d_nsym.p, 8, hipMemcpyDeviceToHost));
     *nbytes = size_t(n_symbols);
-    if (n_symbols > cap) return MH_ERR_CAPACITY;
+    out = get_out(ctx, size_t(n_symbols));                       // the size is known only now
+    if (!out && n_symbols) return MH_ERR_CAPACITY;
     const size_t seg = segment_bytes();
     const size_t slen = n_symbols < seg ? size_t(n_symbols) : seg;
     const uint64_t nchunks = mh_index_entries(n_symbols, chunk_symbols);
@@ -758,6 +761,32 @@ int mh_decode(const mh_model *m, const uint8_t *payload, uint64_t nbits, uint8_t
         if (rc != MH_OK) return rc;
         HIP_TRY(hipMemcpy(out + off, d_out.p, len, hipMemcpyDeviceToHost));
     }
+    return MH_OK;
+}
+
+namespace {
+struct FixedOut { uint8_t *p; size_t cap; };
+uint8_t *fixed_out(void *ctx, size_t n) {
+    FixedOut *f = static_cast<FixedOut *>(ctx);
+    return n <= f->cap ? f->p : nullptr;
+}
+}  // namespace
+
+int mh_decode(const mh_model *m, const uint8_t *payload, uint64_t nbits, uint8_t prev0, uint8_t *out, size_t cap,
+              size_t *nbytes, const uint64_t *index, uint32_t chunk_symbols, uint64_t n_symbols) {
+    if (!out && cap) return MH_ERR_ARG;
+    FixedOut f{out, out ? cap : 0};
+    return mh_decode_to(m, payload, nbits, prev0, fixed_out, &f, nbytes, index, chunk_symbols, n_symbols);
+}
+
+int mh_model_payload_bits(const mh_model *m, const uint64_t *counts, uint64_t *nbits) {
+    if (!m || !counts || !nbits) return MH_ERR_ARG;
+    { int rc = ensure_mirror(m); if (rc != MH_OK) return rc; }
+    const int nctx = m->type ? 256 : 1;
+    uint64_t total = 0;
+    for (int c = 0; c < nctx; ++c)
+        for (int sym = 0; sym < 256; ++sym) total += counts[c * 256 + sym] * uint64_t(m->host.context(c).code(sym).len);
+    *nbits = total;
     return MH_OK;
 }
 

@@ -4,6 +4,8 @@
 #include <errno.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <sstream>
@@ -74,12 +76,74 @@ static std::vector<unsigned char> slurp(FILE* f) {
     return all;
 }
 
+// Whole input from the stream's current position to EOF.  A regular file is mapped, not copied: the
+// library stages it through the card segment by segment, so a file larger than host memory still
+// works and nothing is read twice into process memory.  Pipes are read into a vector.
+struct InputView {
+    const unsigned char* data = nullptr;
+    size_t size = 0;
+    void* map = nullptr;
+    size_t map_len = 0;
+    std::vector<unsigned char> own;
+    explicit InputView(FILE* f) {
+        struct stat st;
+        long pos = ftell(f);
+        if (pos >= 0 && fstat(fileno(f), &st) == 0 && S_ISREG(st.st_mode) && (size_t)st.st_size > (size_t)pos) {
+            void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fileno(f), 0);
+            if (m != MAP_FAILED) {
+                map = m; map_len = (size_t)st.st_size;
+                (void)madvise(m, map_len, MADV_SEQUENTIAL);
+                data = (const unsigned char*)m + pos;
+                size = map_len - (size_t)pos;
+                fseek(f, 0, SEEK_END);
+                return;
+            }
+        }
+        own = slurp(f);
+        data = own.data();
+        size = own.size();
+    }
+    ~InputView() { if (map) munmap(map, map_len); }
+    InputView(const InputView&) = delete;
+    InputView& operator=(const InputView&) = delete;
+};
+
+// Output of a known size.  A regular file is grown to that size and mapped, so the library writes the
+// result where it belongs; anything else (stdout, a pipe) gets a buffer that is written afterwards.
+struct OutputView {
+    unsigned char* data = nullptr;
+    size_t size = 0;
+    void* map = nullptr;
+    FILE* file = nullptr;
+    std::vector<unsigned char> own;
+    void open(FILE* f, size_t n) {
+        file = f; size = n;
+        struct stat st;
+        fflush(f);
+        if (n && fstat(fileno(f), &st) == 0 && S_ISREG(st.st_mode) && ftell(f) == 0 && ftruncate(fileno(f), (off_t)n) == 0) {
+            void* m = mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_SHARED, fileno(f), 0);
+            if (m != MAP_FAILED) { map = m; data = (unsigned char*)m; return; }
+        }
+        own.assign(n ? n : 1, 0);
+        data = own.data();
+    }
+    void finish() {
+        if (map) {
+            if (munmap(map, size) != 0) { eprintf("Error occurred while writing file.\n"); exit(1); }
+            map = nullptr;
+            fseek(file, 0, SEEK_END);
+        } else if (size) {
+            write_buffer(data, 1, size, file);
+        }
+    }
+};
+
 // ------------------------------------------------------------------------ histogram (a1/a2)
 
 void construct_table(FILE* input_fd, int order, uint64_t* counts64) {
-    std::vector<unsigned char> all = slurp(input_fd);
-    if (order) mh_or_die(mh_histogram_o1(all.data(), all.size(), MH_PREV0, counts64), "histogram");
-    else mh_or_die(mh_histogram_o0(all.data(), all.size(), counts64), "histogram");
+    InputView all(input_fd);
+    if (order) mh_or_die(mh_histogram_o1(all.data, all.size, MH_PREV0, counts64), "histogram");
+    else mh_or_die(mh_histogram_o0(all.data, all.size, counts64), "histogram");
 }
 
 // ------------------------------------------------------------------------ provider base
@@ -87,6 +151,7 @@ void construct_table(FILE* input_fd, int order, uint64_t* counts64) {
 i_coding_provider::~i_coding_provider() { mh_model_free(model_); }
 
 void i_coding_provider::build_from_counts(const uint64_t* counts, int order) {
+    counts_.assign(counts, counts + (order ? 65536 : 256));     // kept: compress() sizes its output from them
     mh_model* m = nullptr;
     mh_or_die(mh_model_from_counts(counts, order, &m), "table build");
     adopt(m);
@@ -139,25 +204,35 @@ bool i_coding_provider::context_empty(int prev) {
 // src/coding.cpp:61-94: header placeholder, payload, header rewrite.  Here the payload comes out of the
 // HIP encoder in one piece, so the header is known before anything is written and no seek is needed.
 void i_coding_provider::compress(FILE* input_fd, FILE* output_fd) {
-    std::vector<unsigned char> in = slurp(input_fd);
-    size_t cap = mh_encode_bound(model_, in.size());
-    std::vector<unsigned char> payload(cap ? cap : 1);
+    InputView in(input_fd);
+    // The file size is known before anything is encoded: histogram of the input . code lengths.  (The
+    // histogram that built the tables is reused when there is one; with -e it is taken here.)
+    const int order = mh_model_type(model_);
+    if (counts_.empty()) {
+        counts_.assign(order ? 65536 : 256, 0);
+        if (order) mh_or_die(mh_histogram_o1(in.data, in.size, MH_PREV0, counts_.data()), "histogram");
+        else mh_or_die(mh_histogram_o0(in.data, in.size, counts_.data()), "histogram");
+    }
+    uint64_t bits = 0;
+    mh_or_die(mh_model_payload_bits(model_, counts_.data(), &bits), "compress");
+    const size_t nbytes = (size_t)((bits + 7) / 8);
+    OutputView out;
+    out.open(output_fd, 1 + nbytes);
+    out.data[0] = mh_stream_header(model_, bits);               // src/coding.cpp:88 — known up front, no seek back
     uint64_t nbits = 0;
     std::vector<uint64_t> index;
-    if (!index_path_.empty()) index.resize((size_t)mh_index_entries(in.size(), chunk_) + 1);
-    mh_or_die(mh_encode(model_, in.data(), in.size(), MH_PREV0, payload.data(), cap, &nbits,
+    if (!index_path_.empty()) index.resize((size_t)mh_index_entries(in.size, chunk_) + 1);
+    mh_or_die(mh_encode(model_, in.data, in.size, MH_PREV0, out.data + 1, nbytes, &nbits,
                         index.empty() ? nullptr : index.data(), chunk_), "compress");
-    unsigned char header = mh_stream_header(model_, nbits);
-    write_buffer(&header, 1, 1, output_fd);
-    size_t nbytes = (size_t)((nbits + 7) / 8);
-    if (nbytes) write_buffer(payload.data(), 1, nbytes, output_fd);
+    if (nbits != bits) mh_or_die(MH_ERR_CORRUPT, "compress");
+    out.finish();
     if (!index_path_.empty()) {
         // sidecar: magic, chunk size, symbol count, entries (little-endian u64s)
         FILE* f = fopen(index_path_.c_str(), "wb");
         if (!f) { eprintf("Error while opening index output; %s.\n", strerror(errno)); exit(1); }
-        uint64_t head[3] = {0x315844494D48ull /* "HMIDX1" */, chunk_, (uint64_t)in.size()};
+        uint64_t head[3] = {0x315844494D48ull /* "HMIDX1" */, chunk_, (uint64_t)in.size};
         write_buffer(head, 8, 3, f);
-        size_t ne = (size_t)mh_index_entries(in.size(), chunk_);
+        size_t ne = (size_t)mh_index_entries(in.size, chunk_);
         if (ne) write_buffer(index.data(), 8, ne, f);
         fclose(f);
     }
@@ -166,12 +241,18 @@ void i_coding_provider::compress(FILE* input_fd, FILE* output_fd) {
     else fflush(output_fd);
 }
 
+static uint8_t* open_output_cb(void* ctx, size_t n) {
+    OutputView* o = (OutputView*)ctx;
+    o->open(o->file, n);
+    return o->data;
+}
+
 // src/coding.cpp:96-160
 void i_coding_provider::decompress(FILE* input_fd, FILE* output_fd) {
-    std::vector<unsigned char> in = slurp(input_fd);
-    if (in.empty()) mh_or_die(MH_ERR_CORRUPT, "decompress");
+    InputView in(input_fd);
+    if (in.size == 0) mh_or_die(MH_ERR_CORRUPT, "decompress");
     uint64_t nbits = 0;
-    mh_or_die(mh_stream_parse_header(model_, in[0], in.size(), &nbits), "decompress");
+    mh_or_die(mh_stream_parse_header(model_, in.data[0], in.size, &nbits), "decompress");
     std::vector<uint64_t> index;
     uint64_t n_symbols = 0;
     uint32_t chunk = 0;
@@ -190,20 +271,14 @@ void i_coding_provider::decompress(FILE* input_fd, FILE* output_fd) {
         }
     }
     const bool have_index = !index.empty();
-    // without an index every code is >= 1 bit, so nbits bounds the output size; probe first
+    // the output size is known once the symbols are counted (without an index: after the device has
+    // rebuilt it); the library then asks for the buffer, which is the mapped output file
     size_t n = 0;
-    std::vector<unsigned char> out;
-    if (have_index) {
-        out.resize(n_symbols ? (size_t)n_symbols : 1);
-        mh_or_die(mh_decode(model_, in.data() + 1, nbits, MH_PREV0, out.data(), (size_t)n_symbols, &n, index.data(), chunk, n_symbols),
-                  "decompress");
-    } else {
-        int rc = mh_decode(model_, in.data() + 1, nbits, MH_PREV0, nullptr, 0, &n, nullptr, 0, 0);
-        if (rc != MH_OK && rc != MH_ERR_CAPACITY) mh_or_die(rc, "decompress");
-        out.resize(n ? n : 1);
-        if (n) mh_or_die(mh_decode(model_, in.data() + 1, nbits, MH_PREV0, out.data(), n, &n, nullptr, 0, 0), "decompress");
-    }
-    if (n) write_buffer(out.data(), 1, n, output_fd);
+    OutputView out;
+    out.file = output_fd;
+    mh_or_die(mh_decode_to(model_, in.data + 1, nbits, MH_PREV0, open_output_cb, &out, &n,
+                           have_index ? index.data() : nullptr, have_index ? chunk : 0, have_index ? n_symbols : 0), "decompress");
+    if (out.data) out.finish();
     fclose(input_fd);
     if (output_fd != stdout) fclose(output_fd);
     else fflush(output_fd);

@@ -73,6 +73,7 @@ private:
     encoding_descriptor scratch_desc_;
     tree_node scratch_node_;
     std::string index_path_;
+    std::vector<uint64_t> counts_;               // histogram the tables were built from (empty when loaded from a file)
     uint32_t chunk_ = MH_CHUNK_DEFAULT;
 };
 

@@ -131,7 +131,7 @@ int main(int argc, char* argv[]) {
     if (o.encoding_output) check_access(o.encoding_output, false);
 
     FILE* input_fd = open_or_die(o.input, "rb", "input");
-    FILE* output_fd = o.output ? open_or_die(o.output, "wb", "output") : stdout;
+    FILE* output_fd = o.output ? open_or_die(o.output, "w+b", "output") : stdout;   // read-write: the result is written through a mapping
 
     i_coding_provider* coder = nullptr;
     if (o.encoding_input) {

@@ -96,3 +96,27 @@ def test_error_exits(tmp_path):
     assert run([tmp_path / "nope", "-o", tmp_path / "x"]).returncode == 1           # missing input
     r = run([src, "-q", "-o", tmp_path / "y"])                                      # unknown flag only warns
     assert r.returncode == 0 and b"Unknown option q" in r.stderr
+
+
+def test_large_file_in_segments_and_stdout(tmp_path):
+    """N2: a file staged through the card in several segments (mapped input and output files, seams
+    OR-merged), the same stream through stdout (no mapping possible), and both decode paths."""
+    import numpy as np
+    from oracle import mh_oracle
+    rng = np.random.default_rng(77)
+    w = 1.0 / np.arange(1, 257) ** 1.1
+    data = rng.choice(256, size=(24 << 20) + 12345, p=w / w.sum()).astype(np.uint8).tobytes()
+    src = tmp_path / "in"
+    src.write_bytes(data)
+    env = dict(os.environ, MH_SEGMENT_BYTES=str(4 << 20))
+    assert run([src, "-o", tmp_path / "c", "-d", tmp_path / "t", "--index", tmp_path / "c.idx"], env=env).returncode == 0
+    ref, _ = mh_oracle.Model.from_data(data, 1).compress(data)
+    assert (tmp_path / "c").read_bytes() == ref
+    piped = run([src, "-d", tmp_path / "t2"], env=env)                       # compressed stream on stdout
+    assert piped.returncode == 0 and piped.stdout == ref
+    assert run([tmp_path / "c", "-o", tmp_path / "d1", "-x", "-e", tmp_path / "t"], env=env).returncode == 0
+    assert (tmp_path / "d1").read_bytes() == data
+    assert run([tmp_path / "c", "-o", tmp_path / "d2", "-x", "-e", tmp_path / "t", "--index", tmp_path / "c.idx"], env=env).returncode == 0
+    assert (tmp_path / "d2").read_bytes() == data
+    out = run([tmp_path / "c", "-x", "-e", tmp_path / "t"], env=env)          # decoded bytes on stdout
+    assert out.returncode == 0 and out.stdout == data
