@@ -83,17 +83,20 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
     return v;
 }
 
-// 16 consecutive input bytes of a lane (little-endian dwords) + the byte before them -> the 16
-// (prev, sym) windows, window = sym << 8 | prev = the raw 16-bit field of the stream.
-__device__ __forceinline__ void windows16(const uint4 &x, uint32_t pb, uint32_t (&w)[16]) {
-    w[0] = ((x.x << 8) | pb) & 0xFFFFu;
-    w[1] = x.x & 0xFFFFu;  w[2] = (x.x >> 8) & 0xFFFFu;  w[3] = x.x >> 16;
-    w[4] = __builtin_amdgcn_alignbyte(x.y, x.x, 3) & 0xFFFFu;
-    w[5] = x.y & 0xFFFFu;  w[6] = (x.y >> 8) & 0xFFFFu;  w[7] = x.y >> 16;
-    w[8] = __builtin_amdgcn_alignbyte(x.z, x.y, 3) & 0xFFFFu;
-    w[9] = x.z & 0xFFFFu;  w[10] = (x.z >> 8) & 0xFFFFu; w[11] = x.z >> 16;
-    w[12] = __builtin_amdgcn_alignbyte(x.w, x.z, 3) & 0xFFFFu;
-    w[13] = x.w & 0xFFFFu; w[14] = (x.w >> 8) & 0xFFFFu; w[15] = x.w >> 16;
+// The 16 table slots (mh::enc_slot) of a lane's 16 consecutive input bytes, without forming the
+// windows: per dword the mixed low bytes of its four symbols are bfi(0xF8F8F8F8, x << 3, x >> 5) ^
+// (x << 8 | previous byte), and one byte shuffle per symbol pairs each with its symbol.
+__device__ __forceinline__ void slots16(const uint4 &x4, uint32_t pb, uint32_t (&slot)[16]) {
+    const uint32_t x[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t rot = (((x[k] << 3) & 0xF8F8F8F8u) | ((x[k] >> 5) & 0x07070707u));
+        const uint32_t y = rot ^ ((x[k] << 8) | pb);
+        pb = x[k] >> 24;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            slot[4 * k + j] = __builtin_amdgcn_perm(x[k], y, 0x0C0C0400u + uint32_t(j) * 0x0101u);   // x.byte j << 8 | y.byte j
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -308,14 +311,14 @@ __global__ __launch_bounds__(E_THREADS, 8) void enc_len_kernel(LenParams p) {
                 ahead = load_raw(p.data, p.n, noff, p.prev0);
             }
             uint32_t w[16];
-            windows16(in.x, head_byte(in), w);
+            slots16(in.x, head_byte(in), w);
             if (__all(in.nvalid == E_VEC)) {             // wave-uniform: everything but the stream's last vectors
 #pragma unroll
-                for (int j = 0; j < 16; ++j) sum += ltab[mh::enc_slot(w[j])];
+                for (int j = 0; j < 16; ++j) sum += ltab[w[j]];
             } else {
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
-                    uint32_t l = ltab[mh::enc_slot(w[j])];
+                    uint32_t l = ltab[w[j]];
                     sum += (uint32_t(j) < in.nvalid) ? l : 0u;
                 }
             }
@@ -565,13 +568,13 @@ __global__ __launch_bounds__(E_THREADS) void enc_emit_kernel(EmitParams p) {
             uint32_t emax = nvalid == E_VEC ? 0u : 0xFFFFu;   // ragged vectors take the symbol-by-symbol path
             {
                 uint32_t w[16];
-                windows16(x, pb, w);
+                slots16(x, pb, w);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     uint32_t e[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        e[j] = uint32_t(tab[mh::enc_slot(w[4 * q + j])]);
+                        e[j] = uint32_t(tab[w[4 * q + j]]);
                         emax = e[j] > emax ? e[j] : emax;
                     }
                     uint32_t l0 = e[0] >> 12, l1 = e[1] >> 12, l2 = e[2] >> 12, l3 = e[3] >> 12;

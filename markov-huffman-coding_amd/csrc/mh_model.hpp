@@ -21,17 +21,19 @@ namespace mh {
 // 0 = "no code" (symbol skipped, src/coding.cpp:72 under NDEBUG), ENC16_ESCAPE = look the
 // codeword up in the full (len8, code64) tables in HBM/L2.
 // Index = enc_slot(window) where window = sym << 8 | prev is the raw little-endian 16-bit field
-// read straight out of the byte stream.  The low byte is hashed, (3 * prev + 37 * sym) mod 256, so
-// that the few very frequent (prev, sym) pairs of a skewed source land in different LDS banks AND in
-// different 32-bit words (the histogram packs two counters per word): with a plain or XOR-ed low
-// byte, Zipf-like data puts ~80 % of all accesses into four banks.  3 is odd, so the map is a
-// bijection of prev for every sym; enc_slot_prev() inverts it (171 = 3^-1 mod 256).
+// read straight out of the byte stream.  The low byte is mixed, prev ^ rotl8(sym, 3), so that the few
+// very frequent (prev, sym) pairs of a skewed source land in different LDS banks and words (with a
+// plain or plainly XOR-ed low byte, Zipf-like data puts ~80 % of all accesses into four banks: small
+// prev ^ small sym is small; the rotation moves the symbol's low bits up to bits 3..7).  It is a
+// bijection of prev for every sym, and for four packed symbols it costs five instructions on the
+// device: bfi(0xF8F8F8F8, x << 3, x >> 5) ^ (x << 8 | previous byte).
 constexpr uint16_t ENC16_ESCAPE = 0xFFFF;
 constexpr int ENC16_MAX_LEN = 12;
+constexpr uint32_t slot_mix(uint32_t sym) { return ((sym << 3) | (sym >> 5)) & 0xFFu; }
 constexpr uint32_t enc_slot(uint32_t window) {
-    return (window & 0xFF00u) | ((3u * (window & 0xFFu) + 37u * (window >> 8)) & 0xFFu);
+    return (window & 0xFF00u) | ((window & 0xFFu) ^ slot_mix(window >> 8));
 }
-constexpr uint32_t enc_slot_prev(uint32_t slot) { return (((slot & 0xFFu) - 37u * (slot >> 8)) * 171u) & 0xFFu; }
+constexpr uint32_t enc_slot_prev(uint32_t slot) { return (slot & 0xFFu) ^ slot_mix(slot >> 8); }
 
 // Decode tables: two levels, BOTH LDS-resident whenever they fit (a code that needs an L2 gather per
 // symbol costs the whole wave ~10x an LDS lookup, and with 64 lanes some lane always needs it).
