@@ -346,6 +346,8 @@ def main():
                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(kernels[dom][0])},
             "stages_ms": {k: round(v, 3) for k, v in ms.items()},
+            "compress_ms": round(ms["hist"] + ms["allreduce"] + ms["tree"] + ms["encode"], 3),      # compress = hist + tree + encode
+            "compress_GBps": round(n / ((ms["hist"] + ms["allreduce"] + ms["tree"] + ms["encode"]) * 1e-3) / 1e9, 2),
             "stage_GBps_input": {k: (round(n / (v * 1e-3) / 1e9, 2) if v > 0 else None) for k, v in ms.items()},
             "kernel_roofline_frac": {k: round(b / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if t > 0 else None for k, (b, t) in kernels.items()},
             "encode_read_roofline_frac": round(n / (ms["encode"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms["encode"] > 0 else None,
