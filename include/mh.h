@@ -217,7 +217,10 @@ int mh_dev_encode_at(const mh_model *m, const uint8_t *d_data, size_t n, uint8_t
 /* 64-byte status block + one uint32 per chunk (list of the chunks whose codes exceed the decode
  * tables and are decoded by a second launch); 0 for an invalid chunk size. */
 size_t mh_dev_decode_workspace(uint64_t nbits, uint64_t n_symbols, uint32_t chunk_symbols);
-/* Parallel decode with an index.  ws_bytes must be at least mh_dev_decode_workspace(...) (MH_ERR_ARG).  Errors found on the device (null LUT entry, walk past the end)
+/* Parallel decode with an index.  ws_bytes must be at least mh_dev_decode_workspace(...) (MH_ERR_ARG).
+ * d_payload and d_out are 16-byte aligned; the kernel reads the payload in aligned 32- or 64-byte pieces,
+ * so d_payload must be readable up to the next 64-byte boundary after its last byte (any hipMalloc'ed
+ * buffer is).  Errors found on the device (null LUT entry, walk past the end)
  * are reported through the int32 at the start of the workspace: mh_dev_status() reads it. */
 int mh_dev_decode(const mh_model *m, const uint8_t *d_payload, uint64_t nbits,
                   uint8_t *d_out, uint64_t n_symbols,
