@@ -492,7 +492,6 @@ int mh_dev_decode(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, u
     p.chunk_shift = uint32_t(shift);
     p.prim = m->d_prim; p.sec = m->d_sec; p.sec_base = m->d_sec_base; p.tree = m->d_tree;
     p.P = uint32_t(m->dec_bits); p.nsec = m->nsec; p.sec_lds = m->dec_lds ? 1u : 0u;
-    p.sec_lds_entries = 0;
     p.direct = m->dec_direct ? 1u : 0u; p.H = uint32_t(m->dec_h);
     HIP_TRY(mhk::launch_decode(p, d_ws, static_cast<hipStream_t>(stream)));
     return MH_OK;

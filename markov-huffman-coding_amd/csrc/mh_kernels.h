@@ -77,7 +77,6 @@ struct DecParams {
     uint32_t P;
     uint32_t nsec;
     uint32_t sec_lds;             // 1: prim + sec fit LDS
-    uint32_t sec_lds_entries;     // leading sec entries to keep in LDS when they do not all fit
     uint32_t direct;              // 1: uniform tables of 2^H entries, inner entry = table id
     uint32_t H;
     int *status;

@@ -28,47 +28,6 @@ using mh::TREE_STRIDE;
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
-// 16-byte accesses with the non-temporal hint (data touched once: do not keep it in the vector L1)
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint4 ld_stream16(const uint4 *p) {
-    u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
-    return make_uint4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ void st_stream16(uint4 *p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
-    u32x4 v = {a, b, c, d};
-    __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p));
-}
-
-// (L, tail7) monoid: L = bit length of a run of codewords, tail = its last min(7, L) bits, right
-// aligned.  combine(a, b) describes the concatenation a||b.  Identity = 0.
-// 32-bit packing (inside a tile): L << 7 | tail.       L < 2^25
-// 64-bit packing (tile descriptors): status << 62 | tail << 55 | L.   L < 2^55
-__device__ __forceinline__ uint32_t comb32(uint32_t a, uint32_t b) {
-    uint32_t lb = b >> 7;
-    uint32_t tail = lb >= 7 ? (b & 127u) : (((a & 127u) << lb) | (b & 127u)) & 127u;
-    return (((a >> 7) + lb) << 7) | tail;
-}
-
-constexpr uint64_t D_LMASK = (1ull << 55) - 1;
-constexpr uint64_t D_PAYLOAD = (1ull << 62) - 1;
-constexpr uint64_t D_AGG = 1ull << 62;
-constexpr uint64_t D_PREFIX = 2ull << 62;
-
-__device__ __forceinline__ uint64_t comb64(uint64_t a, uint64_t b) {
-    uint64_t lb = b & D_LMASK;
-    uint64_t ta = (a >> 55) & 127u, tb = (b >> 55) & 127u;
-    uint64_t tail = lb >= 7 ? tb : (((ta << lb) | tb) & 127u);
-    return (((a & D_LMASK) + lb) & D_LMASK) | (tail << 55);
-}
-__device__ __forceinline__ uint64_t widen(uint32_t p) { return (uint64_t(p & 127u) << 55) | uint64_t(p >> 7); }
-
-__device__ __forceinline__ uint64_t ld_desc(const unsigned long long *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_desc(unsigned long long *p, uint64_t v) {
-    __hip_atomic_store(p, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // Inclusive prefix sum over the 64 lanes of a wave with DPP row shifts / row broadcasts (7 VALU
 // instructions; the __shfl_up form costs six LDS-crossbar round trips).
 __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
@@ -668,8 +627,6 @@ struct DecTables {
     const uint16_t *sec;         // second-level tables: LDS copy (decode_kernel) or global (index builder)
     const uint32_t *tree;        // last-resort walk (HBM/L2)
     uint32_t P;                  // primary width in bits
-    const uint16_t *gsec;        // all second-level tables in HBM/L2
-    uint32_t lim;                // entries [0, lim) of gsec are also in `sec` (hybrid mode)
     uint32_t direct, H;          // uniform L2 tables: inner entry = table id, 2^H entries each
 };
 
@@ -884,7 +841,7 @@ __device__ __forceinline__ uint32_t put_byte(uint32_t d, uint32_t e, int j) {
 // WALK: codes longer than both table levels are walked in place.  The K-stream hot loop runs without
 // it (K inlined copies of the walk cost 13 % of the decode time in registers and code): such a stream
 // sets its bit in `redo`, and the kernel hands the chunk to the redo pass.
-template <int K, bool CHECKED, bool REFILL, bool HYBRID, bool DIRECT, int PC, int HC, bool WALK, typename LS>
+template <int K, bool CHECKED, bool REFILL, bool DIRECT, int PC, int HC, bool WALK, typename LS>
 __device__ __forceinline__ void decode_step(const uint16_t *prim, const uint32_t *sec_base, const DecTables &t,
                                             LS (&ls)[K], uint32_t (&pe)[K], bool &bad, uint32_t &redo) {
     const uint32_t P = PC ? uint32_t(PC) : t.P;
@@ -916,13 +873,7 @@ __device__ __forceinline__ void decode_step(const uint16_t *prim, const uint32_t
             if (DIRECT && PC == 8 && HC == 8) idx = __builtin_amdgcn_perm(e[k], hi[k], 0x0C050402u);   // e << 8 | byte 2 of hi
             else if (DIRECT) idx = (e[k] << H) | __builtin_amdgcn_ubfe(hi[k], 32u - P - H, H);
             else idx = sb[k] + (e[k] & 0xFFFu) + __builtin_amdgcn_ubfe(hi[k], 32u - P - h, h);
-            if (HYBRID) {
-                // tables of the frequent contexts sit in LDS; only the rest goes through the vector L1
-                if (in && idx < t.lim) e2[k] = t.sec[idx];
-                if (in && idx >= t.lim) e2[k] = t.gsec[idx];
-            } else if (in) {
-                e2[k] = t.sec[idx];
-            }
+            if (in) e2[k] = t.sec[idx];
         }
         // leaves carry bit 15 and lanes without a second level hold 0: the larger one is the entry that
         // resolves the symbol; if both are inner the result has no leaf flag and the code is walked
@@ -975,7 +926,7 @@ __device__ __forceinline__ void decode_chunk_single(const uint16_t *lut, const u
     bool bad = false;
     uint32_t q = 0, redo = 0;
     for (uint32_t i = 0; i < nsym; ++i) {
-        decode_step<1, true, true, false, DIRECT, 0, 0, true>(lut, sub_base, t, ls, prev, bad, redo);
+        decode_step<1, true, true, DIRECT, 0, 0, true>(lut, sub_base, t, ls, prev, bad, redo);
         q |= (prev[0] & 255u) << (8u * (i & 3u));
         if ((i & 3u) == 3u) { *reinterpret_cast<uint32_t *>(o + i - 3u) = q; q = 0; }
     }
@@ -1014,7 +965,7 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecParams p) {
 
     // (a hybrid — tables of the frequent contexts in LDS, the rest in L2 — was measured and did not pay:
     //  some lane still needs L2 in every round, and that latency, not the gather width, is what costs)
-    const DecTables tabs{SEC_LDS ? lsec : p.sec, p.tree, p.P, p.sec, 0xFFFFFFFFu, p.direct, p.H};
+    const DecTables tabs{SEC_LDS ? lsec : p.sec, p.tree, p.P, p.direct, p.H};
     const uint32_t S = 1u << p.chunk_shift;
     const uint64_t full_chunks = p.n >> p.chunk_shift;          // chunks with exactly S symbols
     if (REDO) {
@@ -1070,8 +1021,8 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecParams p) {
                         for (int k = 0; k < K; ++k) d[k] = 0;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            if (j % SPR == 0) decode_step<K, false, true, false, DIRECT, PC, HC, false>(lut, sub_base, tabs, ls, prev, bad, redo);
-                            else decode_step<K, false, false, false, DIRECT, PC, HC, false>(lut, sub_base, tabs, ls, prev, bad, redo);
+                            if (j % SPR == 0) decode_step<K, false, true, DIRECT, PC, HC, false>(lut, sub_base, tabs, ls, prev, bad, redo);
+                            else decode_step<K, false, false, DIRECT, PC, HC, false>(lut, sub_base, tabs, ls, prev, bad, redo);
 #pragma unroll
                             for (int k = 0; k < K; ++k) d[k] = put_byte(d[k], prev[k], j);
                         }
@@ -1159,7 +1110,7 @@ __global__ __launch_bounds__(256) void index_sync_kernel(IdxParams p, uint32_t i
     else start = __hip_atomic_load(&p.seg_end_state[i - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (iter > 0 && start == p.seg_used[i]) return;                    // same input as last time
     const BitSrc src{p.payload, p.payload_bytes >> 2, p.payload_bytes};
-    const DecTables tabs{p.sec, p.tree, p.P, p.sec, 0, p.direct, p.H};
+    const DecTables tabs{p.sec, p.tree, p.P, p.direct, p.H};
     uint32_t count;
     bool bad;
     uint64_t end = walk_segment(p, tabs, src, start, seg_end, count, bad, [](uint32_t, uint32_t, uint64_t) {});
@@ -1190,7 +1141,7 @@ __global__ __launch_bounds__(256) void index_fill_kernel(IdxParams p) {
     const uint64_t base = p.seg_sym_start[i];
     const uint64_t smask = (1ull << p.chunk_shift) - 1;
     const BitSrc src{p.payload, p.payload_bytes >> 2, p.payload_bytes};
-    const DecTables tabs{p.sec, p.tree, p.P, p.sec, 0, p.direct, p.H};
+    const DecTables tabs{p.sec, p.tree, p.P, p.direct, p.H};
     uint32_t count;
     bool bad, overflow = false;
     uint64_t end = walk_segment(p, tabs, src, start, seg_end, count, bad, [&](uint32_t k, uint32_t prev, uint64_t pos) {
@@ -1212,7 +1163,7 @@ __global__ __launch_bounds__(256) void index_fill_kernel(IdxParams p) {
 __global__ void build_index_kernel(IdxParams p) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     const BitSrc src{p.payload, p.payload_bytes >> 2, p.payload_bytes};
-    const DecTables tabs{p.sec, p.tree, p.P, p.sec, 0, p.direct, p.H};
+    const DecTables tabs{p.sec, p.tree, p.P, p.direct, p.H};
     BitCursor bc;
     bc.init(src, 0);
     uint64_t bi = 0, nsym = 0;
