@@ -105,6 +105,8 @@ class Codec:
         self.nidx = (n + CHUNK - 1) // CHUNK
         self.index = torch.empty(max(self.nidx, 1), dtype=torch.int64, device=device)
         self.nbits = torch.zeros(2, dtype=torch.int64, device=device)
+        self.hist_ws_bytes = int(self.lib.mh_dev_histogram_workspace(n))
+        self.hist_ws = torch.empty(self.hist_ws_bytes, dtype=torch.uint8, device=device)
         self.enc_ws_bytes = self.lib.mh_dev_encode_workspace(n)
         self.enc_ws = torch.empty(self.enc_ws_bytes + 64, dtype=torch.uint8, device=device)
         self.dec_ws_bytes = int(self.lib.mh_dev_decode_workspace(0, n, CHUNK))
@@ -118,8 +120,8 @@ class Codec:
         return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def histogram(self, data, prev0):
-        self.check(self.lib.mh_dev_histogram_o1(data.data_ptr(), self.n, prev0, self.counts.data_ptr(), None, 0,
-                                                self.stream()), "hist")
+        self.check(self.lib.mh_dev_histogram_o1(data.data_ptr(), self.n, prev0, self.counts.data_ptr(), self.hist_ws.data_ptr(),
+                                                self.hist_ws_bytes, self.stream()), "hist")
 
     def build_model(self):
         return self.mhc.Model.from_device_counts(self.counts.data_ptr(), 1, self.stream())

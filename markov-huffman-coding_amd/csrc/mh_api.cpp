@@ -416,11 +416,12 @@ void mh_model_free(mh_model *m) {
 
 /* ------------------------------------------------------------ device calls */
 
-size_t mh_dev_histogram_workspace(size_t) { return 64; }
+size_t mh_dev_histogram_workspace(size_t) { return have_device() ? mhk::hist_workspace_bytes() : 64; }
 
-int mh_dev_histogram_o1(const uint8_t *d_data, size_t n, uint8_t prev0, uint64_t *d_counts, void *, size_t, void *stream) {
+int mh_dev_histogram_o1(const uint8_t *d_data, size_t n, uint8_t prev0, uint64_t *d_counts, void *d_ws, size_t ws_bytes, void *stream) {
     if ((!d_data && n) || !d_counts || !aligned16(d_data)) return MH_ERR_ARG;
-    HIP_TRY(mhk::launch_hist_o1(d_data, n, prev0, reinterpret_cast<unsigned long long *>(d_counts), static_cast<hipStream_t>(stream)));
+    HIP_TRY(mhk::launch_hist_o1(d_data, n, prev0, reinterpret_cast<unsigned long long *>(d_counts), d_ws, ws_bytes,
+                                static_cast<hipStream_t>(stream)));
     return MH_OK;
 }
 
@@ -547,16 +548,18 @@ static int histogram_host(const uint8_t *data, size_t n, uint8_t prev0, uint64_t
     if (!have_device()) return MH_ERR_NO_DEVICE;
     const size_t nc = order ? 65536 : 256;
     const size_t seg = segment_bytes();
-    DevBuf d_data, d_counts;
+    DevBuf d_data, d_counts, d_hws;
     HIP_TRY(d_data.alloc(n < seg ? n : seg));
     HIP_TRY(d_counts.alloc(nc * 8));
+    const size_t hws = order && n >= (size_t(1) << 20) ? mh_dev_histogram_workspace(n) : 0;   // pays from about a megabyte on
+    if (hws) HIP_TRY(d_hws.alloc(hws));
     std::vector<uint64_t> part(nc);
     for (size_t i = 0; i < nc; ++i) counts[i] = 0;
     for (size_t off = 0; off < n || off == 0; off += seg) {
         const size_t len = n - off < seg ? n - off : seg;
         if (len) HIP_TRY(hipMemcpy(d_data.p, data + off, len, hipMemcpyHostToDevice));
         const uint8_t p0 = off ? data[off - 1] : prev0;            // context carried across the seam (src/main.cpp:32,36)
-        int rc = order ? mh_dev_histogram_o1(d_data.as<uint8_t>(), len, p0, d_counts.as<uint64_t>(), nullptr, 0, nullptr)
+        int rc = order ? mh_dev_histogram_o1(d_data.as<uint8_t>(), len, p0, d_counts.as<uint64_t>(), hws ? d_hws.p : nullptr, hws, nullptr)
                        : mh_dev_histogram_o0(d_data.as<uint8_t>(), len, d_counts.as<uint64_t>(), nullptr, 0, nullptr);
         if (rc != MH_OK) return rc;
         HIP_TRY(hipMemcpy(part.data(), d_counts.p, nc * 8, hipMemcpyDeviceToHost));

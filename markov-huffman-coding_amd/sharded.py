@@ -120,7 +120,9 @@ class HipBackend:
 
     def histogram(self, shard, prev0):
         counts = torch.zeros(65536, dtype=torch.int64, device=shard.device)
-        self._check(self.lib.mh_dev_histogram_o1(shard.data_ptr(), shard.numel(), prev0, counts.data_ptr(), None, 0,
+        wsb = int(self.lib.mh_dev_histogram_workspace(shard.numel()))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=shard.device)
+        self._check(self.lib.mh_dev_histogram_o1(shard.data_ptr(), shard.numel(), prev0, counts.data_ptr(), ws.data_ptr(), wsb,
                                                  self._stream()), "mh_dev_histogram_o1")
         return counts
 

@@ -62,6 +62,29 @@ def test_histogram_counter_overflow_path(mhc, oracle):
     assert np.array_equal(mhc.histogram_o0(data), oracle.histogram_o0(data))
 
 
+@pytest.mark.parametrize("n", [0, 5, 4096, (3 << 20) + 11])
+def test_histogram_with_workspace_equals_atomic_flush(mhc, oracle, n):
+    """mh_dev_histogram_o1 with its optional workspace (per-workgroup slabs + reduce kernel) and without
+    it (64-bit atomics) give the same counters, both equal to the oracle's; includes a 16-bit counter
+    overflow (a run of one pair longer than 32767)."""
+    import ctypes as C
+    lib = mhc.lib()
+    data = bytearray(zipf_bytes(n, 91))
+    if n > (1 << 20):
+        data[1000:1000 + 70000] = b"\x07" * 70000
+    data = bytes(data)
+    d_data = mhc.DeviceBuffer(n + 16, init=np.frombuffer(data + bytes(16), dtype=np.uint8))
+    wsb = lib.mh_dev_histogram_workspace(n)
+    d_ws = mhc.DeviceBuffer(max(wsb, 16))
+    got = []
+    for ws, nb in ((d_ws.ptr, wsb), (None, 0)):
+        d_counts = mhc.DeviceBuffer(65536 * 8, init=np.full(65536, 7, dtype=np.uint64))
+        mhc._check(lib.mh_dev_histogram_o1(d_data.ptr, n, 0x41, d_counts.ptr, ws, nb, None), "hist")
+        got.append(d_counts.download(np.uint64))
+    ref = oracle.histogram_o1(data, 0x41)
+    assert np.array_equal(got[0], ref) and np.array_equal(got[1], ref)
+
+
 def test_histogram_prev0(mhc, oracle):
     data = zipf_bytes(100000, 9)
     for prev0 in (0, 0x20, 0xFF):
