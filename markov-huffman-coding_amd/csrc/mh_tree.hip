@@ -64,6 +64,9 @@ __global__ __launch_bounds__(64) void tree_build_kernel(const unsigned long long
             }
             hkey[i] = key; hitem[i] = item;
         };
+        // Sift-down with the same comparisons in the same order, two levels per LDS round trip: the keys
+        // of both children AND of all four grandchildren are fetched together (the walk is one lane waiting
+        // on LDS latency at every level; entries below the current node are not modified while sinking).
         auto pop = [&]() -> uint16_t {
             const uint16_t top = hitem[0];
             --hn;
@@ -71,14 +74,28 @@ __global__ __launch_bounds__(64) void tree_build_kernel(const unsigned long long
             const uint16_t item = hitem[hn];
             int i = 0;
             for (;;) {
-                int l = 2 * i + 1, r = l + 1;
-                int pick = (r < hn && hkey[r] < hkey[l]) ? r : l;   // right only if strictly smaller
-                if (pick < hn && hkey[pick] < key) {
-                    hkey[i] = hkey[pick]; hitem[i] = hitem[pick];
-                    i = pick;
-                } else {
-                    break;
-                }
+                const int l = 2 * i + 1, r = l + 1;
+                if (l >= hn) break;
+                // children and grandchildren (indices clamped for the load, validity decided by < hn)
+                auto at = [&](int idx) -> unsigned long long { return hkey[idx < 259 ? idx : 259]; };
+                const unsigned long long kl = at(l), kr = at(r);
+                const unsigned long long kll = at(2 * l + 1), klr = at(2 * l + 2), krl = at(2 * r + 1), krr = at(2 * r + 2);
+                const uint16_t il = hitem[l], ir = hitem[r < 259 ? r : 259];
+                const bool right1 = r < hn && kr < kl;               // right only if strictly smaller
+                const int pick = right1 ? r : l;
+                const unsigned long long k1 = right1 ? kr : kl;
+                if (!(k1 < key)) break;
+                hkey[i] = k1; hitem[i] = right1 ? ir : il;
+                i = pick;
+                const int l2 = 2 * i + 1, r2 = l2 + 1;
+                if (l2 >= hn) break;
+                const unsigned long long kl2 = right1 ? krl : kll, kr2 = right1 ? krr : klr;
+                const bool right2 = r2 < hn && kr2 < kl2;
+                const int pick2 = right2 ? r2 : l2;
+                const unsigned long long k2 = right2 ? kr2 : kl2;
+                if (!(k2 < key)) break;
+                hkey[i] = k2; hitem[i] = hitem[pick2];
+                i = pick2;
             }
             hkey[i] = key; hitem[i] = item;
             return top;
