@@ -1347,7 +1347,6 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
     // instantiations: <SEC_LDS, SPR, DIRECT, K, GW, OUTB, PC, HC>
     // tables in LDS -> wide (2 streams, 64-byte granules and store bursts) or light (4 streams, 32-byte
     // granules and store bursts: 16-byte stores reach HBM as 32-byte writes, measured -14 %); L2 gathers -> light
-    void (*k_lds2[2])(DecParams) = {decode_kernel<true, 2, false, 2, 16, 4, 0, 0>, decode_kernel<true, 2, false, 2, 16, 4, 8, 0>};
     void (*k_lds2_light[2])(DecParams) = {decode_kernel<true, 2, false, 4, 8, 2, 0, 0>, decode_kernel<true, 2, false, 4, 8, 2, 8, 0>};
     auto k_lds4 = decode_kernel<true, 4, false, 2, 16, 4, 8, 0>;
     auto k_lds4_light = decode_kernel<true, 4, false, 4, 8, 2, 8, 0>;
@@ -1359,7 +1358,7 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
     auto r_l2d = decode_kernel<false, 2, true, 1, 8, 1, 0, 0, true>;
     static bool once = false;
     if (!once) {
-        const void *all[] = {(const void *)k_lds2[0], (const void *)k_lds2[1], (const void *)k_lds2_light[0], (const void *)k_lds2_light[1],
+        const void *all[] = {(const void *)k_lds2_light[0], (const void *)k_lds2_light[1],
                              (const void *)k_lds4, (const void *)k_lds4_light, (const void *)k_l2, (const void *)k_l2d[0], (const void *)k_l2d[1],
                              (const void *)r_lds, (const void *)r_l2, (const void *)r_l2d};
         for (const void *f : all) {
@@ -1371,16 +1370,18 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
     if (!p.sec_lds && p.P != 8) return hipErrorInvalidValue;       // the L2 layouts are built with P = 8
     size_t lds = 1024 + (size_t(256) << p.P) * 2 + (p.sec_lds ? ((size_t(p.nsec) * 2 + 15) & ~size_t(15)) : 0);
     if (lds > size_t(DEC_LDS_MAX)) return hipErrorInvalidValue;
-    // with the tables in LDS the kernel is bound by how the streams touch HBM once the payload is a
-    // large part of the traffic (measured: uniform data 1.6x faster with the wide streams, 41 %-ratio
-    // text 8 % slower): pick by compressed bits per symbol
-    const bool wide = p.sec_lds && p.n > 0 && p.nbits * 10 > p.n * 8 * 6;      // ratio > 0.6
+    // With the tables in LDS and NO second level (every code <= 8 bits) the kernel is bound by how the
+    // streams touch HBM once the payload is a large part of the traffic: uniform data runs 1.6x faster
+    // with the wide streams.  With a second level the dependent lookups dominate and four streams per
+    // lane win (measured with Zipf code lengths and all tables in LDS: 5.5 ms light, 7.7 ms wide per
+    // 4 GiB), as they do for low-ratio data (41 %-ratio text 8 % slower with the wide streams).
+    const bool short_codes = p.nsec == 0 && p.P == 8;
+    const bool wide = p.sec_lds && short_codes && p.n > 0 && p.nbits * 10 > p.n * 8 * 6;      // ratio > 0.6
     const uint64_t per_block = uint64_t(DEC_THREADS) * (wide ? 2 : 4);
     uint64_t want = (p.nchunks + per_block - 1) / per_block;
     int grid = int(want > uint64_t(cu_count()) ? uint64_t(cu_count()) : want);
-    const bool short_codes = p.nsec == 0 && p.P == 8;
     const int p8 = p.P == 8;
-    if (p.sec_lds && wide) hipLaunchKernelGGL(short_codes ? k_lds4 : k_lds2[p8], dim3(grid), dim3(DEC_THREADS), lds, st, p);
+    if (wide) hipLaunchKernelGGL(k_lds4, dim3(grid), dim3(DEC_THREADS), lds, st, p);
     else if (p.sec_lds) hipLaunchKernelGGL(short_codes ? k_lds4_light : k_lds2_light[p8], dim3(grid), dim3(DEC_THREADS), lds, st, p);
     else if (p.direct) hipLaunchKernelGGL(k_l2d[p.H == 8], dim3(grid), dim3(DEC_THREADS), lds, st, p);
     else hipLaunchKernelGGL(k_l2, dim3(grid), dim3(DEC_THREADS), lds, st, p);
