@@ -5,8 +5,11 @@ One "step" = one full pass of the hot path over one HBM-resident synthetic strea
     order-1 histogram -> [RCCL all-reduce of the 256x256 counts when N > 1] -> per-context tree build
     -> encode (payload + chunk index) -> decode (from payload + index)
 N = 1 workload: BASELINE.json configs[2] — 16 GiB of Zipf(s=1.1) bytes (the configuration the metric
-is quoted on; it fits one GPU).  N > 1: the stream is sharded into contiguous 16 GiB-per-GPU chunks
-(weak scaling); the only collective on the data path is the histogram all-reduce.
+is quoted on; it fits one GPU).  N > 1, default: the stream is sharded into contiguous 16 GiB-per-GPU
+chunks (weak scaling).  `--total-size 17179869184` instead splits ONE 16 GiB stream over the N GPUs
+(strong scaling: the metric's "16 GB byte stream at 1/2/4/8 GPUs"), and `--config 4` is BASELINE.json
+configs[3]: uniform random bytes, 8 GiB per GPU (64 GiB on 8).  Either way the only collective on the
+data path is the histogram all-reduce, and `config.workload` says which mode ran.
 
 Prints ONE JSON line (rank 0).  `value` = total uncompressed bytes of all ranks / step time (max over
 ranks), inputs resident in HBM.  `roofline` describes the dominant kernel: algorithmic HBM bytes per
@@ -35,11 +38,52 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 CHUNK = int(os.environ.get("MH_BENCH_CHUNK", "0"))   # 0: 1024 symbols, 256 below 2 GiB per GPU (keeps every CU busy)
 
 
-def zipf_cdf(device, s=1.1):
-    w = 1.0 / torch.arange(1, 257, dtype=torch.float64) ** s
-    cdf = torch.cumsum(w / w.sum(), 0)
-    cdf[-1] = 1.0
-    return cdf.to(torch.float32).to(device)
+# ---- counter-based generator: byte i of a stream is a pure function of (seed, i), so any
+# shard or slice can be regenerated independently, on the device (torch int64 ops) or on the host (numpy).
+_M64 = (1 << 64) - 1
+_GOLDEN = 0x9E3779B97F4A7C15
+
+
+def _s64(v):
+    """Python int -> the int64 with the same 64-bit pattern."""
+    v &= _M64
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def _lsr(x, k, xp):
+    """Logical right shift of int64 values (torch and numpy shift arithmetically)."""
+    return (x >> k) & ((1 << (64 - k)) - 1)
+
+
+def splitmix64(counter, seed, xp):
+    """splitmix64 finaliser of (counter + 1) * golden + seed * golden^2; int64 in, int64 out (bit pattern)."""
+    x = counter * _s64(_GOLDEN) + _s64((seed + 1) * _GOLDEN * _GOLDEN + _GOLDEN)
+    x = (x ^ _lsr(x, 30, xp)) * _s64(0xBF58476D1CE4E5B9)
+    x = (x ^ _lsr(x, 27, xp)) * _s64(0x94D049BB133111EB)
+    return x ^ _lsr(x, 31, xp)
+
+
+def zipf_thresholds(s=1.1):
+    """T[k] = round(CDF(k+1) * 2^32), k = 0..254: a 32-bit uniform u maps to the number of T[k] <= u."""
+    w = 1.0 / np.arange(1, 257, dtype=np.float64) ** s
+    cdf = np.cumsum(w / w.sum())
+    return np.minimum(np.rint(cdf[:255] * 4294967296.0), 4294967295.0).astype(np.int64)
+
+
+def synth_slice(kind, seed, first, count, device=None):
+    """Bytes [first, first + count) of the (kind, seed) stream: torch uint8 tensor on `device`, or a numpy
+    array when device is None.  Both give the same bytes."""
+    if device is None:
+        with np.errstate(over="ignore"):
+            z = splitmix64(np.arange(first, first + count, dtype=np.int64), seed, np)
+        if kind == "uniform":
+            return _lsr(z, 56, np).astype(np.uint8)
+        return np.searchsorted(zipf_thresholds(), _lsr(z, 32, np), side="right").astype(np.uint8)
+    z = splitmix64(torch.arange(first, first + count, dtype=torch.int64, device=device), seed, torch)
+    if kind == "uniform":
+        return _lsr(z, 56, torch).to(torch.uint8)
+    thr = torch.from_numpy(zipf_thresholds()).to(device)
+    return torch.searchsorted(thr, _lsr(z, 32, torch), right=True).to(torch.uint8)
 
 
 LOREM = ("lorem ipsum dolor sit amet consectetur adipiscing elit sed do eiusmod tempor incididunt ut labore et dolore "
@@ -68,33 +112,30 @@ def lorem_block(nbytes, seed):
     return bytes(out[:nbytes])
 
 
-def generate(kind, n, seed, first_slice, device):
-    """Seeded synthetic bytes, produced slice by slice (2^26 B) so any shard can be regenerated alone."""
+def generate(kind, n, seed, first_byte, device):
+    """Bytes [first_byte, first_byte + n) of the seeded synthetic stream, resident on `device`."""
     out = torch.empty(n, dtype=torch.uint8, device=device)
     if kind == "text":
-        # 8 MiB of generated text, tiled (the survey tiled the repo's ipsum file the same way)
-        base = torch.frombuffer(bytearray(lorem_block(min(n, 8 << 20), seed + first_slice)), dtype=torch.uint8).to(device)
-        reps = (n + base.numel() - 1) // base.numel()
-        out.copy_(base.repeat(reps)[:n])
+        # 8 MiB of generated text, tiled (the survey tiled the repo's ipsum file the same way); a shard starts
+        # at its own phase of the tiling, so shards concatenate into the single tiled stream
+        base = torch.frombuffer(bytearray(lorem_block(8 << 20, seed)), dtype=torch.uint8).to(device)
+        phase = first_byte % base.numel()
+        reps = (n + phase + base.numel() - 1) // base.numel()
+        out.copy_(base.repeat(reps)[phase:phase + n])
         return out
+    if kind not in ("zipf", "uniform"):
+        raise ValueError(kind)
     sl = 1 << 26
-    cdf = zipf_cdf(device)
-    g = torch.Generator(device=device)
-    for i, off in enumerate(range(0, n, sl)):
+    for off in range(0, n, sl):
         m = min(sl, n - off)
-        g.manual_seed(seed * 1000003 + first_slice + i)
-        if kind == "zipf":
-            u = torch.rand(m, device=device, generator=g)
-            out[off:off + m] = torch.searchsorted(cdf, u, right=False).clamp_(max=255).to(torch.uint8)
-        elif kind == "uniform":
-            out[off:off + m] = torch.randint(0, 256, (m,), device=device, generator=g, dtype=torch.uint8)
-        else:
-            raise ValueError(kind)
+        out[off:off + m] = synth_slice(kind, seed, first_byte + off, m, device)
     return out
 
 
 class Codec:
-    """Thin holder of device buffers + the C-ABI calls of one rank."""
+    """Thin holder of device buffers + the C-ABI calls of one rank.  Everything a step needs is allocated
+    here, once: the timed step allocates nothing and waits for the device exactly once (the 16 KiB of table
+    sizes the host needs to pick the decode-table layout)."""
 
     def __init__(self, mhc, n, device):
         self.mhc, self.lib, self.n, self.device = mhc, mhc.lib(), n, device
@@ -111,6 +152,9 @@ class Codec:
         self.enc_ws = torch.empty(self.enc_ws_bytes + 64, dtype=torch.uint8, device=device)
         self.dec_ws_bytes = int(self.lib.mh_dev_decode_workspace(0, n, CHUNK))
         self.dec_ws = torch.empty(self.dec_ws_bytes, dtype=torch.uint8, device=device)
+        self.model_ws_bytes = int(self.lib.mh_dev_model_workspace(1))
+        self.model_ws = torch.empty(self.model_ws_bytes, dtype=torch.uint8, device=device)
+        self.nbits_hint = 0          # last known payload length: steers the decode variant choice only
 
     def check(self, rc, what):
         if rc != 0:
@@ -119,12 +163,14 @@ class Codec:
     def stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-    def histogram(self, data, prev0):
-        self.check(self.lib.mh_dev_histogram_o1(data.data_ptr(), self.n, prev0, self.counts.data_ptr(), self.hist_ws.data_ptr(),
-                                                self.hist_ws_bytes, self.stream()), "hist")
+    def histogram(self, data, prev0, n=None):
+        self.check(self.lib.mh_dev_histogram_o1(data.data_ptr(), self.n if n is None else n, prev0, self.counts.data_ptr(),
+                                                self.hist_ws.data_ptr(), self.hist_ws_bytes, self.stream()), "hist")
 
     def build_model(self):
-        return self.mhc.Model.from_device_counts(self.counts.data_ptr(), 1, self.stream())
+        """Tables built on the device into the preallocated workspace: no allocation, one stream sync."""
+        return self.mhc.Model.from_device_counts_ws(self.counts.data_ptr(), 1, self.model_ws.data_ptr(), self.model_ws_bytes,
+                                                    self.stream())
 
     def payload_bits(self, model, counts, out):
         self.check(self.lib.mh_dev_payload_bits(model.handle, counts.data_ptr(), out.data_ptr(), self.stream()), "payload_bits")
@@ -138,12 +184,14 @@ class Codec:
                                              self.nbits.data_ptr(), self.index.data_ptr(), CHUNK, self.enc_ws.data_ptr(),
                                              self.enc_ws_bytes, self.stream()), "encode")
 
-    def decode(self, model, nbits):
-        self.check(self.lib.mh_dev_decode(model.handle, self.payload.data_ptr(), nbits, self.decoded.data_ptr(), self.n,
-                                          self.index.data_ptr(), CHUNK, self.dec_ws.data_ptr(), self.dec_ws_bytes, self.stream()), "decode")
+    def decode(self, model):
+        """The payload length stays on the device (self.nbits[0], written by the encoder)."""
+        self.check(self.lib.mh_dev_decode_dn(model.handle, self.payload.data_ptr(), self.nbits.data_ptr(), self.nbits_hint,
+                                             self.decoded.data_ptr(), self.n, self.index.data_ptr(), CHUNK, self.dec_ws.data_ptr(),
+                                             self.dec_ws_bytes, self.stream()), "decode")
 
 
-def cpu_baseline(mhc, model, sample, gpu_payload_prefix_check):
+def cpu_baseline(mhc, table_bytes, sample, gpu_payload_prefix_check):
     """Reference CPU path on a bounded sample: round-trip GB/s = bytes / (compress + decompress wall)."""
     from oracle import mh_oracle
     n = len(sample)
@@ -162,7 +210,7 @@ def cpu_baseline(mhc, model, sample, gpu_payload_prefix_check):
             ok = open(os.path.join(tmp, "d"), "rb").read() == sample
             # and the GPU stream vs the genuine reference with the GPU-built table on the same bytes
             with open(os.path.join(tmp, "gt"), "wb") as f:
-                f.write(model.table_bytes())
+                f.write(table_bytes)
             run([src, "-o", os.path.join(tmp, "gc"), "-e", os.path.join(tmp, "gt")])
             ref_stream = open(os.path.join(tmp, "gc"), "rb").read()[1:]
         kind = "reference"
@@ -173,7 +221,7 @@ def cpu_baseline(mhc, model, sample, gpu_payload_prefix_check):
         t1 = time.perf_counter()
         ok = om.decompress(blob) == sample
         t2 = time.perf_counter()
-        ref_stream = mh_oracle.Model.from_table(model.table_bytes()).compress(sample)[0][1:]
+        ref_stream = mh_oracle.Model.from_table(table_bytes).compress(sample)[0][1:]
         kind = "port"
     stream_ok = gpu_payload_prefix_check(ref_stream)
     return {
@@ -190,8 +238,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--size", type=int, default=16 << 30, help="bytes per GPU (default 16 GiB)")
-    ap.add_argument("--kind", default="zipf", choices=["zipf", "uniform", "text"])
+    ap.add_argument("--size", type=int, default=None, help="bytes per GPU, weak scaling (default 16 GiB)")
+    ap.add_argument("--total-size", type=int, default=None,
+                    help="strong scaling: ONE stream of this many bytes split into N contiguous shards (e.g. 17179869184)")
+    ap.add_argument("--config", type=int, default=3, choices=[3, 4],
+                    help="BASELINE.json configs[]: 3 (default) = 16 GiB Zipf(1.1) per GPU; 4 = uniform random, 8 GiB per GPU (64 GiB on 8)")
+    ap.add_argument("--kind", default=None, choices=["zipf", "uniform", "text"])
     ap.add_argument("--cpu-sample", type=int, default=256 << 20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -232,13 +284,23 @@ def main():
 
     mhc = entry.load_package()
     mhc.lib()                      # fails loudly if libmhc.so is missing: there is no fallback path
-    n = args.size
+    kind = args.kind or ("uniform" if args.config == 4 else "zipf")
+    # ---- what each rank holds: bytes [first, first + n) of ONE seeded stream
+    if args.total_size is not None:
+        mode, total = "strong", args.total_size
+        unit = 16                                  # shards start on 16-byte boundaries (device loads are 16-byte vectors)
+        units = (total + unit - 1) // unit
+        first = min(total, (units * rank // world) * unit)
+        n = min(total, (units * (rank + 1) // world) * unit) - first
+    else:
+        mode = "weak"
+        n = args.size if args.size is not None else ((8 << 30) if args.config == 4 else (16 << 30))
+        first, total = rank * n, n * world
     global CHUNK
     if CHUNK == 0:
         CHUNK = 1024 if n >= (2 << 30) else 256
-    seed = {"zipf": 2, "uniform": 3, "text": 1}[args.kind]     # C2 seed 1, C3 seed 2, C4 seed 3
-    slices_per_rank = (n + (1 << 26) - 1) >> 26
-    data = generate(args.kind, n, seed, rank * slices_per_rank, device)
+    seed = {"zipf": 2, "uniform": 3, "text": 1}[kind]     # C2 seed 1, C3 seed 2, C4 seed 3
+    data = generate(kind, n, seed, first, device)
     # context of each shard's first byte = last byte of the previous shard (' ' for rank 0)
     prev0 = 0x20
     if world > 1:
@@ -255,10 +317,9 @@ def main():
     ev = lambda: torch.cuda.Event(enable_timing=True)
     stage_ms = {"hist": 0.0, "allreduce": 0.0, "tree": 0.0, "encode": 0.0, "decode": 0.0}
     model = None
-    nbits = 0
 
     def step(record):
-        nonlocal model, nbits
+        nonlocal model
         e = [ev() for _ in range(6)]
         e[0].record()
         codec.histogram(data, prev0)
@@ -267,7 +328,7 @@ def main():
             local_counts.copy_(codec.counts)          # the shard's own histogram fixes its payload length
             all_reduce(codec.counts)                  # the one collective: 512 KiB sum over xGMI
         e[2].record()
-        model = codec.build_model()                   # syncs the stream once (small D2H of the counts)
+        model = codec.build_model()                   # the step's one host wait (16 KiB of table sizes)
         e[3].record()
         if world > 1:
             # placement before encoding: shard bits = local histogram . code lengths, all-gather,
@@ -279,8 +340,7 @@ def main():
         else:
             codec.encode(model, data, prev0)
         e[4].record()
-        nbits = int(codec.nbits[0].item())            # end position in the rank's buffer: the decoder's bound
-        codec.decode(model, nbits)
+        codec.decode(model)                           # reads the payload length where the encoder left it (HBM)
         e[5].record()
         torch.cuda.synchronize()
         if record:
@@ -289,6 +349,7 @@ def main():
 
     for _ in range(args.warmup):
         step(False)
+        codec.nbits_hint = int(codec.nbits[0].item())
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -305,21 +366,24 @@ def main():
         elapsed = float(t.item())
 
     # ---- correctness of what was timed (outside the timed region)
+    nbits = int(codec.nbits[0].item())
     rc = codec.lib.mh_dev_status(codec.enc_ws.data_ptr(), codec.stream())
     rc2 = codec.lib.mh_dev_status(codec.dec_ws.data_ptr(), codec.stream())
     round_trip = bool(rc == 0 and rc2 == 0 and torch.equal(codec.decoded, data))
     if world > 1:     # the shard ended where its histogram said it would: the ranks' payloads tile the global stream
-        round_trip = round_trip and int(codec.nbits[0].item()) == (int(start_bit.item()) & 7) + int(my_bits.item())
+        round_trip = round_trip and nbits == (int(start_bit.item()) & 7) + int(my_bits.item())
     ok = torch.tensor([1 if round_trip else 0], device=device)
+    tot_bits = torch.tensor([nbits - (int(start_bit.item()) & 7) if world > 1 else nbits], dtype=torch.int64, device=device)
     if world > 1:
         all_reduce(ok, op=dist.ReduceOp.MIN)
+        all_reduce(tot_bits)
     round_trip_all = bool(ok.item())
 
     if rank == 0:
         K = args.steps
         ms = {k: v / K for k, v in stage_ms.items()}
-        r = nbits / 8.0 / n
-        total_bytes = float(n) * world
+        r = nbits / 8.0 / max(n, 1)
+        total_bytes = float(total)
         gbps = total_bytes / (elapsed / K) / 1e9
         # algorithmic bytes per launch: hist 1, encode 1 + r, decode r + 1 per input byte
         kernels = {
@@ -336,14 +400,22 @@ def main():
             except Exception:
                 traffic = None
         ach = kernels[dom][0] / (kernels[dom][1] * 1e-3) / 1e9
+        kname = {"zipf": "Zipf(s=1.1)", "uniform": "uniform", "text": "Lorem-Ipsum-style ASCII"}[kind]
+        if mode == "weak":
+            workload = ("order-1 Markov-Huffman round trip (histogram+tree+encode+decode), %d GiB %s per GPU, "
+                        "chunk index every %d symbols" % (n >> 30, kname, CHUNK))
+        else:
+            workload = ("order-1 Markov-Huffman round trip (histogram+tree+encode+decode), ONE %.3f GiB %s stream split into %d "
+                        "contiguous shards (strong scaling), chunk index every %d symbols" % (total / 2.0 ** 30, kname, world, CHUNK))
         out = {
             "metric": "encode+decode GB/s on 16 GB byte stream, bit-exact round-trip",
             "value": round(gbps, 3), "unit": "GB/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / K * 1e3, 3), "higher_is_better": True, "scaling": mode,
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "order-1 Markov-Huffman round trip (histogram+tree+encode+decode), %d GiB %s per GPU, "
-                                   "chunk index every %d symbols" % (n >> 30, {"zipf": "Zipf(s=1.1)", "uniform": "uniform", "text": "Lorem-Ipsum-style ASCII"}[args.kind], CHUNK),
-                       "bytes_per_gpu": n, "sharding": "contiguous byte ranges, histogram all-reduce (RCCL)" if world > 1 else "single GPU"},
+            "config": {"workload": workload, "baseline_config": args.config, "bytes_per_gpu": n, "total_bytes": int(total),
+                       "generator": "counter-based splitmix64 (seed %d), byte i = f(seed, i): any shard regenerable alone" % seed
+                                    if kind != "text" else "8 MiB of seeded Lorem-Ipsum-style text, tiled",
+                       "sharding": "contiguous byte ranges, histogram all-reduce (RCCL)" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(kernels[dom][0])},
@@ -353,7 +425,7 @@ def main():
             "stage_GBps_input": {k: (round(n / (v * 1e-3) / 1e9, 2) if v > 0 else None) for k, v in ms.items()},
             "kernel_roofline_frac": {k: round(b / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if t > 0 else None for k, (b, t) in kernels.items()},
             "encode_read_roofline_frac": round(n / (ms["encode"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms["encode"] > 0 else None,
-            "compressed_ratio": round(r, 5), "round_trip_bit_exact": round_trip_all,
+            "compressed_ratio": round(r, 5), "total_payload_bits": int(tot_bits.item()), "round_trip_bit_exact": round_trip_all,
             "max_code_len": model.max_code_len,
             "decode_tables": dict(zip(("primary_bits", "secondary_entries", "in_lds"), model.decode_layout())),
         }
@@ -370,7 +442,14 @@ def main():
                 full = end_bits // 8
                 gpu = codec.payload[:full].cpu().numpy().tobytes()
                 return gpu == ref_stream[:full] and len(ref_stream) == (end_bits + 7) // 8
-            out["cpu_baseline"] = cpu_baseline(mhc, model, sample, prefix_check)
+            table = model.table_bytes()               # before the workspace is reused for the sample's histogram model
+            out["cpu_baseline"] = cpu_baseline(mhc, table, sample, prefix_check)
+            # the histogram kernel against the oracle's on the same sample (its LDS counter overflow path runs here)
+            from oracle import mh_oracle
+            codec.histogram(data, 0x20, sample_n)
+            torch.cuda.synchronize()
+            out["cpu_baseline"]["gpu_histogram_equals_cpu_histogram_on_sample"] = bool(
+                np.array_equal(codec.counts.cpu().numpy().astype(np.uint64), mh_oracle.histogram_o1(sample)))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

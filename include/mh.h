@@ -16,8 +16,11 @@
  *     exactly that.
  *   - the caller owns every buffer.  "mh_*" functions take HOST pointers and
  *     stage through HBM internally; "mh_dev_*" functions take DEVICE pointers
- *     plus a hipStream_t (as void*), never allocate, and never synchronise
- *     unless stated.
+ *     plus a hipStream_t (as void*) and neither allocate nor synchronise,
+ *     with the exceptions stated at their declarations: the model builders
+ *     (mh_dev_model_from_counts allocates and synchronises once,
+ *     mh_dev_model_from_counts_ws only synchronises once), mh_dev_build_index
+ *     and mh_dev_status.
  *   - all compute runs in hand-written HIP kernels for gfx950.  There is no
  *     CPU fallback: without a usable GPU every compute call returns
  *     MH_ERR_NO_DEVICE.
@@ -86,6 +89,12 @@ int mh_model_from_counts(const uint64_t *counts, int order, mh_model **out);
  * copy of the trees that table files and the query calls below need is made lazily, on first use.
  * Order 0 (one tree) takes the host route. */
 int mh_dev_model_from_counts(const uint64_t *d_counts, int order, void *stream, mh_model **out);
+/* The same (order 1 only) with every device byte of the model placed in a caller workspace of at least
+ * mh_dev_model_workspace(1) bytes (16-byte aligned): no allocation inside, and `stream` is synchronised
+ * exactly once.  The model borrows the workspace: keep it alive, and do not rebuild into it, until the
+ * model has been freed and the work that uses it has finished.  MH_ERR_CAPACITY when it is too small. */
+size_t mh_dev_model_workspace(int order);
+int mh_dev_model_from_counts_ws(const uint64_t *d_counts, int order, void *d_ws, size_t ws_bytes, void *stream, mh_model **out);
 
 /* Replaces the table-file constructors huffman_table(bitbuffer&) / markov_huffman_table(bitbuffer&)
  * (src/huffman.cpp:22-25,166-172; src/markov_huffman.cpp:15-25) and main()'s type sniffing on the
@@ -194,7 +203,7 @@ int mh_dev_histogram_o0(const uint8_t *d_data, size_t n, uint64_t *d_counts,
 
 size_t mh_dev_encode_workspace(size_t n);
 /* d_nbits: one uint64 (payload bits).  d_index: mh_index_entries(n, chunk_symbols) entries or NULL.
- * d_status: one int32, set non-zero by the device on a bounded-wait expiry (check after sync). */
+ * Errors found on the device (capacity overrun) go to the int32 at the start of d_ws: mh_dev_status(). */
 int mh_dev_encode(const mh_model *m, const uint8_t *d_data, size_t n, uint8_t prev0,
                   uint8_t *d_payload, size_t cap, uint64_t *d_nbits,
                   uint64_t *d_index, uint32_t chunk_symbols,
@@ -229,6 +238,13 @@ int mh_dev_decode(const mh_model *m, const uint8_t *d_payload, uint64_t nbits,
                   uint8_t *d_out, uint64_t n_symbols,
                   const uint64_t *d_index, uint32_t chunk_symbols,
                   void *d_ws, size_t ws_bytes, void *stream);
+/* mh_dev_decode for a payload whose length is still on the device (e.g. straight after mh_dev_encode, with
+ * no host round trip in between): the kernels read *d_nbits.  nbits_hint (0 = unknown) only steers the
+ * choice between kernel variants; results never depend on it. */
+int mh_dev_decode_dn(const mh_model *m, const uint8_t *d_payload, const uint64_t *d_nbits, uint64_t nbits_hint,
+                     uint8_t *d_out, uint64_t n_symbols,
+                     const uint64_t *d_index, uint32_t chunk_symbols,
+                     void *d_ws, size_t ws_bytes, void *stream);
 /* Index building for a stream without one (what the reference writes: src/coding.cpp:35-59 has no
  * index): parallel fixed-point iteration over 512-byte bit segments — each segment is decoded from a
  * guessed state and re-decoded while its predecessor's end state changes; Huffman streams

@@ -27,13 +27,14 @@ INDEX_BIT_MASK = 0x00FFFFFFFFFFFFFF
 EXPORTS = [
     "mh_strerror", "mh_last_hip_error", "mh_device_count", "mh_set_device",
     "mh_dev_malloc", "mh_dev_free", "mh_dev_upload", "mh_dev_download",
-    "mh_model_from_counts", "mh_dev_model_from_counts", "mh_model_from_table_bits", "mh_model_write_table",
+    "mh_model_from_counts", "mh_dev_model_from_counts", "mh_dev_model_workspace", "mh_dev_model_from_counts_ws",
+    "mh_model_from_table_bits", "mh_model_write_table",
     "mh_model_type", "mh_model_max_code_len", "mh_model_get_code", "mh_model_get_lut", "mh_model_decode_layout",
     "mh_model_image", "mh_model_free",
     "mh_histogram_o1", "mh_histogram_o0", "mh_encode", "mh_encode_bound", "mh_stream_header",
     "mh_stream_parse_header", "mh_decode",
     "mh_dev_histogram_workspace", "mh_dev_histogram_o1", "mh_dev_histogram_o0",
-    "mh_decode_to", "mh_model_payload_bits", "mh_dev_encode_workspace", "mh_dev_encode", "mh_dev_payload_bits", "mh_dev_encode_at", "mh_dev_decode_workspace", "mh_dev_decode",
+    "mh_decode_to", "mh_model_payload_bits", "mh_dev_encode_workspace", "mh_dev_encode", "mh_dev_payload_bits", "mh_dev_encode_at", "mh_dev_decode_workspace", "mh_dev_decode", "mh_dev_decode_dn",
     "mh_dev_build_index_workspace", "mh_dev_build_index", "mh_dev_status",
 ]
 
@@ -66,6 +67,9 @@ def lib():
         l.mh_dev_download.argtypes = [vp, vp, sz]
         l.mh_model_from_counts.argtypes = [vp, i32, C.POINTER(vp)]
         l.mh_dev_model_from_counts.argtypes = [vp, i32, vp, C.POINTER(vp)]
+        l.mh_dev_model_workspace.argtypes = [i32]
+        l.mh_dev_model_workspace.restype = sz
+        l.mh_dev_model_from_counts_ws.argtypes = [vp, i32, vp, sz, vp, C.POINTER(vp)]
         l.mh_model_from_table_bits.argtypes = [vp, sz, C.POINTER(vp)]
         l.mh_model_write_table.argtypes = [vp, vp, sz, psz]
         l.mh_model_type.argtypes = [vp]
@@ -97,6 +101,7 @@ def lib():
         l.mh_dev_decode_workspace.argtypes = [u64, u64, u32]
         l.mh_dev_decode_workspace.restype = sz
         l.mh_dev_decode.argtypes = [vp, vp, u64, vp, u64, vp, u32, vp, sz, vp]
+        l.mh_dev_decode_dn.argtypes = [vp, vp, vp, u64, vp, u64, vp, u32, vp, sz, vp]
         l.mh_dev_build_index_workspace.argtypes = [u64]
         l.mh_dev_build_index_workspace.restype = sz
         l.mh_dev_build_index.argtypes = [vp, vp, u64, u8, vp, u64, u32, vp, vp, sz, vp]
@@ -179,6 +184,15 @@ class Model:
     def from_device_counts(cls, d_counts_ptr, order, stream=None):
         h = C.c_void_p()
         _check(lib().mh_dev_model_from_counts(d_counts_ptr, order, stream, C.byref(h)), "mh_dev_model_from_counts")
+        return cls(h)
+
+    @classmethod
+    def from_device_counts_ws(cls, d_counts_ptr, order, d_ws_ptr, ws_bytes, stream=None):
+        """Model built into a caller workspace (no allocation inside, one stream sync); the caller keeps
+        the workspace alive for as long as the model is used."""
+        h = C.c_void_p()
+        _check(lib().mh_dev_model_from_counts_ws(d_counts_ptr, order, d_ws_ptr, ws_bytes, stream, C.byref(h)),
+               "mh_dev_model_from_counts_ws")
         return cls(h)
 
     @classmethod

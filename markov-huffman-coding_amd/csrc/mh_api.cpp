@@ -20,6 +20,7 @@ struct mh_model {
     int device = -1;
     // what the entry points need without touching the mirror
     int type = 1, max_len = 0, dec_bits = 8, dec_h = 0;
+    uint32_t len_gcd = 0;        // gcd of all code lengths (index builder: segment length is a multiple of it)
     bool dec_lds = true, dec_direct = false;
     uint32_t nsec = 0;
     // device build: node arrays stay on the device until somebody asks for the mirror
@@ -64,6 +65,11 @@ bool have_device() {
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+uint32_t gcd_u32(uint32_t a, uint32_t b) {
+    while (b) { const uint32_t t = a % b; a = b; b = t; }
+    return a;
+}
+
 int chunk_shift_of(uint32_t chunk_symbols) {
     if (chunk_symbols < MH_CHUNK_MIN || chunk_symbols > MH_CHUNK_MAX) return -1;
     if (chunk_symbols & (chunk_symbols - 1)) return -1;
@@ -99,6 +105,14 @@ int upload_model(mh_model *m) {
     m->dec_bits = m->packed.dec_bits; m->dec_h = m->packed.dec_h;
     m->dec_lds = m->packed.dec_lds; m->dec_direct = m->packed.dec_direct;
     m->nsec = uint32_t(m->packed.dec_sec.size());
+    // gcd of the code lengths, the 1-bit code of one-symbol contexts aside (src/huffman.cpp:154-162: such a
+    // context shifts the stream's phase once, it does not take the stream off the lattice of the others)
+    for (int c = 0; c < 256; ++c) {
+        int live = 0;
+        for (int sy = 0; sy < 256; ++sy) live += m->packed.len8[size_t(c) * 256 + sy] != 0;
+        if (live < 2) continue;
+        for (int sy = 0; sy < 256; ++sy) m->len_gcd = gcd_u32(m->len_gcd, m->packed.len8[size_t(c) * 256 + sy]);
+    }
     if (!have_device()) return MH_OK;
     if (m->max_len > mh::MAX_CODE_BITS) return MH_OK;   // compute calls report MH_ERR_CODE_TOO_LONG
     HIP_TRY(hipGetDevice(&m->device));
@@ -235,12 +249,26 @@ static int model_from_device_counts_via_host(const uint64_t *d_counts, int order
     return mh_model_from_counts(counts.data(), order, out);
 }
 
-int mh_dev_model_from_counts(const uint64_t *d_counts, int order, void *stream, mh_model **out) {
-    if (!d_counts || !out || (order != 0 && order != 1)) return MH_ERR_ARG;
-    if (!have_device()) return MH_ERR_NO_DEVICE;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    if (order == 0) return model_from_device_counts_via_host(d_counts, order, st, out);   // one tree: not worth a kernel
+// Fixed-size part of a device-built model: every image + the node arrays, each piece 256-byte aligned.
+namespace {
+struct BuildLayout { size_t off[12], fixed; };
+BuildLayout build_layout() {
+    const size_t nn = size_t(256) * mhk::TB_NODE_STRIDE;
+    const size_t sizes[12] = {65536 * 2, 65536, 65536, 65536 * 8, size_t(256) * mh::TREE_STRIDE * 4, 65536 * 2, 256 * 4,
+                              nn * 2, nn * 2, nn, nn, size_t(256) * mhk::TB_META_STRIDE * 4};
+    BuildLayout L;
+    size_t total = 0;
+    for (int i = 0; i < 12; ++i) { L.off[i] = total; total += (sizes[i] + 255) & ~size_t(255); }
+    L.fixed = total;
+    return L;
+}
+// second-level tables: at most 32767 uniform tables of 256 entries in the L2 layout (far less in the LDS layout)
+constexpr size_t MODEL_WS_SEC_BYTES = size_t(32768) * 256 * 2 + 64;
 
+// d_ws == nullptr: the model allocates (and owns) its device memory.  Otherwise it lives in the caller's
+// workspace: no allocation, and the stream is synchronised exactly once (16 KiB of table sizes come back
+// so that the host can pick the decode-table layout).
+int dev_model_build(const uint64_t *d_counts, void *d_ws, size_t ws_bytes, hipStream_t st, mh_model **out) {
     mh_model *m = new (std::nothrow) mh_model;
     if (!m) return MH_ERR_NOMEM;
     m->type = 1;
@@ -248,14 +276,16 @@ int mh_dev_model_from_counts(const uint64_t *d_counts, int order, void *stream, 
     auto fail = [&](int rc) { mh_model_free(m); return rc; };
 #define HIP_TRY_M(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(hip_fail(_e)); } while (0)
     HIP_TRY_M(hipGetDevice(&m->device));
-    // one block for every fixed-size image + the node arrays
-    const size_t nn = size_t(256) * mhk::TB_NODE_STRIDE;
-    const size_t sizes[] = {65536 * 2, 65536, 65536, 65536 * 8, size_t(256) * mh::TREE_STRIDE * 4, 65536 * 2, 256 * 4,
-                            nn * 2, nn * 2, nn, nn, size_t(256) * mhk::TB_META_STRIDE * 4};
-    size_t off[12], total = 0;
-    for (int i = 0; i < 12; ++i) { off[i] = total; total += (sizes[i] + 255) & ~size_t(255); }
-    HIP_TRY_M(hipMalloc(&m->d_build, total));
-    unsigned char *b = static_cast<unsigned char *>(m->d_build);
+    const BuildLayout L = build_layout();
+    unsigned char *b;
+    if (d_ws) {
+        if (!aligned16(d_ws) || ws_bytes < L.fixed + 64) return fail(MH_ERR_CAPACITY);
+        b = static_cast<unsigned char *>(d_ws);
+    } else {
+        HIP_TRY_M(hipMalloc(&m->d_build, L.fixed));
+        b = static_cast<unsigned char *>(m->d_build);
+    }
+    const size_t *off = L.off;
     m->d_enc16 = reinterpret_cast<uint16_t *>(b + off[0]);
     m->d_len8 = b + off[1];
     m->d_len_slot = b + off[2];
@@ -282,6 +312,9 @@ int mh_dev_model_from_counts(const uint64_t *d_counts, int order, void *stream, 
     for (int c = 0; c < 256; ++c) {
         const uint32_t *mt = &meta[size_t(c) * mhk::TB_META_STRIDE];
         m->max_len = std::max(m->max_len, int(mt[2]));
+        // mt[15]: bit l-1 = a code of l bits exists (bit 31: 32 or more); one-symbol contexts aside, as in upload_model()
+        for (uint32_t l = 1; l <= 32; ++l)
+            if (mt[15] & (1u << (l - 1))) m->len_gcd = gcd_u32(m->len_gcd, l == 32 ? 1u : l);
         ntab8 += mt[3];
         for (int P = 0; P < 9; ++P) { tot[P] += mt[4 + P]; worst[P] = std::max(worst[P], size_t(mt[4 + P])); }
         weight[c] = (uint64_t(mt[14]) << 32) | mt[13];
@@ -292,10 +325,7 @@ int mh_dev_model_from_counts(const uint64_t *d_counts, int order, void *stream, 
         if (worst[q] <= size_t(mh::DEC_SEC_MAX_PER_CTX) && (size_t(256) << q) + tot[q] <= size_t(mh::DEC_LDS_ENTRIES)) P = q;
     m->dec_lds = P != 0;
     if (!m->dec_lds) {
-        if (ntab8 > 32767) {                                  // general L2 layout: rare; let the host do it
-            mh_model_free(m);
-            return model_from_device_counts_via_host(d_counts, order, st, out);
-        }
+        if (ntab8 > 32767) return fail(MH_ERR_ARG - 100);       // general L2 layout: rare; the caller lets the host do it
         P = 8;
         m->dec_direct = true;
         m->dec_h = std::min(std::max(m->max_len - 8, 1), 8);
@@ -304,28 +334,51 @@ int mh_dev_model_from_counts(const uint64_t *d_counts, int order, void *stream, 
     int order_idx[256];
     for (int i = 0; i < 256; ++i) order_idx[i] = i;
     std::stable_sort(order_idx, order_idx + 256, [&](int a, int b2) { return weight[a] > weight[b2]; });
-    std::vector<uint32_t> sec_base(256, 0);
+    mhk::TreePackArgs pa{};
     size_t nsec = 0;
     for (int i = 0; i < 256; ++i) {
         const int c = order_idx[i];
         const uint32_t *mt = &meta[size_t(c) * mhk::TB_META_STRIDE];
-        sec_base[c] = uint32_t(nsec);
+        pa.sec_base_val[c] = uint32_t(nsec);                     // travels in the kernel arguments: no pageable copy to wait for
         nsec += m->dec_direct ? (size_t(mt[3]) << m->dec_h) : size_t(mt[4 + P]);
     }
     m->nsec = uint32_t(nsec);
     const size_t sec_bytes = ((nsec * 2 + 15) & ~size_t(15)) + 16;
-    HIP_TRY_M(hipMalloc(&m->d_sec_own, sec_bytes));
-    m->d_sec = static_cast<uint16_t *>(m->d_sec_own);
-    HIP_TRY_M(hipMemsetAsync(m->d_sec_own, 0, sec_bytes, st));
-    HIP_TRY_M(hipMemcpyAsync(m->d_sec_base, sec_base.data(), 256 * 4, hipMemcpyHostToDevice, st));
-    mhk::TreePackArgs pa{m->d_node_left, m->d_node_right, m->d_node_sym, d_node_height, m->d_meta, m->d_sec_base,
-                         uint32_t(P), m->dec_direct ? 1u : 0u, uint32_t(m->dec_h), 8u, m->d_prim, m->d_sec, m->d_tree};
+    if (d_ws) {
+        if (ws_bytes < L.fixed + sec_bytes) return fail(MH_ERR_CAPACITY);
+        m->d_sec = reinterpret_cast<uint16_t *>(b + L.fixed);
+    } else {
+        HIP_TRY_M(hipMalloc(&m->d_sec_own, sec_bytes));
+        m->d_sec = static_cast<uint16_t *>(m->d_sec_own);
+    }
+    HIP_TRY_M(hipMemsetAsync(m->d_sec, 0, sec_bytes, st));
+    pa.node_left = m->d_node_left; pa.node_right = m->d_node_right; pa.node_sym = m->d_node_sym; pa.node_height = d_node_height;
+    pa.ctx_meta = m->d_meta; pa.sec_base = m->d_sec_base;
+    pa.P = uint32_t(P); pa.direct = m->dec_direct ? 1u : 0u; pa.H = uint32_t(m->dec_h); pa.hcap = 8u;
+    pa.prim = m->d_prim; pa.sec = m->d_sec; pa.tree = m->d_tree;
     HIP_TRY_M(mhk::launch_tree_pack(pa, 256, st));
-    // sec_base lives in pageable host memory: make sure the copy has been consumed before it goes away
-    HIP_TRY_M(hipStreamSynchronize(st));
 #undef HIP_TRY_M
     *out = m;
     return MH_OK;
+}
+}  // namespace
+
+size_t mh_dev_model_workspace(int order) { return order == 1 ? build_layout().fixed + MODEL_WS_SEC_BYTES : 0; }
+
+int mh_dev_model_from_counts_ws(const uint64_t *d_counts, int order, void *d_ws, size_t ws_bytes, void *stream, mh_model **out) {
+    if (!d_counts || !out || order != 1 || !d_ws) return MH_ERR_ARG;
+    if (!have_device()) return MH_ERR_NO_DEVICE;
+    return dev_model_build(d_counts, d_ws, ws_bytes, static_cast<hipStream_t>(stream), out);
+}
+
+int mh_dev_model_from_counts(const uint64_t *d_counts, int order, void *stream, mh_model **out) {
+    if (!d_counts || !out || (order != 0 && order != 1)) return MH_ERR_ARG;
+    if (!have_device()) return MH_ERR_NO_DEVICE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (order == 0) return model_from_device_counts_via_host(d_counts, order, st, out);   // one tree: not worth a kernel
+    int rc = dev_model_build(d_counts, nullptr, 0, st, out);
+    if (rc == MH_ERR_ARG - 100) return model_from_device_counts_via_host(d_counts, order, st, out);
+    return rc;
 }
 
 int mh_model_from_table_bits(const uint8_t *bytes, size_t n, mh_model **out) {
@@ -475,8 +528,8 @@ size_t mh_dev_decode_workspace(uint64_t, uint64_t n_symbols, uint32_t chunk_symb
 
 size_t mh_dev_build_index_workspace(uint64_t nbits) { return mhk::build_index_workspace_bytes(nbits); }
 
-int mh_dev_decode(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, uint8_t *d_out, uint64_t n_symbols,
-                  const uint64_t *d_index, uint32_t chunk_symbols, void *d_ws, size_t ws_bytes, void *stream) {
+static int dev_decode(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, const uint64_t *d_nbits, uint8_t *d_out,
+                      uint64_t n_symbols, const uint64_t *d_index, uint32_t chunk_symbols, void *d_ws, size_t ws_bytes, void *stream) {
     if (!m || !d_ws || ws_bytes < 64) return MH_ERR_ARG;
     if (ws_bytes < mh_dev_decode_workspace(nbits, n_symbols, chunk_symbols)) return MH_ERR_ARG;
     if (n_symbols && (!d_payload || !d_out || !d_index)) return MH_ERR_ARG;
@@ -487,6 +540,7 @@ int mh_dev_decode(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, u
     if (!m->d_prim) return MH_ERR_NO_DEVICE;
     mhk::DecParams p{};
     p.payload = d_payload; p.payload_bytes = (nbits + 7) / 8; p.nbits = nbits;
+    p.d_nbits = reinterpret_cast<const unsigned long long *>(d_nbits);
     p.out = d_out; p.n = n_symbols;
     p.index = reinterpret_cast<const unsigned long long *>(d_index);
     p.nchunks = mh_index_entries(n_symbols, chunk_symbols);
@@ -496,6 +550,17 @@ int mh_dev_decode(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, u
     p.direct = m->dec_direct ? 1u : 0u; p.H = uint32_t(m->dec_h);
     HIP_TRY(mhk::launch_decode(p, d_ws, static_cast<hipStream_t>(stream)));
     return MH_OK;
+}
+
+int mh_dev_decode(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, uint8_t *d_out, uint64_t n_symbols,
+                  const uint64_t *d_index, uint32_t chunk_symbols, void *d_ws, size_t ws_bytes, void *stream) {
+    return dev_decode(m, d_payload, nbits, nullptr, d_out, n_symbols, d_index, chunk_symbols, d_ws, ws_bytes, stream);
+}
+
+int mh_dev_decode_dn(const mh_model *m, const uint8_t *d_payload, const uint64_t *d_nbits, uint64_t nbits_hint, uint8_t *d_out,
+                     uint64_t n_symbols, const uint64_t *d_index, uint32_t chunk_symbols, void *d_ws, size_t ws_bytes, void *stream) {
+    if (!d_nbits) return MH_ERR_ARG;
+    return dev_decode(m, d_payload, nbits_hint, d_nbits, d_out, n_symbols, d_index, chunk_symbols, d_ws, ws_bytes, stream);
 }
 
 int mh_dev_build_index(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, uint8_t prev0, uint64_t *d_index,
@@ -514,6 +579,7 @@ int mh_dev_build_index(const mh_model *m, const uint8_t *d_payload, uint64_t nbi
     p.prim = m->d_prim; p.sec = m->d_sec; p.sec_base = m->d_sec_base; p.tree = m->d_tree;
     p.P = uint32_t(m->dec_bits);
     p.direct = m->dec_direct ? 1u : 0u; p.H = uint32_t(m->dec_h);
+    p.len_gcd = m->len_gcd;
     HIP_TRY(mhk::launch_build_index(p, d_ws, static_cast<hipStream_t>(stream)));
     return MH_OK;
 }

@@ -64,7 +64,8 @@ struct EmitParams {
 struct DecParams {
     const uint8_t *payload;
     uint64_t payload_bytes;
-    uint64_t nbits;
+    uint64_t nbits;               // payload bits (a hint for the variant choice when d_nbits is set)
+    const unsigned long long *d_nbits;   // when not null the kernels read the payload length from here
     uint8_t *out;
     uint64_t n;                   // symbols to produce
     const unsigned long long *index;
@@ -103,14 +104,16 @@ struct IdxParams {
     unsigned int *changed;
     unsigned long long *seg_end_state, *seg_used, *seg_sym_start;
     uint32_t *seg_count;
-    uint32_t seg_shift;
+    uint32_t len_gcd;             // gcd of the model's code lengths (0/1: none)
+    uint32_t seg_bits;
     uint64_t nseg;
 };
 
 // ---- device tree build (mh_tree.hip)
 constexpr int TB_NODE_STRIDE = 520;   // >= 513 nodes per context
 constexpr int TB_META_STRIDE = 16;    // per context: nnodes, root, max_len, #inner nodes at depth 8,
-                                      // second-level sizes for P = 0..8 (table heights capped at 8), weight lo/hi
+                                      // second-level sizes for P = 0..8 (table heights capped at 8), weight lo/hi,
+                                      // bit mask of the code lengths in use (0 for a one-symbol context)
 struct TreeBuildOut {
     uint8_t *len8; unsigned long long *code64; uint16_t *enc16; uint8_t *len_slot;
     uint16_t *node_left, *node_right; uint8_t *node_sym, *node_height;
@@ -119,7 +122,8 @@ struct TreeBuildOut {
 struct TreePackArgs {
     const uint16_t *node_left, *node_right; const uint8_t *node_sym, *node_height;
     const uint32_t *ctx_meta;
-    const uint32_t *sec_base;     // 256, entry offsets chosen by the host
+    uint32_t *sec_base;           // 256: device copy of sec_base_val, written by the kernel (the decoders read it)
+    uint32_t sec_base_val[256];   // entry offsets chosen by the host
     uint32_t P, direct, H, hcap;
     uint16_t *prim, *sec; uint32_t *tree;
 };

@@ -1,17 +1,21 @@
 // mh_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the Markov-Huffman hot path.
 //
-//   hist_o1_kernel     256x256 conditional histogram, LDS-resident packed counters        (a1)
-//   hist_o0_kernel     256-bin histogram                                                  (a2)
-//   encode_kernel      single pass: LDS codeword table, wave prefix-sum of bit lengths,
-//                      LDS bit assembly, decoupled look-back across tiles, coalesced store (a9-a12)
-//   decode_kernel      LDS 8-bit LUTs per context + tree-walk fallback, one lane per chunk (a13-a15)
-//   index_sync/fill    parallel index builder for streams that come without an index      (N1)
+//   hist_o1_kernel     256x256 conditional histogram, LDS-resident packed counters (+ slab reduce)   (a1)
+//   hist_o0_kernel     256-bin histogram                                                            (a2)
+//   enc_len_kernel     code-length sum per 4 KiB wave-tile (LDS length table)                       (a9-a10)
+//   scan_*             exclusive prefix over the wave-tile sums -> absolute bit offsets
+//   enc_emit_kernel    LDS codeword table, wave prefix-sum of bit lengths (DPP), bits OR-ed into a
+//                      wave-private LDS image, byte-swapped coalesced dword stores, seam atomics   (a9-a12)
+//   decode_kernel      two-level decode tables (level 1 in LDS = the reference's 8-bit LUT), K chunks
+//                      per lane, granule FIFO input, redo pass with the tree walk                  (a13-a15)
+//   index_sync/fill    parallel index builder for streams that come without an index              (N1)
 //
 // (aN) = row of SURVEY.md §8(a).  All integer/bit work: no MFMA.  No CUDA idioms: waves are 64 wide,
-// cross-lane traffic uses __shfl_up/__ballot on 64 lanes, inter-workgroup hand-off uses single 8-byte
-// agent-scope relaxed atomics (the data is the flag).
+// cross-lane traffic uses DPP / __shfl / __ballot on 64 lanes; workgroups never wait for each other.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <mutex>
 
 #include "mh_kernels.h"
 #include "mh_model.hpp"
@@ -971,6 +975,10 @@ template <bool SEC_LDS, int SPR, bool DIRECT, int K, int GW, int OUTB, int PC, i
 __global__ __launch_bounds__(NT) void decode_kernel(DecParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (REDO && p.redo[0] == 0) return;                         // the usual case: nothing was handed over
+    if (p.d_nbits) {                                            // payload length still on the device (mh_dev_decode_dn)
+        p.nbits = *p.d_nbits;
+        p.payload_bytes = (p.nbits + 7) >> 3;
+    }
     // LDS: sec_base u32[256] | prim u16[256 << P] | sec u16[nsec] (only when the model's tables fit)
     uint32_t *sub_base = reinterpret_cast<uint32_t *>(smem);
     uint16_t *lut = reinterpret_cast<uint16_t *>(smem + 1024);
@@ -1088,7 +1096,7 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecParams p) {
 
 // ---- index builder for streams that come without an index ---------------------------------------
 // The reference's stream has no index (src/coding.cpp:35-59) and the decoder state is (bit position,
-// previous byte).  Parallel reconstruction by fixed-point iteration over bit segments of 2^seg_shift
+// previous byte).  Parallel reconstruction by fixed-point iteration over bit segments of seg_bits
 // bits: segment i's start state is segment i-1's end state; every segment starts from a guess and is
 // re-decoded whenever its predecessor's end state changes.  Segment 0 is exact after pass 0, and
 // Huffman streams re-synchronise after a few symbols, so a handful of passes converge; a pass that
@@ -1122,16 +1130,18 @@ __device__ __forceinline__ uint64_t walk_segment(const IdxParams &p, const DecTa
     return st_pack(prev, pos);
 }
 
-__global__ __launch_bounds__(256) void index_sync_kernel(IdxParams p, uint32_t iter) {
-    if (iter > 0 && p.changed[iter - 1] == 0) return;                  // already at the fixed point
+// `first`: first pass of an instance (every segment starts from its guess, at bit i * seg_bits + phase);
+// later passes re-decode only the segments whose predecessor's end state has changed.
+__global__ __launch_bounds__(256) void index_sync_kernel(IdxParams p, uint32_t iter, uint32_t first, uint32_t phase) {
+    if (!first && p.changed[iter - 1] == 0) return;                    // already at the fixed point
     const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= p.nseg) return;
-    const uint64_t seg_end = ((i + 1) << p.seg_shift) < p.nbits ? ((i + 1) << p.seg_shift) : p.nbits;
+    const uint64_t seg_end = ((i + 1) * p.seg_bits) < p.nbits ? ((i + 1) * p.seg_bits) : p.nbits;
     uint64_t start;
     if (i == 0) start = st_pack(p.prev0, 0);
-    else if (iter == 0) start = st_pack(0x20, i << p.seg_shift);
+    else if (first) start = st_pack(0x20, i * p.seg_bits + phase);
     else start = __hip_atomic_load(&p.seg_end_state[i - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (iter > 0 && start == p.seg_used[i]) return;                    // same input as last time
+    if (!first && start == p.seg_used[i]) return;                      // same input as last time
     const BitSrc src{p.payload, p.payload_bytes >> 2, p.payload_bytes};
     const DecTables tabs{p.sec, p.tree, p.P, p.direct, p.H};
     uint32_t count;
@@ -1159,7 +1169,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void index_scan_add_kernel(unsigned l
 __global__ __launch_bounds__(256) void index_fill_kernel(IdxParams p) {
     const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= p.nseg) return;
-    const uint64_t seg_end = ((i + 1) << p.seg_shift) < p.nbits ? ((i + 1) << p.seg_shift) : p.nbits;
+    const uint64_t seg_end = ((i + 1) * p.seg_bits) < p.nbits ? ((i + 1) * p.seg_bits) : p.nbits;
     const uint64_t start = i == 0 ? st_pack(p.prev0, 0) : p.seg_end_state[i - 1];
     const uint64_t base = p.seg_sym_start[i];
     const uint64_t smask = (1ull << p.chunk_shift) - 1;
@@ -1212,20 +1222,47 @@ __global__ void build_index_kernel(IdxParams p) {
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-static int g_cu_count = 0;
+// Per-device launch state.  hipFuncSetAttribute (dynamic LDS above 64 KiB) is a per-device setting and the
+// CU count differs between devices, so both are keyed by the device current at the call; a mutex makes
+// the first call on a device safe from several threads (include/mh.h: models are thread-shareable and
+// mh_set_device() may switch devices inside one process).
+constexpr int MAX_DEVICES = 64;
+struct DeviceState {
+    int cu_count = 0;
+    bool hist_ready = false, encode_ready = false, decode_ready = false;
+};
+static DeviceState g_dev[MAX_DEVICES];
+static std::mutex g_dev_mu;
+
+static DeviceState &device_state() {          // caller holds g_dev_mu
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) dev = 0;
+    DeviceState &d = g_dev[dev];
+    if (d.cu_count == 0) {
+        hipDeviceProp_t prop;
+        d.cu_count = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return d;
+}
 
 static int cu_count() {
-    if (g_cu_count == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        g_cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    return g_cu_count;
+    std::lock_guard<std::mutex> lock(g_dev_mu);
+    return device_state().cu_count;
 }
 
 static hipError_t allow_lds(const void *fn, int bytes) {
     return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+// Runs `setup` once per device (under the lock); `flag` selects the DeviceState member.
+template <typename F>
+static hipError_t once_per_device(bool DeviceState::*flag, F setup) {
+    std::lock_guard<std::mutex> lock(g_dev_mu);
+    DeviceState &d = device_state();
+    if (d.*flag) return hipSuccess;
+    hipError_t e = setup();
+    if (e == hipSuccess) d.*flag = true;
+    return e;
 }
 
 size_t hist_workspace_bytes() { return size_t(cu_count()) * 32768u * 4u; }
@@ -1234,8 +1271,8 @@ hipError_t launch_hist_o1(const uint8_t *d_data, uint64_t n, uint32_t prev0, uns
                           hipStream_t st) {
     hipError_t e = hipMemsetAsync(d_counts, 0, 65536 * sizeof(unsigned long long), st);
     if (e != hipSuccess || n == 0) return e;
-    static bool once = false;
-    if (!once) { e = allow_lds(reinterpret_cast<const void *>(hist_o1_kernel), HIST_LDS_BYTES); if (e != hipSuccess) return e; once = true; }
+    e = once_per_device(&DeviceState::hist_ready, [] { return allow_lds(reinterpret_cast<const void *>(hist_o1_kernel), HIST_LDS_BYTES); });
+    if (e != hipSuccess) return e;
     uint64_t nvec = n >> 4;
     uint64_t want = (nvec + HIST_THREADS - 1) / HIST_THREADS;
     int grid = int(want < 1 ? 1 : (want > uint64_t(cu_count()) ? uint64_t(cu_count()) : want));
@@ -1312,12 +1349,11 @@ hipError_t launch_encode(const EncodeArgs &a, void *d_ws, hipStream_t st) {
         hipLaunchKernelGGL(empty_payload_kernel, dim3(1), dim3(1), 0, st, a.start_bit, a.nbits, a.out, a.cap);
         return hipGetLastError();
     }
-    static bool once = false;
-    if (!once) {
-        e = allow_lds(reinterpret_cast<const void *>(enc_len_kernel), LEN_LDS_BYTES); if (e != hipSuccess) return e;
-        e = allow_lds(reinterpret_cast<const void *>(enc_emit_kernel), EMIT_LDS_BYTES); if (e != hipSuccess) return e;
-        once = true;
-    }
+    e = once_per_device(&DeviceState::encode_ready, [] {
+        hipError_t r = allow_lds(reinterpret_cast<const void *>(enc_len_kernel), LEN_LDS_BYTES);
+        return r != hipSuccess ? r : allow_lds(reinterpret_cast<const void *>(enc_emit_kernel), EMIT_LDS_BYTES);
+    });
+    if (e != hipSuccess) return e;
     uint32_t *wt_bits = reinterpret_cast<uint32_t *>(ws + L.off_bits);
     unsigned long long *wt_start = reinterpret_cast<unsigned long long *>(ws + L.off_start);
     unsigned long long *blk_sum = reinterpret_cast<unsigned long long *>(ws + L.off_blk);
@@ -1356,17 +1392,17 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
     auto r_lds = decode_kernel<true, 2, false, 1, 8, 1, 0, 0, true>;
     auto r_l2 = decode_kernel<false, 2, false, 1, 8, 1, 0, 0, true>;
     auto r_l2d = decode_kernel<false, 2, true, 1, 8, 1, 0, 0, true>;
-    static bool once = false;
-    if (!once) {
+    e = once_per_device(&DeviceState::decode_ready, [&] {
         const void *all[] = {(const void *)k_lds2_light[0], (const void *)k_lds2_light[1],
                              (const void *)k_lds4, (const void *)k_lds4_light, (const void *)k_l2, (const void *)k_l2d[0], (const void *)k_l2d[1],
                              (const void *)r_lds, (const void *)r_l2, (const void *)r_l2d};
         for (const void *f : all) {
-            e = allow_lds(f, DEC_LDS_MAX);
-            if (e != hipSuccess) return e;
+            hipError_t r = allow_lds(f, DEC_LDS_MAX);
+            if (r != hipSuccess) return r;
         }
-        once = true;
-    }
+        return hipSuccess;
+    });
+    if (e != hipSuccess) return e;
     if (!p.sec_lds && p.P != 8) return hipErrorInvalidValue;       // the L2 layouts are built with P = 8
     size_t lds = 1024 + (size_t(256) << p.P) * 2 + (p.sec_lds ? ((size_t(p.nsec) * 2 + 15) & ~size_t(15)) : 0);
     if (lds > size_t(DEC_LDS_MAX)) return hipErrorInvalidValue;
@@ -1396,12 +1432,18 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
 
 // workspace: [0,64) status | changed u32[IDX_MAX_PASSES] | end_state u64[nseg] | used u64[nseg] |
 //            count u32[nseg] | sym_start u64[nseg] | blk_sum u64[nblk + 1]
-constexpr uint32_t IDX_SEG_SHIFT = 12;         // 4096-bit (512-byte) segments
+// Segments are ~4096 bits (512 bytes) long, rounded DOWN to a multiple of the gcd g of the model's code
+// lengths: when every code length is a multiple of g > 1 (fixed-length codes of 3, 5, 6, 7 bits: a
+// near-uniform 8-, 32-, 64- or 128-symbol alphabet such as base64 text), code boundaries only occur at
+// multiples of g, and a guessed start that is off that lattice can never re-synchronise: each pass would
+// then fix a single segment.  With the guesses on the lattice such streams synchronise at once.
+constexpr uint32_t IDX_SEG_BITS = 4096;
+constexpr uint32_t IDX_SEG_BITS_MIN = IDX_SEG_BITS - 64;       // smallest segment any gcd <= 64 gives (workspace sizing)
 constexpr uint32_t IDX_MAX_PASSES = 96;
 struct IdxWs { size_t off_changed, off_end, off_used, off_count, off_start, off_blk, total; uint64_t nseg, nblk; };
 static IdxWs idx_ws_layout(uint64_t nbits) {
     IdxWs w;
-    w.nseg = (nbits + (1ull << IDX_SEG_SHIFT) - 1) >> IDX_SEG_SHIFT;
+    w.nseg = (nbits + IDX_SEG_BITS_MIN - 1) / IDX_SEG_BITS_MIN;  // capacity; the launch uses the model's segment length
     w.nblk = (w.nseg + SCAN_BLOCK - 1) / SCAN_BLOCK;
     auto up = [](size_t v) { return (v + 63) & ~size_t(63); };
     w.off_changed = 64;
@@ -1425,32 +1467,51 @@ hipError_t launch_build_index(IdxParams p, void *d_ws, hipStream_t st) {
     p.seg_used = reinterpret_cast<unsigned long long *>(ws + L.off_used);
     p.seg_count = reinterpret_cast<uint32_t *>(ws + L.off_count);
     p.seg_sym_start = reinterpret_cast<unsigned long long *>(ws + L.off_start);
-    p.seg_shift = IDX_SEG_SHIFT;
-    p.nseg = L.nseg;
+    const uint32_t g = p.len_gcd >= 1 && p.len_gcd <= 64 ? p.len_gcd : 1;
+    p.seg_bits = IDX_SEG_BITS - IDX_SEG_BITS % g;
+    p.nseg = (p.nbits + p.seg_bits - 1) / p.seg_bits;          // <= L.nseg
     hipError_t e = hipMemsetAsync(ws, 0, L.off_end, st);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(p.n_symbols, 0, 8, st);
     if (e != hipSuccess || p.nbits == 0) return e;
-    const unsigned grid = unsigned((L.nseg + 255) / 256);
+    const unsigned grid = unsigned((p.nseg + 255) / 256);
+    const uint64_t nblk = (p.nseg + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    // One instance of the iteration = a first pass from guessed starts + passes that chase the changes.
+    // g == 1: a single instance with the whole pass budget.  g > 1 (every code length a multiple of g): the
+    // guesses of an instance all sit on one residue class i * seg_bits + phase (seg_bits is a multiple of g);
+    // the stream's own class is set by whatever came before (e.g. a 1-bit code for the very first symbol,
+    // whose context ' ' has a single successor), so the classes are tried in turn with a short budget each;
+    // the right one converges in two or three passes.  If none does, the last instance runs on to the pass
+    // cap and the sequential walk below is the last resort.
     bool converged = false;
-    for (uint32_t it = 0; it < IDX_MAX_PASSES && !converged;) {
-        const uint32_t batch_end = it + 8 < IDX_MAX_PASSES ? it + 8 : IDX_MAX_PASSES;
-        for (; it < batch_end; ++it) hipLaunchKernelGGL(index_sync_kernel, dim3(grid), dim3(256), 0, st, p, it);
-        unsigned int last = 1;
-        e = hipMemcpyAsync(&last, p.changed + (it - 1), 4, hipMemcpyDeviceToHost, st);
-        if (e != hipSuccess) return e;
-        e = hipStreamSynchronize(st);
-        if (e != hipSuccess) return e;
-        converged = last == 0;
+    const uint32_t nphase = g > 1 ? (g < 16u ? g : 16u) : 1u;
+    uint32_t it = 0;
+    for (uint32_t phase = 0; phase < nphase && !converged; ++phase) {
+        const bool last_instance = phase + 1 == nphase;
+        const uint32_t budget_end = last_instance ? IDX_MAX_PASSES : (it + 5 < IDX_MAX_PASSES ? it + 5 : IDX_MAX_PASSES);
+        bool first = true;
+        while (it < budget_end && !converged) {
+            const uint32_t batch_end = it + 8 < budget_end ? it + 8 : budget_end;
+            for (; it < batch_end; ++it) {
+                hipLaunchKernelGGL(index_sync_kernel, dim3(grid), dim3(256), 0, st, p, it, first ? 1u : 0u, phase);
+                first = false;
+            }
+            unsigned int last = 1;
+            e = hipMemcpyAsync(&last, p.changed + (it - 1), 4, hipMemcpyDeviceToHost, st);
+            if (e != hipSuccess) return e;
+            e = hipStreamSynchronize(st);
+            if (e != hipSuccess) return e;
+            converged = last == 0;
+        }
     }
     if (!converged) {      // segments that never re-synchronise: do it the slow, certain way
         hipLaunchKernelGGL(build_index_kernel, dim3(1), dim3(64), 0, st, p);
         return hipGetLastError();
     }
     unsigned long long *blk_sum = reinterpret_cast<unsigned long long *>(ws + L.off_blk);
-    hipLaunchKernelGGL(scan_local_kernel, dim3(unsigned(L.nblk)), dim3(SCAN_THREADS), 0, st, p.seg_count, L.nseg, p.seg_sym_start, blk_sum);
-    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, blk_sum, L.nblk, static_cast<const unsigned long long *>(nullptr));
-    hipLaunchKernelGGL(index_scan_add_kernel, dim3(unsigned(L.nblk)), dim3(SCAN_THREADS), 0, st, p.seg_sym_start, blk_sum, L.nseg, L.nblk, p.n_symbols);
+    hipLaunchKernelGGL(scan_local_kernel, dim3(unsigned(nblk)), dim3(SCAN_THREADS), 0, st, p.seg_count, p.nseg, p.seg_sym_start, blk_sum);
+    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, blk_sum, nblk, static_cast<const unsigned long long *>(nullptr));
+    hipLaunchKernelGGL(index_scan_add_kernel, dim3(unsigned(nblk)), dim3(SCAN_THREADS), 0, st, p.seg_sym_start, blk_sum, p.nseg, nblk, p.n_symbols);
     hipLaunchKernelGGL(index_fill_kernel, dim3(grid), dim3(256), 0, st, p);
     return hipGetLastError();
 }

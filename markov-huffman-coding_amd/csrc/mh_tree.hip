@@ -37,23 +37,89 @@ __global__ __launch_bounds__(64) void tree_build_kernel(const unsigned long long
     __shared__ uint8_t olen[256];
     __shared__ unsigned long long ocode[256];
     __shared__ uint32_t prof[9];
-    __shared__ uint32_t s_nn, s_root, s_single, s_ntab8, s_maxlen;
+    __shared__ uint32_t s_nn, s_root, s_single, s_ntab8, s_maxlen, s_tie;
 
     unsigned long long wsum = 0;
     for (uint32_t i = lane; i < 256; i += 64) {
-        cnt[i] = counts[c * 256 + i];
+        cnt[i] = counts[size_t(c) * 256 + i];
         wsum += cnt[i];
         olen[i] = 0;
         ocode[i] = 0;
     }
     for (int d = 32; d >= 1; d >>= 1) wsum += __shfl_xor(wsum, d);
     if (lane < 9) prof[lane] = 0;
-    if (lane == 0) { s_ntab8 = 0; s_maxlen = 0; s_single = 0; }
+    if (lane == 0) { s_ntab8 = 0; s_maxlen = 0; s_single = 0; s_tie = 0; }
     __syncthreads();
 
-    if (lane == 0) {
+    // ---- leaves, in ascending symbol order (src/huffman.cpp:134-138): node id = rank among the non-zero counts
+    uint32_t nleaf = 0;
+    for (uint32_t i = 0; i < 4; ++i) {
+        const uint32_t s = i * 64 + lane;
+        const bool nz = cnt[s] != 0;
+        const unsigned long long m = __ballot(nz);
+        const uint32_t pos = nleaf + __popcll(m & ((1ull << lane) - 1ull));
+        if (nz) {
+            left[pos] = right[pos] = NONE; parent[pos] = NONE; height[pos] = 0; sym[pos] = uint8_t(s); weight[pos] = cnt[s];
+        }
+        nleaf += __popcll(m);
+    }
+    // ---- fast path: with pairwise distinct keys at every extraction the heap's pop order IS the sorted
+    // order, whatever its internal mechanics (src/min_pq.tpp), so the merge sequence follows from the
+    // sorted leaves and the queue of merged nodes (whose weights are created in non-decreasing order).
+    // Any equal pair among the three smallest keys of a step makes the reference's choice depend on
+    // the heap layout: such a context is rebuilt by the exact heap emulation below.
+    for (uint32_t i = lane; i < 256; i += 64) {
+        hkey[i] = i < nleaf ? weight[i] : ~0ull;                  // hkey / hitem double as the sort buffer
+        hitem[i] = uint16_t(i);
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= 256; k <<= 1) {                      // bitonic sort of 256 (key, id) pairs, ascending
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = lane; t < 128; t += 64) {
+                const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+                const bool up = (lo & k) == 0;
+                const unsigned long long a = hkey[lo], b = hkey[hi];
+                const uint16_t ia = hitem[lo], ib = hitem[hi];
+                const bool gt = a > b || (a == b && ia > ib);
+                if (gt == up) { hkey[lo] = b; hkey[hi] = a; hitem[lo] = ib; hitem[hi] = ia; }
+            }
+            __syncthreads();
+        }
+    }
+    if (lane == 0 && nleaf > 1) {
+        uint32_t i1 = 0, i2 = nleaf, nn = nleaf;                   // heads of the leaf queue and of the merged-node queue
+        bool tie = false;
+        auto key1 = [&](uint32_t i) -> unsigned long long { return i < nleaf ? hkey[i] : ~0ull; };
+        auto key2 = [&](uint32_t i) -> unsigned long long { return i < nn ? weight[i] : ~0ull; };
+        for (uint32_t step = 0; step + 1 < nleaf; ++step) {
+            uint32_t pick[2];
+            unsigned long long pk[2];
+            for (int q = 0; q < 2; ++q) {
+                const unsigned long long k1 = key1(i1), k2 = key2(i2);
+                tie |= k1 == k2;                                   // both queues non-empty here or one key is ~0 (counts never reach it)
+                if (k1 < k2) { pick[q] = hitem[i1]; pk[q] = k1; ++i1; } else { pick[q] = i2; pk[q] = k2; ++i2; }
+            }
+            const unsigned long long k3a = key1(i1), k3b = key2(i2);
+            const unsigned long long k3 = k3a < k3b ? k3a : k3b;
+            tie |= pk[0] == pk[1] || pk[1] == k3;
+            uint32_t a = pick[0], b = pick[1];
+            if (height[a] > height[b]) { const uint32_t t = a; a = b; b = t; }     // src/huffman.cpp:147-149
+            left[nn] = uint16_t(a); right[nn] = uint16_t(b); parent[nn] = NONE; sym[nn] = 0;
+            weight[nn] = weight[a] + weight[b];
+            height[nn] = uint16_t((height[a] > height[b] ? height[a] : height[b]) + 1);
+            parent[a] = parent[b] = uint16_t(nn);
+            ++nn;
+        }
+        s_tie = tie ? 1u : 0u;
+        s_nn = nn;
+        s_root = nn - 1;
+    }
+    __syncthreads();
+
+    if (lane == 0 && (nleaf <= 1 || s_tie)) {
         // ---- exact heap emulation (same comparisons in the same order as swap-based swim/sink)
-        int nn = 0, hn = 0;
+        int nn = int(nleaf), hn = 0;
+        for (int i = 0; i < nn; ++i) parent[i] = NONE;             // the fast path may have linked the leaves
         auto push = [&](unsigned long long key, uint16_t item) {
             int i = hn++;
             while (i != 0) {
@@ -100,13 +166,7 @@ __global__ __launch_bounds__(64) void tree_build_kernel(const unsigned long long
             hkey[i] = key; hitem[i] = item;
             return top;
         };
-        for (int s = 0; s < 256; ++s) {                           // src/huffman.cpp:134-138
-            if (cnt[s]) {
-                left[nn] = right[nn] = NONE; parent[nn] = NONE; height[nn] = 0; sym[nn] = uint8_t(s); weight[nn] = cnt[s];
-                push(cnt[s], uint16_t(nn));
-                ++nn;
-            }
-        }
+        for (int i = 0; i < nn; ++i) push(weight[i], uint16_t(i));   // src/huffman.cpp:134-138 (ascending symbol order)
         int root = -1;
         if (hn > 0) {
             while (hn > 1) {                                      // :143-151
@@ -166,8 +226,10 @@ __global__ __launch_bounds__(64) void tree_build_kernel(const unsigned long long
     __syncthreads();
 
     // ---- outputs
+    uint32_t lenmask = 0;                    // bit l-1 for every code length l < 32 in use, bit 31 for longer ones
     for (uint32_t s = lane; s < 256; s += 64) {
         const uint32_t l = olen[s];
+        if (l) lenmask |= 1u << (l < 32u ? l - 1u : 31u);
         const unsigned long long cd = ocode[s];
         o.len8[c * 256 + s] = uint8_t(l);
         o.code64[c * 256 + s] = cd;
@@ -185,11 +247,13 @@ __global__ __launch_bounds__(64) void tree_build_kernel(const unsigned long long
         o.node_sym[c * TB_NODE_STRIDE + i] = live ? sym[i] : 0;
         o.node_height[c * TB_NODE_STRIDE + i] = live ? uint8_t(height[i] > 255 ? 255 : height[i]) : 0;
     }
+    for (int d = 32; d >= 1; d >>= 1) lenmask |= __shfl_xor(lenmask, d);
     if (lane == 0) {
         uint32_t *m = o.ctx_meta + c * TB_META_STRIDE;
         m[0] = nn; m[1] = root; m[2] = s_maxlen; m[3] = s_ntab8;
         for (int d = 0; d < 9; ++d) m[4 + d] = prof[d];
         m[13] = uint32_t(wsum); m[14] = uint32_t(wsum >> 32);
+        m[15] = nleaf < 2 ? 0u : lenmask;                       // the 1-bit code of a one-symbol context does not count
     }
 }
 
@@ -211,6 +275,7 @@ __global__ __launch_bounds__(256) void tree_pack_kernel(TreePackArgs a) {
     tr[tid] = 0;
     __syncthreads();
     const uint32_t P = a.P, nprim = 1u << P;
+    if (tid == 0) a.sec_base[c] = a.sec_base_val[c];
     if (root == 0xFFFFFFFFu) {                       // empty context: null tables
         if (tid < nprim) a.prim[(c << P) | tid] = DEC16_NULL;
         a.tree[c * TREE_STRIDE + tid] = 0;
@@ -248,7 +313,7 @@ __global__ __launch_bounds__(256) void tree_pack_kernel(TreePackArgs a) {
         __syncthreads();
     }
     const uint32_t off = scan[tid] - tabsize;
-    const uint32_t base = a.sec_base[c];
+    const uint32_t base = a.sec_base_val[c];
     if (tid < nprim) {
         uint16_t e;
         if (left[node] == NONE) e = uint16_t(DEC16_LEAF | (depth << 8) | sym[node]);      // a leaf reached at depth <= P fills its whole range

@@ -53,8 +53,15 @@ def _dev(group):
 
 
 def merged_histogram(local_counts, group=None):
-    """local_counts: int64[65536] tensor on the rank's device (counts < 2^63).  In-place sum over ranks."""
-    dist.all_reduce(local_counts, op=dist.ReduceOp.SUM, group=group)
+    """local_counts: int64[65536] tensor on the rank's device (counts < 2^63).  In-place sum over ranks.
+    With RCCL the tensor is reduced where it lies (HBM, over xGMI); the gloo backend (CPU rehearsals of the
+    N > 1 path, also with the shards on one GPU) is handed a host copy."""
+    if local_counts.is_cuda and dist.get_backend(group) != "nccl":
+        host = local_counts.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        local_counts.copy_(host)
+    else:
+        dist.all_reduce(local_counts, op=dist.ReduceOp.SUM, group=group)
     return local_counts
 
 
@@ -92,10 +99,13 @@ def stitch(parts, total_bits):
     stream's payload: every shard is OR-ed in at byte start_bit // 8 (its leading start_bit % 8 bits
     are zero, so the seam byte it shares with its predecessor merges without shifting anything)."""
     out = bytearray((total_bits + 7) // 8)
-    for start, payload in parts:
+    for start, payload in sorted(parts, key=lambda p: p[0]):
+        payload = bytes(payload)
+        if not payload:
+            continue
         off = start // 8
-        for i, b in enumerate(bytes(payload)):
-            out[off + i] |= b
+        out[off] |= payload[0]                                   # the seam byte shared with the previous shard
+        out[off + 1:off + len(payload)] = payload[1:]            # everything after it belongs to this shard alone
     return bytes(out)
 
 
