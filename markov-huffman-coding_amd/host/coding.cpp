@@ -201,6 +201,8 @@ bool i_coding_provider::context_empty(int prev) {
     return !present;
 }
 
+static bool valid_chunk(uint64_t c) { return c >= MH_CHUNK_MIN && c <= MH_CHUNK_MAX && (c & (c - 1)) == 0; }
+
 // src/coding.cpp:61-94: header placeholder, payload, header rewrite.  Here the payload comes out of the
 // HIP encoder in one piece, so the header is known before anything is written and no seek is needed.
 void i_coding_provider::compress(FILE* input_fd, FILE* output_fd) {
@@ -221,6 +223,7 @@ void i_coding_provider::compress(FILE* input_fd, FILE* output_fd) {
     out.data[0] = mh_stream_header(model_, bits);               // src/coding.cpp:88 — known up front, no seek back
     uint64_t nbits = 0;
     std::vector<uint64_t> index;
+    if (!index_path_.empty() && !valid_chunk(chunk_)) mh_or_die(MH_ERR_ARG, "compress (--chunk)");
     if (!index_path_.empty()) index.resize((size_t)mh_index_entries(in.size, chunk_) + 1);
     mh_or_die(mh_encode(model_, in.data, in.size, MH_PREV0, out.data + 1, nbytes, &nbits,
                         index.empty() ? nullptr : index.data(), chunk_), "compress");
@@ -260,12 +263,17 @@ void i_coding_provider::decompress(FILE* input_fd, FILE* output_fd) {
         FILE* f = fopen(index_path_.c_str(), "rb");
         if (f) {
             uint64_t head[3];
-            if (fread(head, 8, 3, f) == 3 && head[0] == 0x315844494D48ull) {
+            // The sidecar is untrusted input: a chunk size that is not a power of two in [MH_CHUNK_MIN,
+            // MH_CHUNK_MAX] or a symbol count above the payload's bit count (every code has >= 1 bit) cannot
+            // come from this encoder; such a file is ignored and the stream is decoded without an index.
+            if (fread(head, 8, 3, f) == 3 && head[0] == 0x315844494D48ull && valid_chunk(head[1]) && head[2] <= nbits) {
                 chunk = (uint32_t)head[1];
                 n_symbols = head[2];
-                index.resize((size_t)mh_index_entries(n_symbols, chunk) + 1);
                 size_t ne = (size_t)mh_index_entries(n_symbols, chunk);
+                index.resize(ne + 1);
                 if (fread(index.data(), 8, ne, f) != ne) index.clear();
+            } else {
+                eprintf("Warning: index sidecar %s is not usable; extracting without it.\n", index_path_.c_str());
             }
             fclose(f);
         }

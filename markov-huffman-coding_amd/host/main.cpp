@@ -57,7 +57,14 @@ static options parse(int argc, char* argv[]) {
                 return argv[++i];
             };
             if (!strcmp(a, "--index")) o.index_path = need(a);
-            else if (!strcmp(a, "--chunk")) o.chunk = (uint32_t)strtoul(need(a), nullptr, 10);
+            else if (!strcmp(a, "--chunk")) {
+                const unsigned long v = strtoul(need(a), nullptr, 10);
+                if (v < MH_CHUNK_MIN || v > MH_CHUNK_MAX || (v & (v - 1))) {
+                    eprintf("Error: --chunk must be a power of two between %u and %u.\n", MH_CHUNK_MIN, MH_CHUNK_MAX);
+                    exit(1);
+                }
+                o.chunk = (uint32_t)v;
+            }
             else if (!strcmp(a, "--device")) o.device = atoi(need(a));
             else eprintf("Warning: Unknown option %s.\n", a);
             continue;

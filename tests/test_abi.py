@@ -127,3 +127,30 @@ def test_compute_refuses_without_gpu(mhc):
     with pytest.raises(mhc.MhError) as e:
         m.decode(b"\x00", 8)
     assert e.value.status == mhc.MH_ERR_NO_DEVICE
+
+
+def test_cli_rejects_bad_chunk_sizes_before_touching_a_device(tmp_path):
+    """--chunk is validated at parse time (a zero or non-power-of-two value used to reach a division)."""
+    import subprocess
+    binp = os.path.join(ROOT, "bin", "markovhuffman")
+    if not os.path.exists(binp):
+        entry.build()
+    src = tmp_path / "in"
+    src.write_bytes(b"hello")
+    for bad in ("0", "300", "16384", "abc"):
+        r = subprocess.run([binp, str(src), "-o", str(tmp_path / "o"), "--index", str(tmp_path / "i"), "--chunk", bad],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 1
+        assert b"--chunk must be a power of two" in r.stderr
+
+
+def test_tie_free_counts_host_model_matches_oracle(mhc, oracle):
+    """Large pairwise-distinct counts (the shape of a 16 GiB histogram): the host twin of the device tree
+    build against the oracle.  (On the GPU the same counts take the sorted two-queue path of
+    tree_build_kernel; tests/test_gpu_parity.py compares its images with this host build.)"""
+    rng = np.random.default_rng(99)
+    w = 1.0 / np.arange(1, 257) ** 1.1
+    p = np.outer(w, w).ravel()
+    counts = (rng.permutation(65536).astype(np.uint64) + np.floor(p / p.sum() * 2 ** 34).astype(np.uint64) * np.uint64(65536))
+    m = mhc.Model.from_counts(counts, 1)
+    assert m.table_bytes() == oracle.Model.from_counts(counts, 1).table_bytes()

@@ -131,6 +131,35 @@ def test_device_tree_build_equals_host_build(mhc, oracle, kind):
         assert dev.decompress(blob, index=idx, chunk_symbols=256, n_symbols=len(data)) == data
 
 
+@pytest.mark.parametrize("shape", ["distinct", "one_tie_late", "workspace"])
+def test_device_tree_build_sorted_path_and_heap_fallback(mhc, oracle, shape):
+    """tree_build_kernel takes the sorted two-queue path when no two of the three smallest keys of a merge
+    step are equal, and re-runs the context with the exact heap emulation otherwise.  Large pairwise
+    distinct counts (a 16 GiB histogram's shape) exercise the first, a single late tie between a leaf and a
+    merged node the hand-over; `workspace` builds through mh_dev_model_from_counts_ws."""
+    rng = np.random.default_rng(7)
+    w = 1.0 / np.arange(1, 257) ** 1.1
+    p = np.outer(w, w).ravel()
+    counts = rng.permutation(65536).astype(np.uint64) + np.floor(p / p.sum() * 2 ** 34).astype(np.uint64) * np.uint64(65536)
+    if shape == "one_tie_late":
+        for c in range(0, 256, 3):       # make one symbol weigh exactly what the two lightest weigh together
+            row = counts[c * 256:(c + 1) * 256]
+            order = np.argsort(row)
+            row[order[2]] = row[order[0]] + row[order[1]]
+    host = mhc.Model.from_counts(counts, 1)
+    d_counts = mhc.DeviceBuffer(65536 * 8, counts)
+    if shape == "workspace":
+        wsb = mhc.lib().mh_dev_model_workspace(1)
+        d_ws = mhc.DeviceBuffer(wsb)
+        dev = mhc.Model.from_device_counts_ws(d_counts.ptr, 1, d_ws.ptr, wsb)
+    else:
+        dev = mhc.Model.from_device_counts(d_counts.ptr, 1)
+    assert dev.decode_layout() == host.decode_layout()
+    for which in range(8):
+        assert dev.image(which) == host.image(which), "image %d differs" % which
+    assert dev.table_bytes() == oracle.Model.from_counts(counts, 1).table_bytes()
+
+
 # ------------------------------------------------------------------ encode
 
 @pytest.mark.parametrize("name", golden_names())

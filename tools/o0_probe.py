@@ -16,7 +16,7 @@ ev = lambda: torch.cuda.Event(enable_timing=True)
 for it in range(3):
     e = [ev() for _ in range(3)]
     e[0].record(); codec.encode(model, data, 0x20); e[1].record()
+    codec.decode(model); e[2].record(); torch.cuda.synchronize()
     nbits = int(codec.nbits[0].item())
-    codec.decode(model, nbits); e[2].record(); torch.cuda.synchronize()
     print("encode %.3f ms decode %.3f ms ratio %.4f" % (e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2]), nbits / 8 / n))
 print("ok", bool(torch.equal(codec.decoded, data)))
