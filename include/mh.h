@@ -78,6 +78,7 @@ typedef struct mh_model mh_model;
  * and markov_huffman_table(int*) (src/markov_huffman.h:12, src/markov_huffman.cpp:9-13; order 1,
  * counts[256*prev+sym], 65536 counts).  Tie-breaking reproduces min_pq (src/min_pq.tpp:4-52) and the
  * height swap (src/huffman.cpp:147-149) exactly; counts are 64-bit (reference: int).
+ * order 2 (extension, described before the chunk-index section): 1 << 24 counts, needs a device.
  * Builds the code tables and decode LUTs (src/huffman.cpp:91-123) and uploads them to the current
  * device.  Host pointer in. */
 int mh_model_from_counts(const uint64_t *counts, int order, mh_model **out);
@@ -126,6 +127,26 @@ int mh_model_decode_layout(const mh_model *m, int *primary_bits, int *secondary_
 int mh_model_image(const mh_model *m, int which, void *out, size_t cap, size_t *bytes);
 void mh_model_free(mh_model *m);
 
+/*
+ * ORDER 2 — EXTENSION, PARITY UNPINNED.  order == 2 selects 65536 contexts, ctx = (byte before previous)
+ * << 8 | previous byte (both ' ' before the stream): counts[ctx * 256 + sym], 1 << 24 entries.  The
+ * reference implements order 1 only and merely speculates about higher orders (README.md:158-166), so
+ * there is nothing to pin this against; the spec is the generalised oracle (oracle/mh_oracle.h): the same
+ * per-context algorithm (src/huffman.cpp:131-164) per two-byte context.  Differences at the boundary:
+ *   - mh_model_type() == 2; mh_model_get_code() takes the 16-bit context as `prev`; mh_model_get_lut() is
+ *     not available; the model always lives on the device (there is no host-only order-2 model);
+ *   - stream header 0x40 | unused bits (mh_stream_header / mh_stream_parse_header): the reference's magic
+ *     is 0x30 (src/coding.cpp:103-106), so its decompress reports an order-2 stream as corrupt;
+ *   - table file: the 33 bytes of an EMPTY order-1 table (which is what the reference's type sniffing,
+ *     src/main.cpp:147-161, and loader make of it), the magic "MH2\x01", then per context bit 0 | bit 1 +
+ *     tree (src/huffman.cpp:174-188), zero padded;
+ *   - index entries carry the two context bytes in bits 48..63 (MH_INDEX2_BIT_MASK);
+ *   - `prev0` arguments stand for BOTH context bytes.
+ * All tables live in HBM and are served from L2 / the Infinity Cache (16.7 M codewords do not fit LDS).
+ */
+int mh_histogram_o2(const uint8_t *data, size_t n, uint64_t *counts /* 1 << 24 */);
+int mh_dev_histogram_o2(const uint8_t *d_data, size_t n, uint16_t ctx0, uint64_t *d_counts /* 1 << 24 */, void *stream);
+
 /* ------------------------------------------------------------- chunk index */
 /*
  * The reference's stream has no index (src/coding.cpp:35-59), and a decoder's state is
@@ -139,6 +160,8 @@ void mh_model_free(mh_model *m);
 #define MH_CHUNK_MAX 8192u
 #define MH_CHUNK_DEFAULT 1024u
 #define MH_INDEX_BIT_MASK 0x00FFFFFFFFFFFFFFull
+/* order-2 models (extension below): entry = (two context bytes << 48) | bit offset */
+#define MH_INDEX2_BIT_MASK 0x0000FFFFFFFFFFFFull
 static inline uint64_t mh_index_entries(uint64_t n_symbols, uint32_t chunk_symbols) {
     return (n_symbols + chunk_symbols - 1) / chunk_symbols;
 }

@@ -22,6 +22,7 @@ MH_ERR_BADTABLE, MH_ERR_CODE_TOO_LONG, MH_ERR_CAPACITY, MH_ERR_TIMEOUT, MH_ERR_N
 PREV0 = 0x20
 CHUNK_DEFAULT = 1024
 INDEX_BIT_MASK = 0x00FFFFFFFFFFFFFF
+INDEX2_BIT_MASK = 0x0000FFFFFFFFFFFF      # order-2 models: two context bytes in bits 48..63
 
 # every symbol include/mh.h declares (checked by tests/test_abi.py)
 EXPORTS = [
@@ -31,7 +32,7 @@ EXPORTS = [
     "mh_model_from_table_bits", "mh_model_write_table",
     "mh_model_type", "mh_model_max_code_len", "mh_model_get_code", "mh_model_get_lut", "mh_model_decode_layout",
     "mh_model_image", "mh_model_free",
-    "mh_histogram_o1", "mh_histogram_o0", "mh_encode", "mh_encode_bound", "mh_stream_header",
+    "mh_histogram_o1", "mh_histogram_o0", "mh_histogram_o2", "mh_dev_histogram_o2", "mh_encode", "mh_encode_bound", "mh_stream_header",
     "mh_stream_parse_header", "mh_decode",
     "mh_dev_histogram_workspace", "mh_dev_histogram_o1", "mh_dev_histogram_o0",
     "mh_decode_to", "mh_model_payload_bits", "mh_dev_encode_workspace", "mh_dev_encode", "mh_dev_payload_bits", "mh_dev_encode_at", "mh_dev_decode_workspace", "mh_dev_decode", "mh_dev_decode_dn",
@@ -82,6 +83,8 @@ def lib():
         l.mh_model_free.restype = None
         l.mh_histogram_o1.argtypes = [vp, sz, u8, vp]
         l.mh_histogram_o0.argtypes = [vp, sz, vp]
+        l.mh_histogram_o2.argtypes = [vp, sz, vp]
+        l.mh_dev_histogram_o2.argtypes = [vp, sz, C.c_uint16, vp, vp]
         l.mh_encode.argtypes = [vp, vp, sz, u8, vp, sz, pu64, vp, u32]
         l.mh_encode_bound.argtypes = [vp, sz]
         l.mh_encode_bound.restype = sz
@@ -165,6 +168,14 @@ def histogram_o0(data):
     return out
 
 
+def histogram_o2(data):
+    """Order-2 extension (parity unpinned): counts[ctx * 256 + sym], ctx = the two previous bytes."""
+    a = _u8(data)
+    out = np.zeros(1 << 24, dtype=np.uint64)
+    _check(lib().mh_histogram_o2(_ptr(a), a.size, out.ctypes.data), "mh_histogram_o2")
+    return out
+
+
 class Model:
     """Owns an mh_model* (tables resident on the current device)."""
 
@@ -174,7 +185,7 @@ class Model:
     @classmethod
     def from_counts(cls, counts, order):
         c = np.ascontiguousarray(counts, dtype=np.uint64)
-        if c.size != (65536 if order else 256):
+        if c.size != {0: 256, 1: 65536, 2: 1 << 24}[order]:
             raise ValueError("counts size")
         h = C.c_void_p()
         _check(lib().mh_model_from_counts(c.ctypes.data, order, C.byref(h)), "mh_model_from_counts")
@@ -198,7 +209,7 @@ class Model:
     @classmethod
     def from_data(cls, data, order=1):
         """Histogram on the GPU, then tree build (the `markovhuffman in -d table` path)."""
-        return cls.from_counts(histogram_o1(data) if order else histogram_o0(data), order)
+        return cls.from_counts({0: histogram_o0, 1: histogram_o1, 2: histogram_o2}[order](data), order)
 
     @classmethod
     def from_table(cls, table_bytes):
@@ -256,6 +267,10 @@ class Model:
                 lens[p * 256 + s] = l.value
                 codes[p * 256 + s] = c.value
         return lens, codes
+
+    def codes_o2(self):
+        """Order-2 model: (len8[1 << 24], code64[1 << 24]) indexed ctx*256+sym, straight from the device tables."""
+        return (np.frombuffer(self.image(1), dtype=np.uint8), np.frombuffer(self.image(3), dtype=np.uint64))
 
     def lut(self, prev, w):
         p, i, v, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()

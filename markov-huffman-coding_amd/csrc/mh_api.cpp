@@ -19,7 +19,9 @@ struct mh_model {
     mh::Model::Packed packed;    // host-built images (empty after a device build)
     int device = -1;
     // what the entry points need without touching the mirror
-    int type = 1, max_len = 0, dec_bits = 8, dec_h = 0;
+    int type = 1, max_len = 0, dec_bits = 8, dec_h = 0;   // type 2: order-2 contexts (extension, parity unpinned)
+    uint32_t nctx = 256;         // contexts the device tables are laid out for (65536 for type 2)
+    std::vector<uint8_t> table2; // type 2 loaded from a table file: the file itself (write_table returns it)
     uint32_t len_gcd = 0;        // gcd of all code lengths (index builder: segment length is a multiple of it)
     bool dec_lds = true, dec_direct = false;
     uint32_t nsec = 0;
@@ -233,7 +235,16 @@ int mh_dev_download(void *h_dst, const void *d_src, size_t bytes) {
 
 /* ---------------------------------------------------------------- model */
 
+static int model2_from_host_counts(const uint64_t *counts, mh_model **out) {
+    if (!have_device()) return MH_ERR_NO_DEVICE;                 // the order-2 build has no host twin: it runs on the device
+    DevBuf d_counts;
+    HIP_TRY(d_counts.alloc((size_t(1) << 24) * 8));
+    HIP_TRY(hipMemcpy(d_counts.p, counts, (size_t(1) << 24) * 8, hipMemcpyHostToDevice));
+    return mh_dev_model_from_counts(d_counts.as<uint64_t>(), 2, nullptr, out);
+}
+
 int mh_model_from_counts(const uint64_t *counts, int order, mh_model **out) {
+    if (counts && out && order == 2) return model2_from_host_counts(counts, out);
     if (!counts || !out || (order != 0 && order != 1)) return MH_ERR_ARG;
     mh_model *m = new (std::nothrow) mh_model;
     if (!m) return MH_ERR_NOMEM;
@@ -300,7 +311,7 @@ int dev_model_build(const uint64_t *d_counts, void *d_ws, size_t ws_bytes, hipSt
     m->d_meta = reinterpret_cast<uint32_t *>(b + off[11]);
 
     mhk::TreeBuildOut tb{m->d_len8, reinterpret_cast<unsigned long long *>(m->d_code64), m->d_enc16, m->d_len_slot,
-                         m->d_node_left, m->d_node_right, m->d_node_sym, d_node_height, m->d_meta};
+                         m->d_node_left, m->d_node_right, m->d_node_sym, d_node_height, m->d_meta, 8u};
     HIP_TRY_M(mhk::launch_tree_build(reinterpret_cast<const unsigned long long *>(d_counts), 256, tb, st));
     std::vector<uint32_t> meta(size_t(256) * mhk::TB_META_STRIDE);
     HIP_TRY_M(hipMemcpyAsync(meta.data(), m->d_meta, meta.size() * 4, hipMemcpyDeviceToHost, st));
@@ -363,6 +374,183 @@ int dev_model_build(const uint64_t *d_counts, void *d_ws, size_t ws_bytes, hipSt
 }
 }  // namespace
 
+// ---- order 2 (extension; parity unpinned: the spec is the generalised oracle, oracle/mh_oracle.h) ----------
+namespace {
+constexpr uint32_t O2_CTX = 65536;
+constexpr uint32_t O2_HCAP = 4;          // second-level tables of at most 16 entries: <= 4096 entries per context
+const unsigned char O2_MAGIC[4] = {'M', 'H', '2', 1};
+
+bool is_o2_table(const uint8_t *b, size_t n) {
+    if (n < 37 || b[0] != 0x80) return false;
+    for (int i = 1; i < 33; ++i) if (b[i]) return false;
+    return std::memcmp(b + 33, O2_MAGIC, 4) == 0;
+}
+
+struct Build2Layout { size_t off[11], total; };
+Build2Layout build2_layout() {
+    const size_t nn = size_t(O2_CTX) * mhk::TB_NODE_STRIDE, ne = size_t(O2_CTX) * 256;
+    const size_t sizes[11] = {ne, ne * 8, ne * 4, ne * 2, size_t(O2_CTX) * 4, nn * 2, nn * 2, nn, nn, size_t(O2_CTX) * mhk::TB_META_STRIDE * 4, 256};
+    Build2Layout L;
+    size_t total = 0;
+    for (int i = 0; i < 11; ++i) { L.off[i] = total; total += (sizes[i] + 255) & ~size_t(255); }
+    L.total = total;
+    return L;
+}
+
+void place2(mh_model *m, unsigned char *b, const Build2Layout &L, uint8_t **node_height) {
+    m->d_len8 = b + L.off[0];
+    m->d_code64 = reinterpret_cast<uint64_t *>(b + L.off[1]);
+    m->d_tree = reinterpret_cast<uint32_t *>(b + L.off[2]);
+    m->d_prim = reinterpret_cast<uint16_t *>(b + L.off[3]);
+    m->d_sec_base = reinterpret_cast<uint32_t *>(b + L.off[4]);
+    m->d_node_left = reinterpret_cast<uint16_t *>(b + L.off[5]);
+    m->d_node_right = reinterpret_cast<uint16_t *>(b + L.off[6]);
+    m->d_node_sym = b + L.off[7];
+    *node_height = b + L.off[8];
+    m->d_meta = reinterpret_cast<uint32_t *>(b + L.off[9]);
+}
+
+// counts (1 << 24, device) -> 65536 trees, codes and decode tables, all on the device
+int dev_model_build2(const uint64_t *d_counts, hipStream_t st, mh_model **out) {
+    mh_model *m = new (std::nothrow) mh_model;
+    if (!m) return MH_ERR_NOMEM;
+    m->type = 2; m->nctx = O2_CTX; m->mirror_ready = false;
+    m->dec_bits = 8; m->dec_lds = false; m->dec_direct = false; m->dec_h = 0;
+    auto fail = [&](int rc) { mh_model_free(m); return rc; };
+#define HIP_TRY_M(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(hip_fail(_e)); } while (0)
+    HIP_TRY_M(hipGetDevice(&m->device));
+    const Build2Layout L = build2_layout();
+    HIP_TRY_M(hipMalloc(&m->d_build, L.total));
+    uint8_t *d_node_height = nullptr;
+    place2(m, static_cast<unsigned char *>(m->d_build), L, &d_node_height);
+    mhk::TreeBuildOut tb{m->d_len8, reinterpret_cast<unsigned long long *>(m->d_code64), nullptr, nullptr,
+                         m->d_node_left, m->d_node_right, m->d_node_sym, d_node_height, m->d_meta, O2_HCAP};
+    HIP_TRY_M(mhk::launch_tree_build(reinterpret_cast<const unsigned long long *>(d_counts), int(O2_CTX), tb, st));
+    std::vector<uint32_t> meta(size_t(O2_CTX) * mhk::TB_META_STRIDE);
+    HIP_TRY_M(hipMemcpyAsync(meta.data(), m->d_meta, meta.size() * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY_M(hipStreamSynchronize(st));
+    std::vector<uint32_t> sec_base(O2_CTX);
+    size_t nsec = 0;
+    for (uint32_t c = 0; c < O2_CTX; ++c) {
+        const uint32_t *mt = &meta[size_t(c) * mhk::TB_META_STRIDE];
+        m->max_len = std::max(m->max_len, int(mt[2]));
+        for (uint32_t l = 1; l <= 32; ++l)
+            if (mt[15] & (1u << (l - 1))) m->len_gcd = gcd_u32(m->len_gcd, l == 32 ? 1u : l);
+        sec_base[c] = uint32_t(nsec);
+        nsec += mt[4 + 8];                                        // tables under the depth-8 nodes, heights capped at O2_HCAP
+    }
+    if (nsec > 0xFFFFFFFFull - 4096) return fail(MH_ERR_CAPACITY);
+    m->nsec = uint32_t(nsec);
+    if (m->max_len > mh::MAX_CODE_BITS) { *out = m; return MH_OK; }
+    const size_t sec_bytes = ((nsec * 2 + 15) & ~size_t(15)) + 16;
+    HIP_TRY_M(hipMalloc(&m->d_sec_own, sec_bytes));
+    m->d_sec = static_cast<uint16_t *>(m->d_sec_own);
+    HIP_TRY_M(hipMemsetAsync(m->d_sec_own, 0, sec_bytes, st));
+    HIP_TRY_M(hipMemcpyAsync(m->d_sec_base, sec_base.data(), size_t(O2_CTX) * 4, hipMemcpyHostToDevice, st));
+    mhk::TreePackArgs pa{};
+    pa.node_left = m->d_node_left; pa.node_right = m->d_node_right; pa.node_sym = m->d_node_sym; pa.node_height = d_node_height;
+    pa.ctx_meta = m->d_meta; pa.sec_base = m->d_sec_base; pa.sec_base_in = m->d_sec_base;
+    pa.P = 8; pa.direct = 0; pa.H = 0; pa.hcap = O2_HCAP;
+    pa.prim = m->d_prim; pa.sec = m->d_sec; pa.tree = m->d_tree;
+    HIP_TRY_M(mhk::launch_tree_pack(pa, int(O2_CTX), st));
+    HIP_TRY_M(hipStreamSynchronize(st));                         // sec_base lives in pageable host memory
+#undef HIP_TRY_M
+    *out = m;
+    return MH_OK;
+}
+
+// order-2 table file -> host-derived images (ContextCoder per non-empty context) -> device
+int model2_from_table(const uint8_t *bytes, size_t n, mh_model **out) {
+    mh_model *m = new (std::nothrow) mh_model;
+    if (!m) return MH_ERR_NOMEM;
+    m->type = 2; m->nctx = O2_CTX; m->mirror_ready = true;
+    m->dec_bits = 8; m->dec_lds = false; m->dec_direct = false; m->dec_h = 0;
+    m->table2.assign(bytes, bytes + n);
+    const size_t ne = size_t(O2_CTX) * 256;
+    std::vector<uint8_t> len8(ne, 0);
+    std::vector<uint64_t> code64(ne, 0);
+    std::vector<uint16_t> prim(ne, mh::DEC16_NULL), sec;
+    std::vector<uint32_t> tree(ne, 0), sec_base(O2_CTX, 0);
+    mh::BitReader in(bytes + 37, n - 37);
+    mh::ContextCoder cc;
+    for (uint32_t c = 0; c < O2_CTX; ++c) {
+        sec_base[c] = uint32_t(sec.size());
+        if (in.bit()) {
+            if (!cc.load(in)) { delete m; return MH_ERR_BADTABLE; }
+            int live = 0;
+            for (int sy = 0; sy < 256; ++sy) {
+                const mh::Code &cd = cc.code(sy);
+                len8[size_t(c) * 256 + sy] = uint8_t(std::min(cd.len, 255));
+                code64[size_t(c) * 256 + sy] = cd.len <= 64 ? cd.right_aligned() : 0;
+                live += cd.len != 0;
+            }
+            m->max_len = std::max(m->max_len, cc.max_len());
+            if (live >= 2) for (int sy = 0; sy < 256; ++sy) m->len_gcd = gcd_u32(m->len_gcd, len8[size_t(c) * 256 + sy]);
+            cc.pack_decode(8, int(O2_HCAP), 0, &prim[size_t(c) << 8], sec, sec_base[c], &tree[size_t(c) * 256]);
+        }
+        if (in.failed()) { delete m; return MH_ERR_BADTABLE; }
+    }
+    m->nsec = uint32_t(sec.size());
+    if (!have_device() || m->max_len > mh::MAX_CODE_BITS) { *out = m; return MH_OK; }
+    auto fail = [&](int rc) { mh_model_free(m); return rc; };
+#define HIP_TRY_M(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(hip_fail(_e)); } while (0)
+    HIP_TRY_M(hipGetDevice(&m->device));
+    const Build2Layout L = build2_layout();
+    HIP_TRY_M(hipMalloc(&m->d_build, L.total));
+    uint8_t *d_node_height = nullptr;
+    place2(m, static_cast<unsigned char *>(m->d_build), L, &d_node_height);
+    m->d_node_left = m->d_node_right = nullptr; m->d_node_sym = nullptr; m->d_meta = nullptr;   // no trees on the device
+    const size_t sec_bytes = ((sec.size() * 2 + 15) & ~size_t(15)) + 16;
+    HIP_TRY_M(hipMalloc(&m->d_sec_own, sec_bytes));
+    m->d_sec = static_cast<uint16_t *>(m->d_sec_own);
+    HIP_TRY_M(hipMemset(m->d_sec_own, 0, sec_bytes));
+    HIP_TRY_M(hipMemcpy(m->d_len8, len8.data(), ne, hipMemcpyHostToDevice));
+    HIP_TRY_M(hipMemcpy(m->d_code64, code64.data(), ne * 8, hipMemcpyHostToDevice));
+    HIP_TRY_M(hipMemcpy(m->d_tree, tree.data(), ne * 4, hipMemcpyHostToDevice));
+    HIP_TRY_M(hipMemcpy(m->d_prim, prim.data(), ne * 2, hipMemcpyHostToDevice));
+    HIP_TRY_M(hipMemcpy(m->d_sec_base, sec_base.data(), size_t(O2_CTX) * 4, hipMemcpyHostToDevice));
+    if (!sec.empty()) HIP_TRY_M(hipMemcpy(m->d_sec, sec.data(), sec.size() * 2, hipMemcpyHostToDevice));
+#undef HIP_TRY_M
+    *out = m;
+    return MH_OK;
+}
+
+// table file of a device-built order-2 model, written from the node arrays
+int model2_write_table(const mh_model *m, std::vector<uint8_t> &out) {
+    if (!m->table2.empty()) { out = m->table2; return MH_OK; }
+    if (!m->d_node_left) return MH_ERR_NO_DEVICE;
+    const size_t nn = size_t(O2_CTX) * mhk::TB_NODE_STRIDE;
+    std::vector<uint16_t> left(nn), right(nn);
+    std::vector<uint8_t> sym(nn);
+    std::vector<uint32_t> meta(size_t(O2_CTX) * mhk::TB_META_STRIDE);
+    HIP_TRY(hipMemcpy(left.data(), m->d_node_left, nn * 2, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(right.data(), m->d_node_right, nn * 2, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(sym.data(), m->d_node_sym, nn, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(meta.data(), m->d_meta, meta.size() * 4, hipMemcpyDeviceToHost));
+    mh::BitWriter w;
+    w.bit(1);
+    for (int i = 0; i < 256 + 7; ++i) w.bit(0);                   // the empty order-1 table, zero padded
+    for (int i = 0; i < 4; ++i) w.byte(O2_MAGIC[i]);
+    std::vector<uint32_t> stack;
+    for (uint32_t c = 0; c < O2_CTX; ++c) {
+        const uint32_t root = meta[size_t(c) * mhk::TB_META_STRIDE + 1];
+        const uint16_t *l = &left[size_t(c) * mhk::TB_NODE_STRIDE], *r = &right[size_t(c) * mhk::TB_NODE_STRIDE];
+        const uint8_t *sy = &sym[size_t(c) * mhk::TB_NODE_STRIDE];
+        w.bit(root != 0xFFFFFFFFu);
+        if (root == 0xFFFFFFFFu) continue;
+        stack.assign(1, root);                                    // pre-order: inner -> 0, leaf -> 1 + symbol (src/huffman.cpp:174-188)
+        while (!stack.empty()) {
+            const uint32_t i = stack.back();
+            stack.pop_back();
+            if (l[i] == 0xFFFF) { w.bit(1); w.byte(sy[i]); }
+            else { w.bit(0); stack.push_back(r[i]); stack.push_back(l[i]); }
+        }
+    }
+    out = w.bytes();
+    return MH_OK;
+}
+}  // namespace
+
 size_t mh_dev_model_workspace(int order) { return order == 1 ? build_layout().fixed + MODEL_WS_SEC_BYTES : 0; }
 
 int mh_dev_model_from_counts_ws(const uint64_t *d_counts, int order, void *d_ws, size_t ws_bytes, void *stream, mh_model **out) {
@@ -372,9 +560,10 @@ int mh_dev_model_from_counts_ws(const uint64_t *d_counts, int order, void *d_ws,
 }
 
 int mh_dev_model_from_counts(const uint64_t *d_counts, int order, void *stream, mh_model **out) {
-    if (!d_counts || !out || (order != 0 && order != 1)) return MH_ERR_ARG;
+    if (!d_counts || !out || order < 0 || order > 2) return MH_ERR_ARG;
     if (!have_device()) return MH_ERR_NO_DEVICE;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (order == 2) return dev_model_build2(d_counts, st, out);
     if (order == 0) return model_from_device_counts_via_host(d_counts, order, st, out);   // one tree: not worth a kernel
     int rc = dev_model_build(d_counts, nullptr, 0, st, out);
     if (rc == MH_ERR_ARG - 100) return model_from_device_counts_via_host(d_counts, order, st, out);
@@ -383,6 +572,7 @@ int mh_dev_model_from_counts(const uint64_t *d_counts, int order, void *stream, 
 
 int mh_model_from_table_bits(const uint8_t *bytes, size_t n, mh_model **out) {
     if ((!bytes && n) || !out) return MH_ERR_ARG;
+    if (is_o2_table(bytes, n)) return model2_from_table(bytes, n, out);
     mh_model *m = new (std::nothrow) mh_model;
     if (!m) return MH_ERR_NOMEM;
     if (!m->host.load_table(bytes, n)) { delete m; return MH_ERR_BADTABLE; }
@@ -391,8 +581,12 @@ int mh_model_from_table_bits(const uint8_t *bytes, size_t n, mh_model **out) {
 
 int mh_model_write_table(const mh_model *m, uint8_t *out, size_t cap, size_t *nbytes) {
     if (!m || !nbytes) return MH_ERR_ARG;
-    { int rc = ensure_mirror(m); if (rc != MH_OK) return rc; }
-    std::vector<uint8_t> t = m->host.save_table();
+    std::vector<uint8_t> t;
+    if (m->type == 2) { int rc = model2_write_table(m, t); if (rc != MH_OK) return rc; }
+    else {
+        int rc = ensure_mirror(m); if (rc != MH_OK) return rc;
+        t = m->host.save_table();
+    }
     *nbytes = t.size();
     if (!out) return MH_OK;
     if (cap < t.size()) return MH_ERR_CAPACITY;
@@ -406,6 +600,15 @@ int mh_model_max_code_len(const mh_model *m) { return m ? m->max_len : MH_ERR_AR
 
 int mh_model_get_code(const mh_model *m, int prev, int sym, int *len, uint64_t *code) {
     if (!m || !len || !code) return MH_ERR_ARG;
+    if (m->type == 2) {                                          // prev = the 16-bit context; read straight from the device tables
+        if (!m->d_len8) return MH_ERR_NO_DEVICE;
+        const size_t i = (size_t(prev & 0xFFFF) << 8) | size_t(sym & 255);
+        uint8_t l = 0;
+        HIP_TRY(hipMemcpy(&l, m->d_len8 + i, 1, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(code, m->d_code64 + i, 8, hipMemcpyDeviceToHost));
+        *len = l;
+        return MH_OK;
+    }
     { int rc = ensure_mirror(m); if (rc != MH_OK) return rc; }
     const mh::Code &c = m->host.context(prev).code(sym);
     *len = c.len;
@@ -414,7 +617,7 @@ int mh_model_get_code(const mh_model *m, int prev, int sym, int *len, uint64_t *
 }
 
 int mh_model_get_lut(const mh_model *m, int prev, int w, int *present, int *is_internal, int *value, int *depth) {
-    if (!m || !present || !is_internal || !value || !depth) return MH_ERR_ARG;
+    if (!m || !present || !is_internal || !value || !depth || m->type == 2) return MH_ERR_ARG;
     { int rc = ensure_mirror(m); if (rc != MH_OK) return rc; }
     const mh::ContextCoder &c = m->host.context(prev);
     int n = c.lut(w);
@@ -438,18 +641,19 @@ int mh_model_decode_layout(const mh_model *m, int *primary_bits, int *secondary_
 
 int mh_model_image(const mh_model *m, int which, void *out, size_t cap, size_t *bytes) {
     if (!m || !bytes) return MH_ERR_ARG;
-    if (!m->d_enc16) return MH_ERR_NO_DEVICE;
+    if (!m->d_len8) return MH_ERR_NO_DEVICE;
     const void *src = nullptr;
     size_t n = 0;
+    const size_t nc = m->nctx;                                   // 256, or 65536 for an order-2 model (which has no enc16 / len_slot)
     switch (which) {
-        case 0: src = m->d_enc16; n = 65536 * 2; break;
-        case 1: src = m->d_len8; n = 65536; break;
-        case 2: src = m->d_len_slot; n = 65536; break;
-        case 3: src = m->d_code64; n = 65536 * 8; break;
-        case 4: src = m->d_prim; n = (size_t(256) << m->dec_bits) * 2; break;
+        case 0: src = m->d_enc16; n = m->d_enc16 ? 65536 * 2 : 0; break;
+        case 1: src = m->d_len8; n = nc * 256; break;
+        case 2: src = m->d_len_slot; n = m->d_len_slot ? 65536 : 0; break;
+        case 3: src = m->d_code64; n = nc * 256 * 8; break;
+        case 4: src = m->d_prim; n = (nc << m->dec_bits) * 2; break;
         case 5: src = m->d_sec; n = size_t(m->nsec) * 2; break;
-        case 6: src = m->d_sec_base; n = 256 * 4; break;
-        case 7: src = m->d_tree; n = size_t(256) * mh::TREE_STRIDE * 4; break;
+        case 6: src = m->d_sec_base; n = nc * 4; break;
+        case 7: src = m->d_tree; n = nc * mh::TREE_STRIDE * 4; break;
         default: return MH_ERR_ARG;
     }
     *bytes = n;
@@ -484,6 +688,12 @@ int mh_dev_histogram_o0(const uint8_t *d_data, size_t n, uint64_t *d_counts, voi
     return MH_OK;
 }
 
+int mh_dev_histogram_o2(const uint8_t *d_data, size_t n, uint16_t ctx0, uint64_t *d_counts, void *stream) {
+    if ((!d_data && n) || !d_counts || !aligned16(d_data)) return MH_ERR_ARG;
+    HIP_TRY(mhk::launch_hist_o2(d_data, n, ctx0, reinterpret_cast<unsigned long long *>(d_counts), static_cast<hipStream_t>(stream)));
+    return MH_OK;
+}
+
 size_t mh_dev_encode_workspace(size_t n) { return mhk::encode_workspace_bytes(n); }
 
 int mh_dev_encode(const mh_model *m, const uint8_t *d_data, size_t n, uint8_t prev0, uint8_t *d_payload, size_t cap,
@@ -494,23 +704,26 @@ int mh_dev_encode(const mh_model *m, const uint8_t *d_data, size_t n, uint8_t pr
 int mh_dev_payload_bits(const mh_model *m, const uint64_t *d_counts, uint64_t *d_nbits, void *stream) {
     if (!m || !d_counts || !d_nbits) return MH_ERR_ARG;
     if (!m->d_len8) return MH_ERR_NO_DEVICE;
-    HIP_TRY(mhk::launch_payload_bits(reinterpret_cast<const unsigned long long *>(d_counts), m->d_len8, m->type ? 65536u : 256u,
+    HIP_TRY(mhk::launch_payload_bits(reinterpret_cast<const unsigned long long *>(d_counts), m->d_len8, m->type == 2 ? (1u << 24) : m->type ? 65536u : 256u,
                                      reinterpret_cast<unsigned long long *>(d_nbits), static_cast<hipStream_t>(stream)));
     return MH_OK;
 }
 
-int mh_dev_encode_at(const mh_model *m, const uint8_t *d_data, size_t n, uint8_t prev0, const uint64_t *d_start_bit,
-                     uint8_t *d_payload, size_t cap, uint64_t *d_nbits, uint64_t *d_index, uint32_t chunk_symbols,
-                     void *d_ws, size_t ws_bytes, void *stream) {
+// ctx0: the context before the first byte — the previous byte (orders 0/1) or, for an order-2 model,
+// (byte before previous) << 8 | previous byte
+static int dev_encode_ctx(const mh_model *m, const uint8_t *d_data, size_t n, uint32_t ctx0, const uint64_t *d_start_bit,
+                          uint8_t *d_payload, size_t cap, uint64_t *d_nbits, uint64_t *d_index, uint32_t chunk_symbols,
+                          void *d_ws, size_t ws_bytes, void *stream) {
     if (!m || (!d_data && n) || !d_payload || !d_nbits || !d_ws) return MH_ERR_ARG;
     if (!aligned16(d_data) || !aligned16(d_payload) || !aligned16(d_ws)) return MH_ERR_ARG;
     int shift = chunk_shift_of(d_index ? chunk_symbols : MH_CHUNK_DEFAULT);
     if (shift < 0) return MH_ERR_ARG;
     if (ws_bytes < mhk::encode_workspace_bytes(n)) return MH_ERR_CAPACITY;
     if (m->max_len > mh::MAX_CODE_BITS) return MH_ERR_CODE_TOO_LONG;
-    if (!m->d_enc16) return MH_ERR_NO_DEVICE;
+    if (!m->d_len8) return MH_ERR_NO_DEVICE;
     mhk::EncodeArgs p{};
-    p.data = d_data; p.n = n; p.prev0 = prev0; p.chunk_shift = uint32_t(shift);
+    p.order = m->type == 2 ? 2 : 1;
+    p.data = d_data; p.n = n; p.prev0 = ctx0; p.chunk_shift = uint32_t(shift);
     p.out = d_payload; p.cap = cap;
     p.enc16 = m->d_enc16; p.len_slot = m->d_len_slot; p.len8 = m->d_len8; p.code64 = m->d_code64;
     p.nbits = reinterpret_cast<unsigned long long *>(d_nbits);
@@ -518,6 +731,15 @@ int mh_dev_encode_at(const mh_model *m, const uint8_t *d_data, size_t n, uint8_t
     p.start_bit = reinterpret_cast<const unsigned long long *>(d_start_bit);
     HIP_TRY(mhk::launch_encode(p, d_ws, static_cast<hipStream_t>(stream)));
     return MH_OK;
+}
+
+static uint32_t ctx_of_prev0(const mh_model *m, uint8_t prev0) { return m && m->type == 2 ? (uint32_t(prev0) << 8 | prev0) : prev0; }
+
+int mh_dev_encode_at(const mh_model *m, const uint8_t *d_data, size_t n, uint8_t prev0, const uint64_t *d_start_bit,
+                     uint8_t *d_payload, size_t cap, uint64_t *d_nbits, uint64_t *d_index, uint32_t chunk_symbols,
+                     void *d_ws, size_t ws_bytes, void *stream) {
+    return dev_encode_ctx(m, d_data, n, ctx_of_prev0(m, prev0), d_start_bit, d_payload, cap, d_nbits, d_index, chunk_symbols, d_ws,
+                          ws_bytes, stream);
 }
 
 size_t mh_dev_decode_workspace(uint64_t, uint64_t n_symbols, uint32_t chunk_symbols) {
@@ -539,6 +761,7 @@ static int dev_decode(const mh_model *m, const uint8_t *d_payload, uint64_t nbit
     if (m->max_len > mh::MAX_CODE_BITS) return MH_ERR_CODE_TOO_LONG;
     if (!m->d_prim) return MH_ERR_NO_DEVICE;
     mhk::DecParams p{};
+    p.order = m->type == 2 ? 2 : 1;
     p.payload = d_payload; p.payload_bytes = (nbits + 7) / 8; p.nbits = nbits;
     p.d_nbits = reinterpret_cast<const unsigned long long *>(d_nbits);
     p.out = d_out; p.n = n_symbols;
@@ -573,7 +796,8 @@ int mh_dev_build_index(const mh_model *m, const uint8_t *d_payload, uint64_t nbi
     if (!m->d_prim) return MH_ERR_NO_DEVICE;
     mhk::IdxParams p{};
     p.payload = d_payload; p.payload_bytes = (nbits + 7) / 8; p.nbits = nbits;
-    p.prev0 = prev0; p.chunk_shift = uint32_t(shift);
+    p.order = m->type == 2 ? 2 : 1;
+    p.prev0 = ctx_of_prev0(m, prev0); p.chunk_shift = uint32_t(shift);
     p.index = reinterpret_cast<unsigned long long *>(d_index); p.index_cap = index_cap;
     p.n_symbols = reinterpret_cast<unsigned long long *>(d_n_symbols);
     p.prim = m->d_prim; p.sec = m->d_sec; p.sec_base = m->d_sec_base; p.tree = m->d_tree;
@@ -612,12 +836,12 @@ static size_t segment_bytes() {
 static int histogram_host(const uint8_t *data, size_t n, uint8_t prev0, uint64_t *counts, int order) {
     if ((!data && n) || !counts) return MH_ERR_ARG;
     if (!have_device()) return MH_ERR_NO_DEVICE;
-    const size_t nc = order ? 65536 : 256;
+    const size_t nc = order == 2 ? (size_t(1) << 24) : order ? 65536 : 256;
     const size_t seg = segment_bytes();
     DevBuf d_data, d_counts, d_hws;
     HIP_TRY(d_data.alloc(n < seg ? n : seg));
     HIP_TRY(d_counts.alloc(nc * 8));
-    const size_t hws = order && n >= (size_t(1) << 20) ? mh_dev_histogram_workspace(n) : 0;   // pays from about a megabyte on
+    const size_t hws = order == 1 && n >= (size_t(1) << 20) ? mh_dev_histogram_workspace(n) : 0;   // pays from about a megabyte on
     if (hws) HIP_TRY(d_hws.alloc(hws));
     std::vector<uint64_t> part(nc);
     for (size_t i = 0; i < nc; ++i) counts[i] = 0;
@@ -625,8 +849,10 @@ static int histogram_host(const uint8_t *data, size_t n, uint8_t prev0, uint64_t
         const size_t len = n - off < seg ? n - off : seg;
         if (len) HIP_TRY(hipMemcpy(d_data.p, data + off, len, hipMemcpyHostToDevice));
         const uint8_t p0 = off ? data[off - 1] : prev0;            // context carried across the seam (src/main.cpp:32,36)
-        int rc = order ? mh_dev_histogram_o1(d_data.as<uint8_t>(), len, p0, d_counts.as<uint64_t>(), hws ? d_hws.p : nullptr, hws, nullptr)
-                       : mh_dev_histogram_o0(d_data.as<uint8_t>(), len, d_counts.as<uint64_t>(), nullptr, 0, nullptr);
+        const uint16_t c0 = off ? uint16_t(data[off - 2] << 8 | data[off - 1]) : uint16_t(prev0 << 8 | prev0);   // segments are >= 8 KiB
+        int rc = order == 2 ? mh_dev_histogram_o2(d_data.as<uint8_t>(), len, c0, d_counts.as<uint64_t>(), nullptr)
+                 : order ? mh_dev_histogram_o1(d_data.as<uint8_t>(), len, p0, d_counts.as<uint64_t>(), hws ? d_hws.p : nullptr, hws, nullptr)
+                         : mh_dev_histogram_o0(d_data.as<uint8_t>(), len, d_counts.as<uint64_t>(), nullptr, 0, nullptr);
         if (rc != MH_OK) return rc;
         HIP_TRY(hipMemcpy(part.data(), d_counts.p, nc * 8, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < nc; ++i) counts[i] += part[i];
@@ -641,6 +867,8 @@ int mh_histogram_o1(const uint8_t *data, size_t n, uint8_t prev0, uint64_t *coun
 
 int mh_histogram_o0(const uint8_t *data, size_t n, uint64_t *counts) { return histogram_host(data, n, 0, counts, 0); }
 
+int mh_histogram_o2(const uint8_t *data, size_t n, uint64_t *counts) { return histogram_host(data, n, MH_PREV0, counts, 2); }
+
 size_t mh_encode_bound(const mh_model *m, size_t n) {
     size_t maxlen = m ? size_t(m->max_len) : 64;
     if (maxlen < 1) maxlen = 1;
@@ -650,13 +878,18 @@ size_t mh_encode_bound(const mh_model *m, size_t n) {
 uint8_t mh_stream_header(const mh_model *m, uint64_t nbits) {
     int type = m ? m->type : 1;
     int bi = int(nbits & 7u);
+    if (type == 2) return uint8_t(0x40 | ((8 - bi) % 8));         // order-2 extension: its own magic nibble (the reference rejects it)
     return uint8_t(0x30 | ((~type & 1) << 3) | ((8 - bi) % 8));   // src/coding.cpp:88
 }
 
 int mh_stream_parse_header(const mh_model *m, uint8_t header, uint64_t file_bytes, uint64_t *nbits) {
     if (!m || !nbits || file_bytes < 1) return MH_ERR_ARG;
-    if ((header & 0xF0) != 0x30) return MH_ERR_CORRUPT;                         // src/coding.cpp:103-106
-    if (((~(header & (1 << 3)) >> 3) & 1) != m->type) return MH_ERR_TYPE;  // src/coding.cpp:107-110
+    if (m->type == 2) {
+        if ((header & 0xF8) != 0x40) return (header & 0xF0) == 0x30 ? MH_ERR_TYPE : MH_ERR_CORRUPT;
+    } else {
+        if ((header & 0xF0) != 0x30) return (header & 0xF8) == 0x40 ? MH_ERR_TYPE : MH_ERR_CORRUPT;   // src/coding.cpp:103-106
+        if (((~(header & (1 << 3)) >> 3) & 1) != m->type) return MH_ERR_TYPE;  // src/coding.cpp:107-110
+    }
     uint64_t total = (file_bytes - 1) * 8;
     uint64_t rem = header & 7u;                                                 // src/coding.cpp:111-115
     if (rem > total) return MH_ERR_CORRUPT;
@@ -691,9 +924,10 @@ int mh_encode(const mh_model *m, const uint8_t *data, size_t n, uint8_t prev0, u
         const size_t len = n - off < seg ? n - off : seg;
         HIP_TRY(hipMemcpy(d_data.p, data + off, len, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d_start.p, &start, 8, hipMemcpyHostToDevice));
-        const uint8_t p0 = off ? data[off - 1] : prev0;
-        int rc = mh_dev_encode_at(m, d_data.as<uint8_t>(), len, p0, d_start.as<uint64_t>(), d_out.as<uint8_t>(), dcap,
-                                  d_nbits.as<uint64_t>(), index ? d_index.as<uint64_t>() : nullptr, chunk_symbols, d_ws.p, wsb, st);
+        const uint32_t c0 = m->type == 2 ? (off ? uint32_t(data[off - 2]) << 8 | data[off - 1] : ctx_of_prev0(m, prev0))
+                                         : (off ? data[off - 1] : prev0);      // segments are >= 8 KiB, so off >= 2 when not 0
+        int rc = dev_encode_ctx(m, d_data.as<uint8_t>(), len, c0, d_start.as<uint64_t>(), d_out.as<uint8_t>(), dcap,
+                                d_nbits.as<uint64_t>(), index ? d_index.as<uint64_t>() : nullptr, chunk_symbols, d_ws.p, wsb, st);
         if (rc != MH_OK) return rc;
         rc = mh_dev_status(d_ws.p, st);
         if (rc != MH_OK) return rc;
@@ -741,7 +975,7 @@ int mh_decode_to(const mh_model *m, const uint8_t *payload, uint64_t nbits, uint
         *nbytes = size_t(n_symbols);
         out = get_out(ctx, size_t(n_symbols));
         if (!out && n_symbols) return MH_ERR_CAPACITY;
-        const uint64_t MASK = MH_INDEX_BIT_MASK;
+        const uint64_t MASK = m->type == 2 ? MH_INDEX2_BIT_MASK : MH_INDEX_BIT_MASK;
         const size_t seg = segment_bytes();
         const uint64_t nchunks = mh_index_entries(n_symbols, chunk_symbols);
         const size_t slen = n_symbols < seg ? size_t(n_symbols) : seg;
@@ -820,7 +1054,7 @@ int mh_decode_to(const mh_model *m, const uint8_t *payload, uint64_t nbits, uint
         uint64_t end_bits = nbits;                               // a segment ends where the next one's first chunk starts
         if (c0 + ne < nchunks) {
             HIP_TRY(hipMemcpy(&end_bits, d_index.as<uint64_t>() + c0 + ne, 8, hipMemcpyDeviceToHost));
-            end_bits &= MH_INDEX_BIT_MASK;
+            end_bits &= m->type == 2 ? MH_INDEX2_BIT_MASK : MH_INDEX_BIT_MASK;
         }
         int rc = mh_dev_decode(m, d_payload.as<uint8_t>(), end_bits, d_out.as<uint8_t>(), len, d_index.as<uint64_t>() + c0,
                                chunk_symbols, d_ws.p, dws, st);
@@ -849,6 +1083,15 @@ int mh_decode(const mh_model *m, const uint8_t *payload, uint64_t nbits, uint8_t
 
 int mh_model_payload_bits(const mh_model *m, const uint64_t *counts, uint64_t *nbits) {
     if (!m || !counts || !nbits) return MH_ERR_ARG;
+    if (m->type == 2) {                                          // counts: 1 << 24 entries; the lengths come from the device table
+        if (!m->d_len8) return MH_ERR_NO_DEVICE;
+        std::vector<uint8_t> len8(size_t(1) << 24);
+        HIP_TRY(hipMemcpy(len8.data(), m->d_len8, len8.size(), hipMemcpyDeviceToHost));
+        uint64_t total = 0;
+        for (size_t i = 0; i < len8.size(); ++i) total += counts[i] * len8[i];
+        *nbits = total;
+        return MH_OK;
+    }
     { int rc = ensure_mirror(m); if (rc != MH_OK) return rc; }
     const int nctx = m->type ? 256 : 1;
     uint64_t total = 0;

@@ -12,9 +12,10 @@ enum { MHK_STATUS_OK = 0, MHK_STATUS_TIMEOUT = 1, MHK_STATUS_CAPACITY = 2, MHK_S
 
 // host-side description of one encode call (device pointers)
 struct EncodeArgs {
+    int order;                    // 0/1: the LDS-table path; 2: order-2 contexts, tables gathered from HBM/L2
     const uint8_t *data;          // n input bytes, 16-byte aligned
     uint64_t n;
-    uint32_t prev0;
+    uint32_t prev0;               // context before the first byte (order 2: the 16-bit context)
     uint32_t chunk_shift;         // log2(chunk_symbols)
     uint8_t *out;                 // payload, 16-byte aligned
     uint64_t cap;                 // bytes available at out
@@ -62,6 +63,7 @@ struct EmitParams {
 };
 
 struct DecParams {
+    int order;                    // 2: order-2 tables (general form, P = 8, 65536 contexts)
     const uint8_t *payload;
     uint64_t payload_bytes;
     uint64_t nbits;               // payload bits (a hint for the variant choice when d_nbits is set)
@@ -85,6 +87,7 @@ struct DecParams {
 };
 
 struct IdxParams {
+    int order;
     const uint8_t *payload;
     uint64_t payload_bytes;
     uint64_t nbits;
@@ -115,15 +118,18 @@ constexpr int TB_META_STRIDE = 16;    // per context: nnodes, root, max_len, #in
                                       // second-level sizes for P = 0..8 (table heights capped at 8), weight lo/hi,
                                       // bit mask of the code lengths in use (0 for a one-symbol context)
 struct TreeBuildOut {
-    uint8_t *len8; unsigned long long *code64; uint16_t *enc16; uint8_t *len_slot;
+    uint8_t *len8; unsigned long long *code64;
+    uint16_t *enc16; uint8_t *len_slot;      // LDS-table images of the order-1 encoder; nullptr for order 2
     uint16_t *node_left, *node_right; uint8_t *node_sym, *node_height;
     uint32_t *ctx_meta;
+    uint32_t hcap;                // cap on second-level table heights in the size profile (8; order 2: 4)
 };
 struct TreePackArgs {
     const uint16_t *node_left, *node_right; const uint8_t *node_sym, *node_height;
     const uint32_t *ctx_meta;
     uint32_t *sec_base;           // 256: device copy of sec_base_val, written by the kernel (the decoders read it)
-    uint32_t sec_base_val[256];   // entry offsets chosen by the host
+    uint32_t sec_base_val[256];   // entry offsets chosen by the host (order 0/1: travels in the kernel arguments)
+    const uint32_t *sec_base_in;  // order 2: 65536 offsets in device memory (then sec_base_val is unused)
     uint32_t P, direct, H, hcap;
     uint16_t *prim, *sec; uint32_t *tree;
 };
@@ -134,6 +140,7 @@ size_t hist_workspace_bytes();
 hipError_t launch_hist_o1(const uint8_t *d_data, uint64_t n, uint32_t prev0, unsigned long long *d_counts, void *d_ws, size_t ws_bytes,
                           hipStream_t st);
 hipError_t launch_hist_o0(const uint8_t *d_data, uint64_t n, unsigned long long *d_counts, hipStream_t st);
+hipError_t launch_hist_o2(const uint8_t *d_data, uint64_t n, uint32_t ctx0, unsigned long long *d_counts, hipStream_t st);
 size_t encode_workspace_bytes(uint64_t n);
 hipError_t launch_encode(const EncodeArgs &a, void *d_ws, hipStream_t st);
 hipError_t launch_payload_bits(const unsigned long long *d_counts, const uint8_t *d_len8, uint32_t entries, unsigned long long *d_out,

@@ -65,12 +65,18 @@ __device__ __forceinline__ void slots16(const uint4 &x4, uint32_t pb, uint32_t (
 // ------------------------------------------------------------------------------------------------
 // histogram, order 1
 // ------------------------------------------------------------------------------------------------
-// 65536 counters do not fit LDS as u32 (256 KiB > 160 KiB), so two 15-bit counters plus a guard bit
-// each share one LDS word: bits [14:0]+[15] and [30:16]+[31].  A returning ds_add tells the lane that
-// took a counter from 0x7FFF to 0x8000; that lane subtracts the guard bit again and credits 32768 to
-// the 64-bit counter in HBM.  A guard bit never carries into the neighbour because fewer than 32768
-// adds can be in flight between the add that sets it and the subtract that clears it (the workgroup
-// has 1024 lanes x 16 adds).
+// 65536 counters do not fit LDS as u32 (256 KiB > 160 KiB), so two 16-bit fields share one LDS word, each
+// a 14-bit counter under two guard bits (bits 14 and 15 of its half).  A returning ds_add tells a lane that
+// its add carried a field across a multiple of 0x4000; that lane subtracts 0x4000 again and credits 16384 to
+// the 64-bit counter in HBM — one fix-up per crossing, whichever lane caused it, so the field's value plus
+// 16384 x (fix-ups done) is always the true count and late fix-ups only let the field run higher for a while.
+// A field spills into its neighbour only at 0x10000, i.e. with FOUR crossings (49152 adds) still un-applied.
+// What can be un-applied: a fix-up trails its add by two trips through the CU's LDS queue (the adding wave's
+// own batch has to return, then its subtract queues up), and the queue holds at most 16 waves x 16
+// outstanding instructions x 64 lanes = 16384 adds, so about 33 K adds to ONE counter in the worst case (a
+// run of one repeated pair, e.g. zero pages, where every lane of the workgroup hits the same word).
+// The first version had a single guard bit (room for 32768): tests/test_gpu_scale.py
+// test_histogram_guard_bit_fixups_many_per_workgroup caught it losing 8 x 32768 counts on 64 MiB of zeros.
 constexpr int HIST_THREADS = 1024;
 constexpr int HIST_LDS_BYTES = 32768 * 4;
 
@@ -81,15 +87,15 @@ __device__ __forceinline__ uint32_t hist_slot(uint32_t prev, uint32_t sym) { ret
 __device__ __forceinline__ uint32_t hist_slot_prev(uint32_t slot) { return (slot & 255u) ^ (slot >> 8); }
 
 __device__ __forceinline__ void hist_fixup(uint32_t *h, unsigned long long *counts, uint32_t slot) {
-    atomicSub(&h[slot & 0x7FFFu], (slot >> 15) ? 0x80000000u : 0x8000u);
-    atomicAdd(&counts[hist_slot_prev(slot) * 256u + (slot >> 8)], 32768ull);
+    atomicSub(&h[slot & 0x7FFFu], (slot >> 15) ? 0x40000000u : 0x4000u);
+    atomicAdd(&counts[hist_slot_prev(slot) * 256u + (slot >> 8)], 16384ull);
 }
 
 __device__ __forceinline__ void hist_add(uint32_t *h, unsigned long long *counts, uint32_t prev, uint32_t sym) {
     const uint32_t slot = hist_slot(prev, sym);
     const uint32_t inc = (slot >> 15) ? 0x10000u : 1u;
     const uint32_t old = atomicAdd(&h[slot & 0x7FFFu], inc);
-    if (((old + inc) & ~old) & 0x80008000u) hist_fixup(h, counts, slot);
+    if (((old + inc) ^ old) & 0xC000C000u) hist_fixup(h, counts, slot);
 }
 
 // slab: when not null, every workgroup stores its 32768 LDS words there (plain coalesced stores) and
@@ -111,9 +117,9 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_o1_kernel(const uint8_t *__
         // The kernel is VALU-bound (measured: 13.6 instructions per symbol at 77 % VALU utilisation with
         // the previous slot hash), so the per-symbol work is kept to: one byte shuffle for the slot, the
         // word address, the half's increment, the atomic, and three instructions of overflow tracking.
-        // All 16 returning adds are issued back to back; the rare guard-bit fix-ups come afterwards.
+        // All 16 returning adds are issued back to back; the rare fix-ups come afterwards.
         uint32_t slot[16], old[16], inc[16];
-        uint32_t newly = 0;                                      // bits that one of this lane's adds set
+        uint32_t newly = 0;                                      // bits that one of this lane's adds flipped
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t y = x[k] ^ ((x[k] << 8) | pb);        // prev ^ sym for the four symbols of the dword
@@ -129,11 +135,11 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_o1_kernel(const uint8_t *__
             }
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) newly |= (old[i] + inc[i]) & ~old[i];
-        if (newly & 0x80008000u) {                               // some add of this lane carried into a guard bit
+        for (int i = 0; i < 16; ++i) newly |= (old[i] + inc[i]) ^ old[i];
+        if (newly & 0xC000C000u) {                               // some add of this lane crossed a multiple of 0x4000
 #pragma unroll
             for (int i = 0; i < 16; ++i)
-                if (((old[i] + inc[i]) & ~old[i]) & 0x80008000u) hist_fixup(h, counts, slot[i]);
+                if (((old[i] + inc[i]) ^ old[i]) & 0xC000C000u) hist_fixup(h, counts, slot[i]);
         }
     }
     // ragged tail (< 16 bytes): one lane of block 0
@@ -164,7 +170,7 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_o1_kernel(const uint8_t *__
     }
 }
 
-// Sums the workgroups' slabs into the 64-bit counters (which already hold the 32768-credits of counter
+// Sums the workgroups' slabs into the 64-bit counters (which already hold the 16384-credits of counter
 // overflows): thread w owns word w = two counters, reads are coalesced across the block.
 __global__ __launch_bounds__(256) void hist_reduce_kernel(const uint32_t *__restrict__ slab, uint32_t nslab, unsigned long long *counts) {
     const uint32_t w = blockIdx.x * 256u + threadIdx.x;          // < 32768
@@ -439,6 +445,10 @@ __device__ __forceinline__ void flush_words(uint32_t *stage, uint32_t *out32, ui
 // Escape path of one sub-step (some code in the wave is longer than 12 bits): everything is recomputed
 // from the lane's 16 input bytes so that the hot path keeps no per-symbol state alive.  The sub-step
 // may carry up to 64 bits per symbol, so the image is filled and flushed in rounds.
+// ORDER 2 (extension, see the order-2 section below): pb holds the TWO bytes before the lane's vector,
+// (byte before previous) << 8 | previous byte, every codeword comes from the full tables in HBM/L2
+// (len8 / code64 indexed ctx * 256 + sym), and index entries carry the 16-bit context in bits 48..63.
+template <int ORDER>
 __device__ __forceinline__ void emit_substep_slow(const EmitParams &p, const uint16_t *tab, uint32_t *stage, uint32_t *out32,
                                                   uint4 x, uint32_t pb, uint32_t nvalid, uint32_t lane, uint64_t off,
                                                   uint64_t abs_bits, uint64_t &gbase, uint32_t &cur, bool &seam0,
@@ -448,10 +458,11 @@ __device__ __forceinline__ void emit_substep_slow(const EmitParams &p, const uin
     // rolling walk over the lane's bytes: no per-symbol arrays, a handful of registers
     struct Roll {
         uint4 x; uint32_t prev;
+        // order 1: sym << 8 | prev (the raw 16-bit field of the stream); order 2: ctx16 << 8 | sym
         __device__ __forceinline__ uint32_t next_window() {
             uint32_t sym = x.x & 255u;
-            uint32_t win = (sym << 8) | prev;
-            prev = sym;
+            uint32_t win = ORDER == 2 ? ((prev << 8) | sym) : ((sym << 8) | prev);
+            prev = ORDER == 2 ? (((prev << 8) | sym) & 0xFFFFu) : sym;
             x.x = __builtin_amdgcn_alignbyte(x.y, x.x, 1);
             x.y = __builtin_amdgcn_alignbyte(x.z, x.y, 1);
             x.z = __builtin_amdgcn_alignbyte(x.w, x.z, 1);
@@ -460,6 +471,12 @@ __device__ __forceinline__ void emit_substep_slow(const EmitParams &p, const uin
         }
     };
     auto code_of = [&](uint32_t win, bool valid, uint32_t &l, uint64_t &c) {
+        if (ORDER == 2) {
+            l = valid ? uint32_t(p.len8[win]) : 0u;
+            c = valid ? p.code64[win] : 0ull;
+            if (l > 64u) { l = 0; c = 0; }
+            return;
+        }
         uint32_t e = valid ? uint32_t(tab[mh::enc_slot(win)]) : 0u;
         l = e >> 12;
         c = e & 0xFFFu;
@@ -486,7 +503,7 @@ __device__ __forceinline__ void emit_substep_slow(const EmitParams &p, const uin
     const uint32_t exc = inc - L;
     const uint32_t S = 1u << p.chunk_shift;
     if (p.index && nvalid && ((uint32_t(off) & (S - 1u)) == 0u))
-        p.index[off >> p.chunk_shift] = (uint64_t(pb) << 56) | (abs_bits + exc);
+        p.index[off >> p.chunk_shift] = (uint64_t(pb) << (ORDER == 2 ? 48 : 56)) | (abs_bits + exc);
 
     const uint32_t end = cur + sub_bits;     // image bit one past the sub-step (frame of this sub-step)
     const uint32_t nwords = uint32_t(E_STAGE_WORDS - 2);
@@ -573,7 +590,7 @@ __global__ __launch_bounds__(E_THREADS) void enc_emit_kernel(EmitParams p) {
             }
             uint32_t sub_bits;
             if (__any(emax >= 0xD000u)) {        // wave-uniform: an escape code or a ragged vector somewhere
-                emit_substep_slow(p, tab, stage, out32, x, pb, nvalid, lane, off, abs_bits, gbase, cur, seam0, sub_bits);
+                emit_substep_slow<1>(p, tab, stage, out32, x, pb, nvalid, lane, off, abs_bits, gbase, cur, seam0, sub_bits);
             } else {
                 // exclusive wave scan of the lane totals
                 const uint32_t inc = wave_inclusive_sum(L);
@@ -1193,6 +1210,7 @@ __global__ __launch_bounds__(256) void index_fill_kernel(IdxParams p) {
 
 // Sequential fallback (one lane) for streams whose segments refuse to synchronise: walks the whole
 // payload once.  The loop condition is the reference's `while(bi < length)` (src/coding.cpp:124).
+template <int ORDER>
 __global__ void build_index_kernel(IdxParams p) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     const BitSrc src{p.payload, p.payload_bytes >> 2, p.payload_bytes};
@@ -1200,23 +1218,218 @@ __global__ void build_index_kernel(IdxParams p) {
     BitCursor bc;
     bc.init(src, 0);
     uint64_t bi = 0, nsym = 0;
-    uint32_t prev = p.prev0;
+    uint32_t prev = p.prev0;                                // order 2: the 16-bit context
     const uint64_t S = 1ull << p.chunk_shift;
     bool bad = false;
     while (bi < p.nbits) {
         if ((nsym & (S - 1)) == 0) {
             uint64_t ci = nsym >> p.chunk_shift;
             if (ci >= p.index_cap) { atomicExch(p.status, MHK_STATUS_CAPACITY); break; }
-            p.index[ci] = (uint64_t(prev) << 56) | bi;
+            p.index[ci] = (uint64_t(prev) << (ORDER == 2 ? 48 : 56)) | bi;
         }
         uint32_t used = 0;
-        prev = decode_one(p.prim, p.sec_base, tabs, src, bc, prev, used, bad);
+        const uint32_t sym = decode_one(p.prim, p.sec_base, tabs, src, bc, prev, used, bad);
         if (bad) break;
+        prev = ORDER == 2 ? (((prev << 8) | sym) & 0xFFFFu) : sym;
         bi += used;
         ++nsym;
     }
     if (bad || bi > p.nbits) atomicExch(p.status, MHK_STATUS_CORRUPT);
     *p.n_symbols = nsym;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ORDER 2 — context = the previous TWO bytes (BASELINE config 5).  An extension the
+// reference only speculates about (README.md:158-166): PARITY UNPINNED, the spec is the generalised
+// oracle (oracle/mh_oracle.h, order-2 section).  65536 contexts x 256 symbols = 16.7 M counters and
+// codewords: nothing of that fits LDS, so the tables live in HBM and are served from L2 / the Infinity
+// Cache (text-like sources touch a few thousand contexts: a few MiB of hot table).
+//   hist_o2_kernel    LDS-resident tagged counter cache in front of 64-bit global atomics
+//   enc2_len_kernel   code-length sum per 4 KiB wave-tile, lengths gathered from HBM/L2
+//   enc2_emit_kernel  the emit loop of enc_emit_kernel with every codeword gathered from the full tables
+//   decode2_kernel    one lane per chunk, both table levels + the walk tree gathered from HBM/L2
+// Context convention: ctx = (byte before previous) << 8 | previous byte; both are ' ' before the stream.
+// Index entries carry the 16-bit context in bits 48..63 (the bit offset keeps 48 bits).
+// ------------------------------------------------------------------------------------------------
+constexpr uint64_t IDX2_POS = 0x0000FFFFFFFFFFFFull;
+
+// ctx of the byte at `off` for lane 0 of a wave (off is a multiple of 16): the two bytes before it
+__device__ __forceinline__ uint32_t ctx_before(const uint8_t *__restrict__ data, uint64_t n, uint64_t off, uint32_t ctx0) {
+    if (off == 0 || off > n) return ctx0;
+    return (uint32_t(data[off - 2]) << 8) | uint32_t(data[off - 1]);
+}
+// the lane's vector + the context in front of it (previous lane's last two bytes, except in lane 0)
+__device__ __forceinline__ uint32_t head_ctx(const LaneIn &in) {
+    const uint32_t v = __shfl_up(in.x.w >> 16, 1);               // byte 14 | byte 15 << 8 of the previous lane
+    const uint32_t up = ((v & 255u) << 8) | (v >> 8);
+    return (threadIdx.x & 63u) == 0 ? in.head : up;
+}
+__device__ __forceinline__ LaneIn load_raw2(const uint8_t *__restrict__ data, uint64_t n, uint64_t off, uint32_t ctx0) {
+    LaneIn r;
+    r.x = make_uint4(0, 0, 0, 0); r.nvalid = 0; r.head = ctx0;
+    if (off + E_VEC <= n) {
+        r.x = *reinterpret_cast<const uint4 *>(data + off);
+        r.nvalid = E_VEC;
+    } else if (off < n) {
+        r.nvalid = uint32_t(n - off);
+        uint32_t b[4] = {0, 0, 0, 0};
+        for (uint32_t j = 0; j < r.nvalid; ++j) b[j >> 2] |= uint32_t(data[off + j]) << (8u * (j & 3u));
+        r.x = make_uint4(b[0], b[1], b[2], b[3]);
+    }
+    if ((threadIdx.x & 63u) == 0) r.head = ctx_before(data, n, off, ctx0);
+    return r;
+}
+
+// ---- histogram: counts[ctx * 256 + sym] (64-bit, HBM).  A workgroup keeps 16384 (key, count) slots in LDS:
+// the first key to claim a slot owns it for the whole launch (tags never change once set, so the claim is
+// one compare-and-swap and there is no eviction race); every later occurrence of that key is one LDS add,
+// keys that lose a slot go straight to a 64-bit global atomic.  Skewed sources (text) keep most of their
+// mass in LDS; flat ones degrade to the global-atomic rate.
+constexpr int H2_THREADS = 1024;
+constexpr uint32_t H2_SLOTS = 16384;
+constexpr uint32_t H2_EMPTY = 0xFFFFFFFFu;
+constexpr int H2_LDS_BYTES = int(H2_SLOTS) * 8;
+
+__device__ __forceinline__ void hist2_add(uint32_t *tag, uint32_t *cnt, unsigned long long *counts, uint32_t key) {
+    const uint32_t slot = (key * 0x9E3779B1u) >> 18;             // 14 bits
+    const uint32_t old = atomicCAS(&tag[slot], H2_EMPTY, key);
+    if (old == H2_EMPTY || old == key) atomicAdd(&cnt[slot], 1u);
+    else atomicAdd(&counts[key], 1ull);
+}
+
+__global__ __launch_bounds__(H2_THREADS) void hist_o2_kernel(const uint8_t *__restrict__ data, uint64_t n, uint32_t ctx0,
+                                                             unsigned long long *counts) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *tag = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *cnt = tag + H2_SLOTS;
+    for (uint32_t i = threadIdx.x; i < H2_SLOTS; i += H2_THREADS) { tag[i] = H2_EMPTY; cnt[i] = 0; }
+    __syncthreads();
+    const uint64_t nvec = n >> 4;
+    const uint4 *vdata = reinterpret_cast<const uint4 *>(data);
+    // whole waves stay in the loop together (the neighbour's bytes come by shuffle)
+    const uint64_t nvec_up = (nvec + 63) & ~uint64_t(63);
+    for (uint64_t v = uint64_t(blockIdx.x) * H2_THREADS + threadIdx.x; v < nvec_up; v += uint64_t(gridDim.x) * H2_THREADS) {
+        const bool live = v < nvec;
+        const uint4 x4 = live ? vdata[v] : make_uint4(0, 0, 0, 0);
+        const uint32_t up = __shfl_up(x4.w >> 16, 1);
+        uint32_t ctx = ((up & 255u) << 8) | (up >> 8);
+        if ((threadIdx.x & 63u) == 0) ctx = live ? ctx_before(data, n, v << 4, ctx0) : ctx0;
+        if (!live) continue;
+        const uint32_t x[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t key = (ctx << 8) | ((x[k] >> (8 * j)) & 255u);
+                hist2_add(tag, cnt, counts, key);
+                ctx = key & 0xFFFFu;
+            }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                   // ragged tail (< 16 bytes)
+        uint64_t i = nvec << 4;
+        uint32_t ctx = ctx_before(data, n, i, ctx0);
+        for (; i < n; ++i) {
+            const uint32_t key = (ctx << 8) | data[i];
+            atomicAdd(&counts[key], 1ull);
+            ctx = key & 0xFFFFu;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < H2_SLOTS; i += H2_THREADS)
+        if (tag[i] != H2_EMPTY && cnt[i]) atomicAdd(&counts[tag[i]], (unsigned long long)cnt[i]);
+}
+
+// ---- encode, pass 1: p.len_slot = len8[ctx * 256 + sym] (HBM), p.prev0 = the 16-bit start context
+__global__ __launch_bounds__(E_THREADS) void enc2_len_kernel(LenParams p) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave0 = uint64_t(blockIdx.x) * E_WAVES + (threadIdx.x >> 6);
+    const uint64_t nwaves = uint64_t(gridDim.x) * E_WAVES;
+    for (uint64_t wt = wave0; wt < p.nwt; wt += nwaves) {
+        uint32_t sum = 0;
+#pragma unroll 1
+        for (int k = 0; k < E_SUBSTEPS; ++k) {
+            const LaneIn in = load_raw2(p.data, p.n, wt * E_WT + uint64_t(k) * E_SUB + lane * E_VEC, p.prev0);
+            uint32_t ctx = head_ctx(in);
+            const uint32_t x[4] = {in.x.x, in.x.y, in.x.z, in.x.w};
+            uint32_t l[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {                         // 16 independent gathers in flight
+                const uint32_t key = (ctx << 8) | ((x[j >> 2] >> (8 * (j & 3))) & 255u);
+                l[j] = uint32_t(j) < in.nvalid ? uint32_t(p.len_slot[key]) : 0u;
+                ctx = key & 0xFFFFu;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) sum += l[j] > 64u ? 0u : l[j];
+        }
+        sum = wave_sum(sum);
+        if (lane == 0) p.wt_bits[wt] = sum;
+    }
+}
+
+// ---- encode, pass 2
+__global__ __launch_bounds__(E_THREADS) void enc2_emit_kernel(EmitParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t *stage = reinterpret_cast<uint32_t *>(smem) + wave * E_STAGE_WORDS;
+    for (int i = lane; i < E_STAGE_WORDS; i += 64) stage[i] = 0;
+    __syncthreads();
+    if (*p.status != MHK_STATUS_OK) return;     // capacity overrun found by the scan: write nothing
+    uint32_t *out32 = reinterpret_cast<uint32_t *>(p.out);
+    const uint64_t wave0 = uint64_t(blockIdx.x) * E_WAVES + wave;
+    const uint64_t nwaves = uint64_t(gridDim.x) * E_WAVES;
+    for (uint64_t wt = wave0; wt < p.nwt; wt += nwaves) {
+        const uint64_t s = p.wt_start[wt];
+        uint64_t gbase = s >> 5;
+        uint32_t cur = uint32_t(s & 31u);
+        uint64_t abs_bits = s;
+        bool seam0 = cur != 0;
+#pragma unroll 1
+        for (int k = 0; k < E_SUBSTEPS; ++k) {
+            const uint64_t off = wt * E_WT + uint64_t(k) * E_SUB + lane * E_VEC;
+            const LaneIn in = load_raw2(p.data, p.n, off, p.prev0);
+            uint32_t sub_bits;
+            emit_substep_slow<2>(p, nullptr, stage, out32, in.x, head_ctx(in), in.nvalid, lane, off, abs_bits, gbase, cur, seam0, sub_bits);
+            abs_bits += sub_bits;
+        }
+        if (cur != 0 && lane == 0) {
+            atomicOr(&out32[gbase], __builtin_bswap32(stage[0]));
+            stage[0] = 0;
+        }
+    }
+}
+
+// ---- decode: one lane per chunk; p.prim / p.sec / p.sec_base / p.tree are the order-2 tables (general form, P = 8)
+__global__ __launch_bounds__(256) void decode2_kernel(DecParams p) {
+    if (p.d_nbits) { p.nbits = *p.d_nbits; p.payload_bytes = (p.nbits + 7) >> 3; }
+    const BitSrc src{p.payload, p.payload_bytes >> 2, p.payload_bytes};
+    const DecTables tabs{p.sec, p.tree, p.P, 0u, 0u};
+    const uint32_t S = 1u << p.chunk_shift;
+    for (uint64_t c = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; c < p.nchunks; c += uint64_t(gridDim.x) * blockDim.x) {
+        const uint64_t entry = p.index[c];
+        uint64_t pos = entry & IDX2_POS;
+        uint32_t ctx = uint32_t(entry >> 48);
+        const uint64_t endpos = (c + 1 < p.nchunks) ? (p.index[c + 1] & IDX2_POS) : p.nbits;
+        const uint64_t first = c << p.chunk_shift;
+        const uint32_t nsym = (p.n - first) >= S ? S : uint32_t(p.n - first);
+        if (pos > p.nbits || endpos < pos || endpos > p.nbits) { atomicExch(p.status, MHK_STATUS_CORRUPT); continue; }
+        BitCursor bc;
+        bc.init(src, pos);
+        bool bad = false;
+        uint8_t *o = p.out + first;
+        uint32_t q = 0;
+        for (uint32_t i = 0; i < nsym; ++i) {
+            uint32_t used = 0;
+            const uint32_t sym = decode_one(p.prim, p.sec_base, tabs, src, bc, ctx, used, bad);
+            if (bad) break;
+            pos += used;
+            ctx = ((ctx << 8) | sym) & 0xFFFFu;
+            q |= sym << (8u * (i & 3u));
+            if ((i & 3u) == 3u) { *reinterpret_cast<uint32_t *>(o + i - 3u) = q; q = 0; }
+        }
+        for (uint32_t i = nsym & ~3u; i < nsym && !bad; ++i) o[i] = uint8_t(q >> (8u * (i & 3u)));
+        if (bad || pos != endpos) atomicExch(p.status, MHK_STATUS_CORRUPT);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1229,7 +1442,7 @@ __global__ void build_index_kernel(IdxParams p) {
 constexpr int MAX_DEVICES = 64;
 struct DeviceState {
     int cu_count = 0;
-    bool hist_ready = false, encode_ready = false, decode_ready = false;
+    bool hist_ready = false, hist2_ready = false, encode_ready = false, decode_ready = false;
 };
 static DeviceState g_dev[MAX_DEVICES];
 static std::mutex g_dev_mu;
@@ -1294,6 +1507,18 @@ hipError_t launch_hist_o0(const uint8_t *d_data, uint64_t n, unsigned long long 
     return hipGetLastError();
 }
 
+hipError_t launch_hist_o2(const uint8_t *d_data, uint64_t n, uint32_t ctx0, unsigned long long *d_counts, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(d_counts, 0, (size_t(1) << 24) * sizeof(unsigned long long), st);
+    if (e != hipSuccess || n == 0) return e;
+    e = once_per_device(&DeviceState::hist2_ready, [] { return allow_lds(reinterpret_cast<const void *>(hist_o2_kernel), H2_LDS_BYTES); });
+    if (e != hipSuccess) return e;
+    const uint64_t nvec = n >> 4;
+    const uint64_t want = (nvec + H2_THREADS - 1) / H2_THREADS;
+    const int grid = int(want < 1 ? 1 : (want > uint64_t(cu_count()) ? uint64_t(cu_count()) : want));
+    hipLaunchKernelGGL(hist_o2_kernel, dim3(grid), dim3(H2_THREADS), H2_LDS_BYTES, st, d_data, n, ctx0, d_counts);
+    return hipGetLastError();
+}
+
 uint64_t encode_wave_tiles(uint64_t n) { return (n + E_WT - 1) / E_WT; }
 
 // workspace: [0,64) status | wt_bits u32[nwt] | wt_start u64[nwt] | blk_sum u64[nblk + 1]
@@ -1323,19 +1548,22 @@ __global__ __launch_bounds__(256) void payload_bits_kernel(const unsigned long l
                                                            unsigned long long *out) {
     __shared__ unsigned long long part[256];
     unsigned long long acc = 0;
-    for (uint32_t i = threadIdx.x; i < entries; i += 256) acc += counts[i] * len8[i];
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < entries; i += gridDim.x * 256u) acc += counts[i] * len8[i];
     part[threadIdx.x] = acc;
     __syncthreads();
     for (int d = 128; d > 0; d >>= 1) {
         if (int(threadIdx.x) < d) part[threadIdx.x] += part[threadIdx.x + d];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *out = part[0];
+    if (threadIdx.x == 0 && part[0]) atomicAdd(out, part[0]);
 }
 
 hipError_t launch_payload_bits(const unsigned long long *d_counts, const uint8_t *d_len8, uint32_t entries, unsigned long long *d_out,
                                hipStream_t st) {
-    hipLaunchKernelGGL(payload_bits_kernel, dim3(1), dim3(256), 0, st, d_counts, d_len8, entries, d_out);
+    hipError_t e = hipMemsetAsync(d_out, 0, 8, st);
+    if (e != hipSuccess) return e;
+    const unsigned grid = entries > 65536u ? 1024u : 1u;
+    hipLaunchKernelGGL(payload_bits_kernel, dim3(grid), dim3(256), 0, st, d_counts, d_len8, entries, d_out);
     return hipGetLastError();
 }
 
@@ -1358,10 +1586,15 @@ hipError_t launch_encode(const EncodeArgs &a, void *d_ws, hipStream_t st) {
     unsigned long long *wt_start = reinterpret_cast<unsigned long long *>(ws + L.off_start);
     unsigned long long *blk_sum = reinterpret_cast<unsigned long long *>(ws + L.off_blk);
 
-    LenParams lp{a.data, a.n, a.prev0, a.len_slot, wt_bits, L.nwt};
     uint64_t want = (L.nwt + E_WAVES - 1) / E_WAVES;
     int grid = int(want > uint64_t(2 * cu_count()) ? uint64_t(2 * cu_count()) : want);
-    hipLaunchKernelGGL(enc_len_kernel, dim3(grid), dim3(E_THREADS), LEN_LDS_BYTES, st, lp);
+    if (a.order == 2) {                                      // lengths gathered from the full table (a.len8)
+        LenParams lp{a.data, a.n, a.prev0, a.len8, wt_bits, L.nwt};
+        hipLaunchKernelGGL(enc2_len_kernel, dim3(grid), dim3(E_THREADS), 0, st, lp);
+    } else {
+        LenParams lp{a.data, a.n, a.prev0, a.len_slot, wt_bits, L.nwt};
+        hipLaunchKernelGGL(enc_len_kernel, dim3(grid), dim3(E_THREADS), LEN_LDS_BYTES, st, lp);
+    }
 
     hipLaunchKernelGGL(scan_local_kernel, dim3(unsigned(L.nblk)), dim3(SCAN_THREADS), 0, st, wt_bits, L.nwt, wt_start, blk_sum);
     hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, blk_sum, L.nblk, a.start_bit);
@@ -1370,6 +1603,10 @@ hipError_t launch_encode(const EncodeArgs &a, void *d_ws, hipStream_t st) {
     hipLaunchKernelGGL(scan_apply_kernel, dim3(unsigned(L.nblk)), dim3(SCAN_THREADS), 0, st, sp);
 
     EmitParams ep{a.data, a.n, a.prev0, a.chunk_shift, a.out, a.enc16, a.len8, a.code64, wt_start, L.nwt, a.index, status};
+    if (a.order == 2) {                                      // no table in LDS: two workgroups per CU
+        hipLaunchKernelGGL(enc2_emit_kernel, dim3(grid), dim3(E_THREADS), E_WAVES * E_STAGE_WORDS * 4, st, ep);
+        return hipGetLastError();
+    }
     grid = int(want > uint64_t(cu_count()) ? uint64_t(cu_count()) : want);
     hipLaunchKernelGGL(enc_emit_kernel, dim3(grid), dim3(E_THREADS), EMIT_LDS_BYTES, st, ep);
     return hipGetLastError();
@@ -1380,6 +1617,12 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
     p.redo = reinterpret_cast<uint32_t *>(static_cast<char *>(d_ws) + 64);      // [0] = count, then chunk numbers
     hipError_t e = hipMemsetAsync(d_ws, 0, 64 + 16, st);
     if (e != hipSuccess || p.nchunks == 0) return e;
+    if (p.order == 2) {
+        const uint64_t want2 = (p.nchunks + 255) / 256;
+        const uint64_t cap2 = uint64_t(cu_count()) * 8;
+        hipLaunchKernelGGL(decode2_kernel, dim3(unsigned(want2 > cap2 ? cap2 : want2)), dim3(256), 0, st, p);
+        return hipGetLastError();
+    }
     // instantiations: <SEC_LDS, SPR, DIRECT, K, GW, OUTB, PC, HC>
     // tables in LDS -> wide (2 streams, 64-byte granules and store bursts) or light (4 streams, 32-byte
     // granules and store bursts: 16-byte stores reach HBM as 32-byte writes, measured -14 %); L2 gathers -> light
@@ -1474,6 +1717,10 @@ hipError_t launch_build_index(IdxParams p, void *d_ws, hipStream_t st) {
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(p.n_symbols, 0, 8, st);
     if (e != hipSuccess || p.nbits == 0) return e;
+    if (p.order == 2) {            // order 2: the one-lane walk (the segment passes assume a one-byte context)
+        hipLaunchKernelGGL(build_index_kernel<2>, dim3(1), dim3(64), 0, st, p);
+        return hipGetLastError();
+    }
     const unsigned grid = unsigned((p.nseg + 255) / 256);
     const uint64_t nblk = (p.nseg + SCAN_BLOCK - 1) / SCAN_BLOCK;
     // One instance of the iteration = a first pass from guessed starts + passes that chase the changes.
@@ -1505,7 +1752,8 @@ hipError_t launch_build_index(IdxParams p, void *d_ws, hipStream_t st) {
         }
     }
     if (!converged) {      // segments that never re-synchronise: do it the slow, certain way
-        hipLaunchKernelGGL(build_index_kernel, dim3(1), dim3(64), 0, st, p);
+        if (p.order == 2) hipLaunchKernelGGL(build_index_kernel<2>, dim3(1), dim3(64), 0, st, p);
+        else hipLaunchKernelGGL(build_index_kernel<1>, dim3(1), dim3(64), 0, st, p);
         return hipGetLastError();
     }
     unsigned long long *blk_sum = reinterpret_cast<unsigned long long *>(ws + L.off_blk);

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(64) void tree_build_kernel(const unsigned long long
                     atomicMax(&s_maxlen, d);
                 }
             } else if (d <= 8) {
-                const uint32_t h = height[node] < 8 ? height[node] : 8;
+                const uint32_t h = height[node] < o.hcap ? height[node] : o.hcap;
                 atomicAdd(&prof[d], 1u << h);
                 if (d == 8) atomicAdd(&s_ntab8, 1u);
             }
@@ -233,12 +233,14 @@ __global__ __launch_bounds__(64) void tree_build_kernel(const unsigned long long
         const unsigned long long cd = ocode[s];
         o.len8[c * 256 + s] = uint8_t(l);
         o.code64[c * 256 + s] = cd;
-        const uint32_t slot = mh::enc_slot((s << 8) | c);
-        uint16_t e = 0;
-        if (l > uint32_t(mh::ENC16_MAX_LEN)) e = mh::ENC16_ESCAPE;
-        else if (l > 0) e = uint16_t((l << 12) | uint32_t(cd));
-        o.enc16[slot] = e;
-        o.len_slot[slot] = uint8_t(l);
+        if (o.enc16) {                                       // order 0/1: the encoder's LDS images
+            const uint32_t slot = mh::enc_slot((s << 8) | c);
+            uint16_t e = 0;
+            if (l > uint32_t(mh::ENC16_MAX_LEN)) e = mh::ENC16_ESCAPE;
+            else if (l > 0) e = uint16_t((l << 12) | uint32_t(cd));
+            o.enc16[slot] = e;
+            o.len_slot[slot] = uint8_t(l);
+        }
     }
     for (uint32_t i = lane; i < TB_NODE_STRIDE; i += 64) {
         const bool live = i < nn;
@@ -275,7 +277,8 @@ __global__ __launch_bounds__(256) void tree_pack_kernel(TreePackArgs a) {
     tr[tid] = 0;
     __syncthreads();
     const uint32_t P = a.P, nprim = 1u << P;
-    if (tid == 0) a.sec_base[c] = a.sec_base_val[c];
+    const uint32_t my_base = a.sec_base_in ? a.sec_base_in[c] : a.sec_base_val[c];
+    if (tid == 0 && !a.sec_base_in) a.sec_base[c] = my_base;
     if (root == 0xFFFFFFFFu) {                       // empty context: null tables
         if (tid < nprim) a.prim[(c << P) | tid] = DEC16_NULL;
         a.tree[c * TREE_STRIDE + tid] = 0;
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(256) void tree_pack_kernel(TreePackArgs a) {
         __syncthreads();
     }
     const uint32_t off = scan[tid] - tabsize;
-    const uint32_t base = a.sec_base_val[c];
+    const uint32_t base = my_base;
     if (tid < nprim) {
         uint16_t e;
         if (left[node] == NONE) e = uint16_t(DEC16_LEAF | (depth << 8) | sym[node]);      // a leaf reached at depth <= P fills its whole range

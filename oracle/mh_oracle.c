@@ -28,9 +28,12 @@ typedef struct {
 } table_t;
 
 struct mho_model {
-    int type;       /* src/coding.h:29-32 */
+    int type;       /* src/coding.h:29-32; 2 = the order-2 generalisation (parity unpinned, see mh_oracle.h) */
     table_t *t;     /* 1 table (Huffman) or 256 (Markov, src/markov_huffman.h:10) */
+    table_t **t2;   /* order 2: 65536 pointers, NULL = empty context */
 };
+
+
 
 /* ---------------------------------------------------------------- histogram */
 
@@ -48,6 +51,17 @@ void mho_histogram_o0(const uint8_t *data, size_t n, uint64_t *counts) {
     /* src/main.cpp:168-170 */
     memset(counts, 0, 256 * sizeof(uint64_t));
     for (size_t i = 0; i < n; i++) counts[data[i]]++;
+}
+
+/* order-2 generalisation (parity unpinned): counts[ctx * 256 + c]++, ctx = (byte before previous) << 8 |
+ * previous byte, both ' ' at the start (src/main.cpp:32 doubled) */
+void mho_histogram_o2(const uint8_t *data, size_t n, uint64_t *counts) {
+    unsigned ctx = 0x2020u;
+    memset(counts, 0, (size_t)MHO_O2_COUNTS * sizeof(uint64_t));
+    for (size_t i = 0; i < n; i++) {
+        counts[((size_t)ctx << 8) | data[i]]++;
+        ctx = ((ctx << 8) | data[i]) & 0xFFFFu;
+    }
 }
 
 /* ------------------------------------------------------- min_pq (exact heap) */
@@ -224,11 +238,31 @@ static void save_tree(const table_t *t, int node, bitwr *b) {
 
 mho_model *mho_model_from_counts(const uint64_t *counts, int order) {
     mho_model *m = (mho_model *)calloc(1, sizeof *m);
+    if (order == 2) {                                   /* generalisation: one table per two-byte context */
+        m->type = 2;
+        m->t2 = (table_t **)calloc(MHO_O2_CONTEXTS, sizeof(table_t *));
+        for (unsigned c = 0; c < MHO_O2_CONTEXTS; c++) {
+            const uint64_t *row = counts + 256u * (size_t)c;
+            int any = 0;
+            for (int s = 0; s < 256 && !any; s++) any = row[s] != 0;
+            if (!any) continue;
+            m->t2[c] = (table_t *)malloc(sizeof(table_t));
+            table_build(m->t2[c], row);
+        }
+        return m;
+    }
     int nt = order ? 256 : 1;
     m->type = order ? 1 : 0;
     m->t = (table_t *)calloc((size_t)nt, sizeof(table_t));
     for (int i = 0; i < nt; i++) table_build(&m->t[i], counts + 256 * i); /* src/markov_huffman.cpp:10-12 */
     return m;
+}
+
+static const unsigned char O2_MAGIC[4] = { 'M', 'H', '2', 1 };
+static int is_o2_table(const uint8_t *bytes, size_t n) {
+    if (n < 37 || bytes[0] != 0x80) return 0;
+    for (int i = 1; i < 33; i++) if (bytes[i]) return 0;
+    return memcmp(bytes + 33, O2_MAGIC, 4) == 0;
 }
 
 mho_model *mho_model_from_table(const uint8_t *bytes, size_t n, int *err) {
@@ -237,6 +271,22 @@ mho_model *mho_model_from_table(const uint8_t *bytes, size_t n, int *err) {
     if (err) *err = MHO_OK;
     /* src/main.cpp:147-161: first bit 0 -> Huffman tree, 1 -> Markov file */
     int first = (n > 0) ? ((bytes[0] >> 7) & 1) : 0;
+    if (is_o2_table(bytes, n)) {                        /* order-2 generalisation (see mh_oracle.h) */
+        bitrd b2 = { bytes + 37, (n - 37) * 8, 0, 0 };
+        m->type = 2;
+        m->t2 = (table_t **)calloc(MHO_O2_CONTEXTS, sizeof(table_t *));
+        for (unsigned c = 0; c < MHO_O2_CONTEXTS; c++) {
+            if (rd_bit(&b2)) {
+                table_t *t = m->t2[c] = (table_t *)malloc(sizeof(table_t));
+                table_init(t);
+                t->root = load_tree(t, &b2, 0);
+                if (b2.fail || t->root < 0 || !t->is_internal[t->root]) goto bad;
+                build_tables(t);
+            }
+            if (b2.fail) goto bad;
+        }
+        return m;
+    }
     if (first == 0) {
         m->type = 0;
         m->t = (table_t *)calloc(1, sizeof(table_t));
@@ -267,6 +317,7 @@ bad:
 
 void mho_model_free(mho_model *m) {
     if (!m) return;
+    if (m->t2) { for (unsigned c = 0; c < MHO_O2_CONTEXTS; c++) free(m->t2[c]); free(m->t2); }
     free(m->t);
     free(m);
 }
@@ -275,6 +326,18 @@ int mho_model_type(const mho_model *m) { return m->type; }
 
 size_t mho_model_write_table(const mho_model *m, uint8_t *out, size_t cap) {
     bitwr b = { out, cap, 0 };
+    if (m->type == 2) {                                 /* empty order-1 table + magic + 65536 x (0 | 1 + tree) */
+        wr_bit(&b, 1);
+        for (int i = 0; i < 256; i++) wr_bit(&b, 0);
+        for (int i = 0; i < 7; i++) wr_bit(&b, 0);
+        for (int i = 0; i < 4; i++) wr_byte(&b, O2_MAGIC[i]);
+        for (unsigned c = 0; c < MHO_O2_CONTEXTS; c++) {
+            const table_t *t = m->t2[c];
+            wr_bit(&b, t != NULL);
+            if (t) save_tree(t, t->root, &b);
+        }
+        return (size_t)((b.nbits + 7) / 8);
+    }
     if (m->type == 0) {
         save_tree(&m->t[0], m->t[0].root, &b);          /* src/huffman.cpp:83-85 */
     } else {
@@ -290,9 +353,23 @@ size_t mho_model_write_table(const mho_model *m, uint8_t *out, size_t cap) {
 
 /* -------------------------------------------------------------- lookups */
 
+static table_t g_empty_table;      /* an empty context of an order-2 model: no codes, null LUT */
+static int g_empty_ready = 0;
+static const table_t *empty_table(void) {
+    if (!g_empty_ready) { table_init(&g_empty_table); g_empty_ready = 1; }
+    return &g_empty_table;
+}
+
+/* prev: the previous byte (orders 0/1) or (byte before previous) << 8 | previous byte (order 2) */
 static const table_t *ctx_table(const mho_model *m, int prev) {
+    if (m->type == 2) { const table_t *t = m->t2[prev & 0xFFFF]; return t ? t : empty_table(); }
     return m->type ? &m->t[prev & 255] : &m->t[0];      /* src/markov_huffman.cpp:52-58 / src/huffman.cpp:71-73 */
 }
+/* context after symbol c */
+static unsigned next_ctx(const mho_model *m, unsigned ctx, unsigned c) {
+    return m->type == 2 ? (((ctx << 8) | c) & 0xFFFFu) : c;
+}
+static unsigned first_ctx(const mho_model *m) { return m->type == 2 ? 0x2020u : (unsigned)' '; }
 
 void mho_get_code(const mho_model *m, int prev, int sym, int *len, uint8_t *bits32) {
     const table_t *t = ctx_table(m, prev);
@@ -314,6 +391,20 @@ void mho_export_codes(const mho_model *m, uint8_t *len8, uint64_t *code64) {
     }
 }
 
+void mho_export_codes_o2(const mho_model *m, uint8_t *len8, uint64_t *code64) {
+    for (unsigned p = 0; p < MHO_O2_CONTEXTS; p++) {
+        const table_t *t = ctx_table(m, (int)p);
+        for (int s = 0; s < 256; s++) {
+            int l = t->code_len[s];
+            uint64_t c = 0;
+            for (int i = 0; i < l && i < 64; i++)
+                c = (c << 1) | ((t->code_bits[s][i >> 3] >> (7 - (i & 7))) & 1u);
+            len8[(size_t)p * 256 + s] = (uint8_t)l;
+            code64[(size_t)p * 256 + s] = c;
+        }
+    }
+}
+
 void mho_get_lut(const mho_model *m, int prev, int w, int *present, int *is_internal, int *value, int *depth) {
     const table_t *t = ctx_table(m, prev);
     int n = t->lut[w & 255];
@@ -327,13 +418,13 @@ void mho_get_lut(const mho_model *m, int prev, int w, int *present, int *is_inte
 size_t mho_compress(const mho_model *m, const uint8_t *in, size_t n, uint8_t *out, size_t cap, uint64_t *nbits) {
     /* src/coding.cpp:61-94.  out[0] is the header; payload starts at out[1]. */
     bitwr b = { cap ? out + 1 : out, cap ? cap - 1 : 0, 0 };
-    unsigned prev = ' ';                                /* :67 */
+    unsigned prev = first_ctx(m);                       /* :67 (order 2: both context bytes start as ' ') */
     uint64_t acc = 0; int accn = 0;                     /* MSB-first accumulator of pending bits */
     for (size_t i = 0; i < n; i++) {
         const table_t *t = ctx_table(m, (int)prev);     /* :71 get_encoding(prev, c) */
         unsigned c = in[i];
         int l = t->code_len[c];                         /* length 0: symbol silently skipped under NDEBUG (:72) */
-        prev = c;                                       /* :74 */
+        prev = next_ctx(m, prev, c);                    /* :74 */
         if (l <= 32) {                                  /* src/bitbuffer.cpp:45-73, batched */
             const unsigned char *cb = t->code_bits[c];
             uint64_t v = ((uint64_t)cb[0] << 24) | ((uint64_t)cb[1] << 16) | ((uint64_t)cb[2] << 8) | cb[3];
@@ -360,7 +451,8 @@ size_t mho_compress(const mho_model *m, const uint8_t *in, size_t n, uint8_t *ou
         if (byte < b.cap) b.p[byte] = (uint8_t)(acc << (8 - accn));
     }
     int bi = (int)(total & 7);                          /* src/coding.cpp:85 get_bi() */
-    if (cap) out[0] = (uint8_t)(0x30 | ((~m->type & 1) << 3) | ((8 - bi) % 8));  /* :88 */
+    if (cap) out[0] = m->type == 2 ? (uint8_t)(0x40 | ((8 - bi) % 8))         /* order 2: own magic nibble */
+                                   : (uint8_t)(0x30 | ((~m->type & 1) << 3) | ((8 - bi) % 8));  /* :88 */
     if (nbits) *nbits = total;
     return 1 + (size_t)((total + 7) / 8);
 }
@@ -371,14 +463,18 @@ int64_t mho_decompress(const mho_model *m, const uint8_t *in, size_t n, uint8_t 
     /* src/coding.cpp:96-160 */
     if (n < 1) return MHO_ERR_CORRUPT;
     unsigned header = in[0];                            /* :100 */
-    if ((header & 0xF0) != 0x30) return MHO_ERR_CORRUPT;                    /* :103-106 */
-    if (((~(header & (1 << 3)) >> 3) & 1) != (unsigned)m->type) return MHO_ERR_TYPE;  /* :107-110 */
+    if (m->type == 2) {
+        if ((header & 0xF8) != 0x40) return (header & 0xF0) == 0x30 ? MHO_ERR_TYPE : MHO_ERR_CORRUPT;
+    } else {
+        if ((header & 0xF0) != 0x30) return MHO_ERR_CORRUPT;                    /* :103-106 */
+        if (((~(header & (1 << 3)) >> 3) & 1) != (unsigned)m->type) return MHO_ERR_TYPE;  /* :107-110 */
+    }
     int remainder = header & 7;                         /* :111 */
     int64_t length = (int64_t)(n - 1) * 8 - remainder;  /* :115 (reference: int) */
     const uint8_t *p = in + 1;
     int64_t avail = (int64_t)(n - 1) * 8;               /* bits physically present */
     int64_t pos = 0;                                    /* bitbuffer read cursor */
-    unsigned prev = ' ';                                /* :118 */
+    unsigned prev = first_ctx(m);                       /* :118 */
     int64_t bi = 0;                                     /* :120 */
     unsigned w = 0; int wi = 0;                         /* :122-123 */
     int64_t nout = 0;
@@ -403,7 +499,7 @@ int64_t mho_decompress(const mho_model *m, const uint8_t *in, size_t n, uint8_t 
                 if (!t->is_internal[node]) {
                     if ((size_t)nout < cap) out[nout] = t->value[node];
                     nout++;
-                    prev = t->value[node];
+                    prev = next_ctx(m, prev, t->value[node]);
                     break;
                 }
             }
@@ -411,7 +507,7 @@ int64_t mho_decompress(const mho_model *m, const uint8_t *in, size_t n, uint8_t 
         } else {                                        /* :150-156 */
             if ((size_t)nout < cap) out[nout] = t->value[node];
             nout++;
-            prev = t->value[node];
+            prev = next_ctx(m, prev, t->value[node]);
             w = (w << t->depth[node]) & 0xFF;
             wi = 8 - t->depth[node];
             bi += t->depth[node];

@@ -8,7 +8,8 @@
  * link or call this file: the product path is the HIP library and fails
  * loudly without it.
  *
- * Parity status: PINNED.  tests/test_oracle_golden.py checks this code
+ * Parity status: PINNED for orders 0 and 1 (the order-2 section at the end is a generalisation the
+ * reference does not implement: PARITY UNPINNED, see there).  tests/test_oracle_golden.py checks this code
  * against (a) the golden vectors of SURVEY.md §8(c) — produced in this
  * container by the genuine reference compiled into oracle/_ref/ — and
  * (b) the reference binary itself whenever oracle/_ref/markovhuffman exists.
@@ -71,6 +72,34 @@ size_t mho_compress(const mho_model *m, const uint8_t *in, size_t n, uint8_t *ou
 /* src/coding.cpp:96-160.  in = whole compressed file (header + payload).  Returns decoded byte count
  * (writes min(count, cap) bytes) or a negative MHO_ERR_*. */
 int64_t mho_decompress(const mho_model *m, const uint8_t *in, size_t n, uint8_t *out, size_t cap);
+
+/* ---------------------------------------------------------------------------------------------
+ * ORDER 2 (context = the previous TWO bytes) — GENERALISATION, PARITY UNPINNED.
+ *
+ * The reference implements order 1 only and merely speculates about higher orders
+ * (README.md:158-166), so nothing here can be checked against it.  This is the SPEC the HIP path is
+ * compared with: the same per-context algorithm (src/huffman.cpp:131-164, the same heap, the same
+ * tie-breaks, the same one-symbol hack) applied to 65536 contexts ctx = (byte before previous) << 8 |
+ * previous byte, both starting as ' ' (the reference's initial context, src/main.cpp:32, doubled).
+ *   counts      counts[ctx * 256 + c], 1 << 24 entries
+ *   stream      header byte 0x40 | unused bits of the last byte (the reference's magic is 0x30,
+ *               src/coding.cpp:103-106: its decompress reports such a file as corrupt instead of
+ *               decoding it with the wrong tables), then the MSB-first payload as for order 1
+ *   table file  the 33 bytes of an EMPTY order-1 table (bit 1 + 256 zero bits, zero padded: what the
+ *               reference's loader accepts and what main()'s first-bit sniffing, src/main.cpp:147-161,
+ *               takes for a Markov table with no contexts), then the magic "MH2\x01", then for each of
+ *               the 65536 contexts bit 0 (empty) or bit 1 + the pre-order tree of
+ *               src/huffman.cpp:174-188, zero padded to a byte.  A genuine empty order-1 table is exactly
+ *               33 bytes long, so the two cannot be confused.
+ */
+#define MHO_O2_CONTEXTS 65536
+#define MHO_O2_COUNTS (1u << 24)
+void mho_histogram_o2(const uint8_t *data, size_t n, uint64_t *counts /* 1 << 24 */);
+/* order == 2 in mho_model_from_counts takes 1 << 24 counts; mho_model_from_table recognises the
+ * order-2 file; mho_model_type returns 2; mho_compress / mho_decompress / mho_model_write_table work
+ * on such a model as described above. */
+/* Bulk export for order 2: len8[ctx*256+sym], code64 right-aligned; 1 << 24 entries each. */
+void mho_export_codes_o2(const mho_model *m, uint8_t *len8, uint64_t *code64);
 
 #ifdef __cplusplus
 }

@@ -29,6 +29,8 @@ def _load():
     lib = C.CDLL(_LIB)
     lib.mho_histogram_o1.argtypes = [C.c_void_p, C.c_size_t, C.c_uint8, C.c_void_p]
     lib.mho_histogram_o0.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.mho_histogram_o2.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.mho_export_codes_o2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mho_model_from_counts.argtypes = [C.c_void_p, C.c_int]
     lib.mho_model_from_counts.restype = C.c_void_p
     lib.mho_model_from_table.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]
@@ -75,6 +77,14 @@ def histogram_o0(data):
     return out
 
 
+def histogram_o2(data):
+    """Order-2 generalisation (parity unpinned): counts[ctx * 256 + c], ctx = two previous bytes, '  ' first."""
+    a = _as_u8(data)
+    out = np.zeros(1 << 24, dtype=np.uint64)
+    lib().mho_histogram_o2(a.ctypes.data, a.size, out.ctypes.data)
+    return out
+
+
 class Model:
     """Owns an mho_model*."""
 
@@ -86,12 +96,20 @@ class Model:
     @classmethod
     def from_counts(cls, counts, order):
         c = np.ascontiguousarray(counts, dtype=np.uint64)
-        assert c.size == (65536 if order else 256)
+        assert c.size == {0: 256, 1: 65536, 2: 1 << 24}[order]
         return cls(lib().mho_model_from_counts(c.ctypes.data, order))
 
     @classmethod
     def from_data(cls, data, order=1):
-        return cls.from_counts(histogram_o1(data) if order else histogram_o0(data), order)
+        hist = {0: histogram_o0, 1: histogram_o1, 2: histogram_o2}[order]
+        return cls.from_counts(hist(data), order)
+
+    def codes_o2(self):
+        """(len8[1 << 24], code64[1 << 24]) indexed ctx*256+sym for an order-2 model."""
+        l = np.zeros(1 << 24, dtype=np.uint8)
+        c = np.zeros(1 << 24, dtype=np.uint64)
+        lib().mho_export_codes_o2(self._h, l.ctypes.data, c.ctypes.data)
+        return l, c
 
     @classmethod
     def from_table(cls, table_bytes):

@@ -110,7 +110,11 @@ def test_argument_errors(mhc):
     h = ctypes.c_void_p()
     assert lib.mh_model_from_counts(None, 1, ctypes.byref(h)) == mhc.MH_ERR_ARG
     counts = np.zeros(65536, dtype=np.uint64)
-    assert lib.mh_model_from_counts(counts.ctypes.data, 2, ctypes.byref(h)) == mhc.MH_ERR_ARG
+    assert lib.mh_model_from_counts(counts.ctypes.data, 3, ctypes.byref(h)) == mhc.MH_ERR_ARG
+    assert lib.mh_model_from_counts(counts.ctypes.data, -1, ctypes.byref(h)) == mhc.MH_ERR_ARG
+    if mhc.device_count() == 0:      # the order-2 extension builds on the device only: no host-only model
+        big = np.zeros(1 << 24, dtype=np.uint64)
+        assert lib.mh_model_from_counts(big.ctypes.data, 2, ctypes.byref(h)) == mhc.MH_ERR_NO_DEVICE
 
 
 def test_compute_refuses_without_gpu(mhc):

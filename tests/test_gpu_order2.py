@@ -1,0 +1,135 @@
+"""ORDER 2 (context = the previous two bytes; SURVEY.md §8(f) N4, BASELINE config 5) on the GPU.
+
+PARITY UNPINNED: the reference implements order 1 only (README.md:158-166 speculates about higher orders),
+so there is no reference output to compare with.  The spec is the generalised oracle (oracle/mh_oracle.h,
+order-2 section: the reference's per-context algorithm applied to 65536 two-byte contexts); these tests
+show GPU == that oracle bit for bit (counts, table file, every codeword, the stream) plus round trips."""
+import numpy as np
+import pytest
+
+import __graft_entry__ as entry
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mhc():
+    mod = entry.load_package()
+    mod.lib()
+    assert mod.device_count() >= 1
+    return mod
+
+
+def text_like(n, seed):
+    rng = np.random.default_rng(seed)
+    words = [b"lorem", b"ipsum", b"dolor", b"sit", b"amet", b"consectetur", b"adipiscing", b"elit", b"sed", b"do",
+             b"eiusmod", b"tempor", b"incididunt", b"ut", b"labore", b"et", b"dolore", b"magna", b"aliqua"]
+    out = bytearray()
+    while len(out) < n:
+        out += words[int(rng.integers(len(words)))] + (b". " if rng.random() < 0.1 else b" ")
+    return bytes(out[:n])
+
+
+def zipf_bytes(n, seed, s=1.1, k=256):
+    rng = np.random.default_rng(seed)
+    w = 1.0 / np.arange(1, k + 1) ** s
+    return rng.choice(k, size=n, p=w / w.sum()).astype(np.uint8).tobytes()
+
+
+CASES = {
+    "ipsum": lambda: golden()["input_ipsum.txt"]["data"],
+    "wiki_html": lambda: golden()["input_wiki_cpp.html"]["data"],
+    "kat1": lambda: golden()["kat1"]["data"],
+    "kat3": lambda: golden()["kat3"]["data"],
+    "empty": lambda: b"",
+    "one_Z": lambda: b"Z",
+    "text_1m": lambda: text_like((1 << 20) + 7, 3),
+    "zipf32_512k": lambda: zipf_bytes(1 << 19, 5, k=32),
+    "zipf256_2m": lambda: zipf_bytes((1 << 21) + 3, 6),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_order2_histogram_parity_unpinned(mhc, oracle, name):
+    data = CASES[name]()
+    assert np.array_equal(mhc.histogram_o2(data), oracle.histogram_o2(data))
+
+
+@pytest.mark.parametrize("n", [1, 2, 15, 16, 17, 33, 4097, 65536 + 5])
+def test_order2_histogram_ragged_sizes_parity_unpinned(mhc, oracle, n):
+    data = zipf_bytes(n, n, k=16)
+    assert np.array_equal(mhc.histogram_o2(data), oracle.histogram_o2(data))
+
+
+def test_order2_histogram_repeated_pair_parity_unpinned(mhc):
+    """A run of one repeated byte: every lane of every workgroup lands in ONE slot of the LDS counter cache."""
+    n = 8 << 20
+    data = b"\x00" * n
+    h = mhc.histogram_o2(data)
+    exp = np.zeros(1 << 24, dtype=np.uint64)
+    exp[0x202000] = 1
+    exp[0x200000] = 1
+    exp[0] = n - 2
+    assert np.array_equal(h, exp)
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_order2_tables_stream_and_round_trip_parity_unpinned(mhc, oracle, name):
+    data = CASES[name]()
+    m = mhc.Model.from_data(data, 2)
+    o = oracle.Model.from_data(data, 2)
+    assert m.type == 2
+    table = m.table_bytes()
+    assert table == o.table_bytes()
+    lg, cg = m.codes_o2()
+    lo, co = o.codes_o2()
+    assert np.array_equal(lg, lo) and np.array_equal(cg, co)
+    blob, nbits, idx = m.compress(data, chunk_symbols=256)
+    ref, ref_bits = o.compress(data)
+    assert (nbits, blob) == (ref_bits, ref)
+    assert blob[0] & 0xF8 == 0x40                                 # the extension's own magic nibble
+    assert m.decompress(blob, index=idx, chunk_symbols=256, n_symbols=len(data)) == data
+    assert o.decompress(blob) == data
+    # a model loaded from the table file: same device images as the device-built one, same stream
+    t = mhc.Model.from_table(table)
+    assert t.type == 2 and t.table_bytes() == table
+    for which in (1, 3, 4, 5, 6, 7):
+        assert t.image(which) == m.image(which), "image %d differs" % which
+    assert t.compress(data)[0] == blob
+
+
+@pytest.mark.parametrize("name", ["ipsum", "kat1", "one_Z", "zipf32_512k"])
+def test_order2_decode_without_index_parity_unpinned(mhc, oracle, name):
+    """No sidecar: the one-lane index walk (order 2 has no parallel index builder yet)."""
+    data = CASES[name]()
+    o = oracle.Model.from_data(data, 2)
+    blob, _ = o.compress(data)
+    m = mhc.Model.from_table(o.table_bytes())
+    assert m.decompress(blob) == data
+
+
+def test_order2_stream_and_table_types_are_kept_apart(mhc, oracle):
+    data = CASES["ipsum"]()
+    m2 = mhc.Model.from_data(data, 2)
+    m1 = mhc.Model.from_data(data, 1)
+    b2, _, _ = m2.compress(data)
+    b1, _, _ = m1.compress(data)
+    with pytest.raises(mhc.MhError) as e:
+        m1.decompress(b2)
+    assert e.value.status == mhc.MH_ERR_TYPE
+    with pytest.raises(mhc.MhError) as e:
+        m2.decompress(b1)
+    assert e.value.status == mhc.MH_ERR_TYPE
+    # the reference's loader (here: the order-1 oracle path) takes an order-2 table file for an empty order-1 table
+    assert len(b2) < len(b1)                                      # and order 2 does compress this text better
+
+
+def test_order2_large_text_round_trip_parity_unpinned(mhc, oracle):
+    n = (32 << 20) + 11
+    data = text_like(n, 9)
+    m = mhc.Model.from_data(data, 2)
+    blob, nbits, idx = m.compress(data, chunk_symbols=1024)
+    ref, ref_bits = oracle.Model.from_data(data, 2).compress(data)
+    assert nbits == ref_bits and blob == ref
+    assert m.decompress(blob, index=idx, chunk_symbols=1024, n_symbols=n) == data

@@ -134,3 +134,35 @@ def test_live_differential_vs_reference_binary(oracle, tmp_path, seed, order):
     # and the oracle decodes the reference's stream with the reference's table
     loaded = oracle.Model.from_table((tmp_path / "out.e").read_bytes())
     assert loaded.decompress((tmp_path / "out.c").read_bytes()) == data
+
+
+def test_order2_generalisation_self_consistency_parity_unpinned(oracle):
+    """The order-2 section of the oracle is a generalisation the reference does not have (parity
+    unpinned).  What CAN be checked on the CPU: it round-trips, its table file reloads to the same
+    codes, and restricted to data whose second context byte never matters it reproduces order 1."""
+    data = golden()["input_ipsum.txt"]["data"]
+    m = oracle.Model.from_data(data, 2)
+    blob, nbits = m.compress(data)
+    assert blob[0] & 0xF8 == 0x40
+    assert m.decompress(blob) == data
+    t = m.table_bytes()
+    assert t[:33] == b"\x80" + bytes(32) and t[33:37] == b"MH2\x01"
+    m2 = oracle.Model.from_table(t)
+    assert m2.type == 2 and m2.compress(data)[0] == blob
+    assert oracle.Model.from_table(t[:33]).type == 1               # the prefix alone is the reference's empty Markov table
+    # kat3 = bytes(range(256)) * 64: every byte determines its successor, so order 1 and order 2 both
+    # give 1-bit codes everywhere and the payloads have the same length
+    k3 = golden()["kat3"]["data"]
+    assert oracle.Model.from_data(k3, 2).compress(k3)[1] == oracle.Model.from_data(k3, 1).compress(k3)[1]
+
+
+def test_order2_table_file_loads_on_the_host_side_of_the_library(oracle):
+    """The library parses an order-2 table file without a device (type, write-back)."""
+    import __graft_entry__ as entry
+    entry.build()
+    mhc = entry.load_package()
+    data = golden()["input_wiki_cpp.txt"]["data"]
+    t = oracle.Model.from_data(data, 2).table_bytes()
+    m = mhc.Model.from_table(t)
+    assert m.type == 2
+    assert m.table_bytes() == t
