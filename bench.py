@@ -137,9 +137,9 @@ class Codec:
     here, once: the timed step allocates nothing and waits for the device exactly once (the 16 KiB of table
     sizes the host needs to pick the decode-table layout)."""
 
-    def __init__(self, mhc, n, device):
-        self.mhc, self.lib, self.n, self.device = mhc, mhc.lib(), n, device
-        self.counts = torch.zeros(65536, dtype=torch.int64, device=device)
+    def __init__(self, mhc, n, device, order=1):
+        self.mhc, self.lib, self.n, self.device, self.order = mhc, mhc.lib(), n, device, order
+        self.counts = torch.zeros(65536 if order == 1 else 1 << 24, dtype=torch.int64, device=device)
         self.cap = n + (64 << 20)
         self.payload = torch.empty(self.cap, dtype=torch.uint8, device=device)
         self.decoded = torch.empty(n, dtype=torch.uint8, device=device)
@@ -164,11 +164,17 @@ class Codec:
         return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def histogram(self, data, prev0, n=None):
+        if self.order == 2:         # extension (parity unpinned): 65536 two-byte contexts, counts in HBM
+            self.check(self.lib.mh_dev_histogram_o2(data.data_ptr(), self.n if n is None else n, prev0 << 8 | prev0,
+                                                    self.counts.data_ptr(), self.stream()), "hist2")
+            return
         self.check(self.lib.mh_dev_histogram_o1(data.data_ptr(), self.n if n is None else n, prev0, self.counts.data_ptr(),
                                                 self.hist_ws.data_ptr(), self.hist_ws_bytes, self.stream()), "hist")
 
     def build_model(self):
         """Tables built on the device into the preallocated workspace: no allocation, one stream sync."""
+        if self.order == 2:         # 65536 trees; this build allocates its (data-dependent) tables itself
+            return self.mhc.Model.from_device_counts(self.counts.data_ptr(), 2, self.stream())
         return self.mhc.Model.from_device_counts_ws(self.counts.data_ptr(), 1, self.model_ws.data_ptr(), self.model_ws_bytes,
                                                     self.stream())
 
@@ -244,6 +250,8 @@ def main():
     ap.add_argument("--config", type=int, default=3, choices=[3, 4],
                     help="BASELINE.json configs[]: 3 (default) = 16 GiB Zipf(1.1) per GPU; 4 = uniform random, 8 GiB per GPU (64 GiB on 8)")
     ap.add_argument("--kind", default=None, choices=["zipf", "uniform", "text"])
+    ap.add_argument("--order", type=int, default=1, choices=[1, 2],
+                    help="2 = order-2 contexts (BASELINE configs[4]; extension the reference does not have: parity unpinned; 1 GPU)")
     ap.add_argument("--cpu-sample", type=int, default=256 << 20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -285,6 +293,8 @@ def main():
     mhc = entry.load_package()
     mhc.lib()                      # fails loudly if libmhc.so is missing: there is no fallback path
     kind = args.kind or ("uniform" if args.config == 4 else "zipf")
+    if args.order == 2 and world > 1:
+        raise SystemExit("--order 2 runs on one GPU (its 128 MiB histogram all-reduce is not wired up yet)")
     # ---- what each rank holds: bytes [first, first + n) of ONE seeded stream
     if args.total_size is not None:
         mode, total = "strong", args.total_size
@@ -308,7 +318,7 @@ def main():
         all_gather(last, data[-1:].clone())
         if rank > 0:
             prev0 = int(last[rank - 1].item())
-    codec = Codec(mhc, n, device)
+    codec = Codec(mhc, n, device, args.order)
     all_bits = torch.zeros(world, dtype=torch.int64, device=device)
     my_bits = torch.zeros(1, dtype=torch.int64, device=device)
     start_bit = torch.zeros(1, dtype=torch.int64, device=device)
@@ -392,6 +402,10 @@ def main():
             "decode_kernel": ((1.0 + r) * n, ms["decode"]),
         }
         dom = max(kernels, key=lambda k: kernels[k][1])
+        if args.order == 2:
+            kernels = {k.replace("hist_o1", "hist_o2").replace("encode_kernel", "enc2_emit_kernel").replace("decode_kernel", "decode2_kernel"): v
+                       for k, v in kernels.items()}
+            dom = max(kernels, key=lambda k: kernels[k][1])
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -402,8 +416,9 @@ def main():
         ach = kernels[dom][0] / (kernels[dom][1] * 1e-3) / 1e9
         kname = {"zipf": "Zipf(s=1.1)", "uniform": "uniform", "text": "Lorem-Ipsum-style ASCII"}[kind]
         if mode == "weak":
-            workload = ("order-1 Markov-Huffman round trip (histogram+tree+encode+decode), %d GiB %s per GPU, "
-                        "chunk index every %d symbols" % (n >> 30, kname, CHUNK))
+            workload = ("order-%d Markov-Huffman round trip (histogram+tree+encode+decode), %s %s per GPU, "
+                        "chunk index every %d symbols%s" % (args.order, ("%d GiB" % (n >> 30)) if n >= 1 << 30 else ("%d MiB" % (n >> 20)),
+                                                            kname, CHUNK, " [order 2: extension, parity unpinned]" if args.order == 2 else ""))
         else:
             workload = ("order-1 Markov-Huffman round trip (histogram+tree+encode+decode), ONE %.3f GiB %s stream split into %d "
                         "contiguous shards (strong scaling), chunk index every %d symbols" % (total / 2.0 ** 30, kname, world, CHUNK))
@@ -429,7 +444,10 @@ def main():
             "max_code_len": model.max_code_len,
             "decode_tables": dict(zip(("primary_bits", "secondary_entries", "in_lds"), model.decode_layout())),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if args.order == 2:
+            out["order"] = 2
+            out["parity"] = "unpinned: the reference has no order 2; checked against the generalised oracle in tests/test_gpu_order2.py"
+        if world == 1 and not args.no_cpu_baseline and args.order == 1:
             sample_n = min(args.cpu_sample, n) & ~(CHUNK - 1)
             sample = data[:sample_n].cpu().numpy().tobytes()
 

@@ -14,7 +14,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmhc.so")
+# MH_LIB: an experimental build of the same library (csrc/Makefile `make exp TAG=x EXPFLAGS=-D...`), for A/B runs
+LIB_PATH = os.environ.get("MH_LIB") or os.path.join(_HERE, "libmhc.so")
 
 MH_OK = 0
 MH_ERR_ARG, MH_ERR_NO_DEVICE, MH_ERR_HIP, MH_ERR_CORRUPT, MH_ERR_TYPE = -1, -2, -3, -4, -5

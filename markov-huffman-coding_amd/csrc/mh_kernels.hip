@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
 #include <mutex>
 
 #include "mh_kernels.h"
@@ -31,6 +32,27 @@ using mh::TREE_STRIDE;
 // ------------------------------------------------------------------------------------------------
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+// 16-byte streaming accesses of the decoder (payload granules in, decoded bytes out).  MH_EXP_NT (A/B
+// builds, csrc/Makefile `exp`): non-temporal, i.e. past the vector L1, so that the randomly gathered
+// second-level table lines are what stays there.
+typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld_stream16(const uint4 *p) {
+#ifdef MH_EXP_NT
+    const v4u32 v = __builtin_nontemporal_load(reinterpret_cast<const v4u32 *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void st_stream16(uint4 *p, const uint4 &v) {
+#ifdef MH_EXP_NTS
+    v4u32 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<v4u32 *>(p));
+#else
+    *p = v;
+#endif
+}
 
 // Inclusive prefix sum over the 64 lanes of a wave with DPP row shifts / row broadcasts (7 VALU
 // instructions; the __shfl_up form costs six LDS-crossbar round trips).
@@ -733,35 +755,46 @@ __device__ __forceinline__ uint32_t decode_one(const uint16_t *prim, const uint3
 // set-up use the checked pop.
 // GW = dwords per granule: 8 (32 bytes) or 16 (64 bytes: half the read amplification, twice the
 // registers).  A block is 2 * GW symbols (<= 16 bits each through the tables = one granule).
-template <int GW>
+// DEPTH = granules a stream keeps beside `cur`: 2 (`nxt` resident + `pre` in flight: a granule is consumed
+// one block after it was asked for, so the block-boundary loads never make a pop wait) or 1 (`nxt` alone,
+// loaded straight into: eight registers per stream fewer, which is what lets a lane run more streams; the
+// switch cur <- nxt may then wait for a load that was issued at the last block boundary).
+template <int GW, int DEPTH = 2>
 struct LaneStream {
     static constexpr int NQ = GW / 4;      // uint4 loads per granule
+    static constexpr uint32_t BEHIND = DEPTH + 1;   // `cur` holds granule gnext - BEHIND while nxt is full
     const uint4 *base;    // payload (wave-uniform: lives in SGPRs)
     uint32_t glast;       // last readable granule of the payload (wave-uniform)
-    uint32_t gnext;       // granule (counted from the payload start) that goes into `pre` next
+    uint32_t gnext;       // granule (counted from the payload start) that is loaded next
     uint32_t cur[GW];     // granule feeding the window, cur[0] is next
     uint32_t ccnt;        // dwords left in cur
-    uint32_t nxt[GW];     // following granule, resident
+    uint32_t nxt[GW];     // following granule (DEPTH 1: possibly still in flight)
     bool nxt_full;
-    uint32_t pre[GW];     // the one after, possibly still in flight
+    uint32_t pre[DEPTH == 2 ? GW : 1];     // DEPTH 2: the one after, possibly still in flight
+
     uint64_t buf;         // next bits, first at bit 63
     uint32_t cnt;         // valid bits in buf
 
-    __device__ __forceinline__ void issue_pre() {
+    __device__ __forceinline__ void issue_into(uint32_t (&dst)[GW]) {
         const uint32_t g = gnext < glast ? gnext : glast;
         const uint4 *src = base + uint64_t(NQ) * g;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const uint4 a = src[q];
-            pre[4 * q] = a.x; pre[4 * q + 1] = a.y; pre[4 * q + 2] = a.z; pre[4 * q + 3] = a.w;
+            const uint4 a = ld_stream16(src + q);
+            dst[4 * q] = a.x; dst[4 * q + 1] = a.y; dst[4 * q + 2] = a.z; dst[4 * q + 3] = a.w;
         }
         ++gnext;
+    }
+    __device__ __forceinline__ void issue_pre() {
+        if constexpr (DEPTH == 2) issue_into(pre); else issue_into(nxt);
     }
     // wave-synchronous point (block boundary): the only place where loads are issued and awaited
     __device__ __forceinline__ void block_sync() {
         if (!nxt_full) {
+            if constexpr (DEPTH == 2) {
 #pragma unroll
-            for (int i = 0; i < GW; ++i) nxt[i] = pre[i];
+                for (int i = 0; i < GW; ++i) nxt[i] = pre[i];
+            }
             nxt_full = true;
             issue_pre();
         }
@@ -808,15 +841,24 @@ struct LaneStream {
         base = reinterpret_cast<const uint4 *>(payload);
         glast = uint32_t((total_bytes - 1) / (GW * 4));       // payloads stay below 2^32 granules (128 GiB)
         gnext = uint32_t(w / GW);
-        issue_pre();
+        if constexpr (DEPTH == 2) {
+            issue_into(pre);
 #pragma unroll
-        for (int i = 0; i < GW; ++i) cur[i] = pre[i];
-        ccnt = GW;
-        issue_pre();
+            for (int i = 0; i < GW; ++i) cur[i] = pre[i];
+            ccnt = GW;
+            issue_into(pre);
 #pragma unroll
-        for (int i = 0; i < GW; ++i) nxt[i] = pre[i];
-        nxt_full = true;
-        issue_pre();
+            for (int i = 0; i < GW; ++i) nxt[i] = pre[i];
+            nxt_full = true;
+            issue_into(pre);
+        } else {
+            issue_into(nxt);
+#pragma unroll
+            for (int i = 0; i < GW; ++i) cur[i] = nxt[i];
+            ccnt = GW;
+            issue_into(nxt);
+            nxt_full = true;
+        }
         for (uint32_t skip = uint32_t(w % GW); skip; --skip) (void)pop_word<true>();
         const uint32_t hi = __builtin_bswap32(pop_word<true>());
         const uint32_t lo = __builtin_bswap32(pop_word<true>());
@@ -831,11 +873,11 @@ struct LaneStream {
             cnt += 32u;
         }
     }
-    // position of the next unread bit in the payload, modulo 2^32: `cur` holds granule gnext - 3
-    // (gnext - 2 while `nxt` is empty), GW - ccnt of its dwords have gone into the window, cnt bits of
+    // position of the next unread bit in the payload, modulo 2^32: `cur` holds granule gnext - BEHIND
+    // (one more while `nxt` is empty), GW - ccnt of its dwords have gone into the window, cnt bits of
     // the window are still unread
     __device__ __forceinline__ uint32_t position() const {
-        const uint32_t gran = gnext - (nxt_full ? 3u : 2u);
+        const uint32_t gran = gnext - (nxt_full ? BEHIND : BEHIND - 1u);
         return (gran * GW + (GW - ccnt)) * 32u - cnt;
     }
 };
@@ -988,7 +1030,7 @@ __device__ __forceinline__ void decode_chunk_single(const uint16_t *lut, const u
 // re-fetch every 128-byte line four times, 16-byte stores double the write traffic), so they run
 // K = 2 with 64-byte granules and 64-byte store bursts; models that gather from L2 are bound by that
 // latency and run K = 4 with the lighter 32-byte / 16-byte streams.
-template <bool SEC_LDS, int SPR, bool DIRECT, int K, int GW, int OUTB, int PC, int HC, bool REDO = false, int NT = 512>
+template <bool SEC_LDS, int SPR, bool DIRECT, int K, int GW, int OUTB, int PC, int HC, bool REDO = false, int NT = 512, int DEPTH = 2>
 __global__ __launch_bounds__(NT) void decode_kernel(DecParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (REDO && p.redo[0] == 0) return;                         // the usual case: nothing was handed over
@@ -1035,7 +1077,7 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecParams p) {
         const uint64_t c0 = g0 + threadIdx.x;                   // stream k -> chunk c0 + k * NT
         if (c0 + uint64_t(K - 1) * NT < full_chunks) {
             // ---- K full chunks: interleaved decode
-            LaneStream<GW> ls[K];
+            LaneStream<GW, DEPTH> ls[K];
             uint32_t prev[K];
             bool ok = true;
 #pragma unroll
@@ -1084,7 +1126,7 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecParams p) {
                 for (int k = 0; k < K; ++k) {
                     uint4 *o16 = reinterpret_cast<uint4 *>(p.out + ((c0 + uint64_t(k) * NT) << p.chunk_shift)) + burst * OUTB;
 #pragma unroll
-                    for (int u = 0; u < OUTB; ++u) o16[u] = make_uint4(Q[k][u][0], Q[k][u][1], Q[k][u][2], Q[k][u][3]);
+                    for (int u = 0; u < OUTB; ++u) st_stream16(o16 + u, make_uint4(Q[k][u][0], Q[k][u][1], Q[k][u][2], Q[k][u][3]));
                 }
             }
             // every chunk must end exactly where the next one starts (null entries, a wrong table or a
@@ -1631,6 +1673,11 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
     auto k_lds4_light = decode_kernel<true, 4, false, 4, 8, 2, 8, 0>;
     auto k_l2 = decode_kernel<false, 2, false, 4, 8, 2, 8, 0>;
     void (*k_l2d[2])(DecParams) = {decode_kernel<false, 2, true, 4, 8, 2, 8, 0>, decode_kernel<false, 2, true, 4, 8, 2, 8, 8>};
+    // A/B variants of the L2-direct decoder (MH_DEC_VARIANT=1..): more streams per lane on the shallower FIFO
+    auto x_k4d1 = decode_kernel<false, 2, true, 4, 8, 2, 8, 0, false, 512, 1>;
+    auto x_k5d1 = decode_kernel<false, 2, true, 5, 8, 2, 8, 0, false, 512, 1>;
+    auto x_k6d1 = decode_kernel<false, 2, true, 6, 8, 2, 8, 0, false, 512, 1>;
+    auto x_k6d1o1 = decode_kernel<false, 2, true, 6, 8, 1, 8, 0, false, 512, 1>;
     // redo pass (one lane per handed-over chunk, runtime table widths)
     auto r_lds = decode_kernel<true, 2, false, 1, 8, 1, 0, 0, true>;
     auto r_l2 = decode_kernel<false, 2, false, 1, 8, 1, 0, 0, true>;
@@ -1638,7 +1685,8 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
     e = once_per_device(&DeviceState::decode_ready, [&] {
         const void *all[] = {(const void *)k_lds2_light[0], (const void *)k_lds2_light[1],
                              (const void *)k_lds4, (const void *)k_lds4_light, (const void *)k_l2, (const void *)k_l2d[0], (const void *)k_l2d[1],
-                             (const void *)r_lds, (const void *)r_l2, (const void *)r_l2d};
+                             (const void *)r_lds, (const void *)r_l2, (const void *)r_l2d,
+                             (const void *)x_k4d1, (const void *)x_k5d1, (const void *)x_k6d1, (const void *)x_k6d1o1};
         for (const void *f : all) {
             hipError_t r = allow_lds(f, DEC_LDS_MAX);
             if (r != hipSuccess) return r;
@@ -1656,12 +1704,16 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
     // 4 GiB), as they do for low-ratio data (41 %-ratio text 8 % slower with the wide streams).
     const bool short_codes = p.nsec == 0 && p.P == 8;
     const bool wide = p.sec_lds && short_codes && p.n > 0 && p.nbits * 10 > p.n * 8 * 6;      // ratio > 0.6
-    const uint64_t per_block = uint64_t(DEC_THREADS) * (wide ? 2 : 4);
+    static const int variant = getenv("MH_DEC_VARIANT") ? atoi(getenv("MH_DEC_VARIANT")) : 0;
+    const bool xvar = variant > 0 && !p.sec_lds && p.direct && p.H != 8;
+    const int xk = variant == 1 ? 4 : variant == 2 ? 5 : 6;
+    const uint64_t per_block = uint64_t(DEC_THREADS) * (xvar ? xk : wide ? 2 : 4);
     uint64_t want = (p.nchunks + per_block - 1) / per_block;
     int grid = int(want > uint64_t(cu_count()) ? uint64_t(cu_count()) : want);
     const int p8 = p.P == 8;
     if (wide) hipLaunchKernelGGL(k_lds4, dim3(grid), dim3(DEC_THREADS), lds, st, p);
     else if (p.sec_lds) hipLaunchKernelGGL(short_codes ? k_lds4_light : k_lds2_light[p8], dim3(grid), dim3(DEC_THREADS), lds, st, p);
+    else if (xvar) hipLaunchKernelGGL(variant == 1 ? x_k4d1 : variant == 2 ? x_k5d1 : variant == 3 ? x_k6d1 : x_k6d1o1, dim3(grid), dim3(DEC_THREADS), lds, st, p);
     else if (p.direct) hipLaunchKernelGGL(k_l2d[p.H == 8], dim3(grid), dim3(DEC_THREADS), lds, st, p);
     else hipLaunchKernelGGL(k_l2, dim3(grid), dim3(DEC_THREADS), lds, st, p);
     e = hipGetLastError();

@@ -1,9 +1,10 @@
 // mh_tree.hip — per-context Huffman tree build and table packing on the device.
 //
 //   tree_build_kernel   one wave per context: exact emulation of the reference's heap
-//                       (src/min_pq.tpp:4-52) and merge rule (src/huffman.cpp:131-164) by lane 0 in
-//                       LDS; then all lanes derive depths, codewords (src/huffman.cpp:97-123) and the
-//                       encode tables, and size the decode tables for every primary width.
+//                       (src/min_pq.tpp:4-52) and merge rule (src/huffman.cpp:131-164), the heap held in
+//                       the wave's registers and driven by scalar code (RegHeap); then all lanes derive
+//                       depths, codewords (src/huffman.cpp:97-123) and the encode tables, and size the
+//                       decode tables for every primary width.
 //   tree_pack_kernel    one workgroup per context: fills the two decode-table levels and the walk tree
 //                       for the layout the host picked from those sizes (same rule as Model::pack()).
 //
@@ -26,18 +27,208 @@ using mh::TREE_STRIDE;
 constexpr uint16_t NONE = 0xFFFF;
 
 // ------------------------------------------------------------------------------------------------
+// The reference's binary heap (src/min_pq.tpp:4-52), emulated comparison for comparison, kept in the
+// wave's REGISTERS: heap level L (positions 0 .. 2^L - 1) lives in one VGPR, position = lane (level 7 takes
+// two, level 8 is the single index 255), so an entry is reached with v_readlane / v_writelane at a
+// wave-uniform position and every level of a sift is a handful of scalar instructions — no LDS round trip
+// and no divergent lane (the first version ran the heap in LDS on lane 0: ~0.8 ms for 256 contexts, bound
+// by the LDS latency of ~4000 dependent accesses per context).  Each entry carries its key (the weight;
+// 32 bits when the context's total fits, else 64), and `item` = node id | subtree height << 16, so the
+// merge loop (src/huffman.cpp:143-151) needs nothing back from memory.
+// All values handled here are wave-uniform; sifts are unrolled over the levels by template recursion.
+template <bool K64>
+struct RegHeap {
+    uint32_t klo[10], khi[10], itm[10];   // slot: levels 0..6 -> 0..6, level 7 -> 7 (positions 0..63) and 8 (64..127), level 8 -> 9
+    uint32_t hn = 0;
+
+    static __device__ __forceinline__ uint32_t uni(uint32_t v) { return uint32_t(__builtin_amdgcn_readfirstlane(int(v))); }
+    static __device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t lane) { return uint32_t(__builtin_amdgcn_readlane(int(v), int(lane))); }
+    static __device__ __forceinline__ uint32_t wl(uint32_t val, uint32_t lane, uint32_t old) {
+        // (this clang has no __builtin_amdgcn_writelane; both scalar operands are wave-uniform by construction)
+        // the lane select goes through M0: two different SGPR operands would exceed gfx9's constant-bus limit.
+        // (M0 is a reserved register — the compiler sets it itself before every use of its own — and clang
+        // warns about naming it as a clobber; it is named anyway so that no operand is ever placed in it.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+        // (readfirstlane: an "s" operand the compiler holds in a VGPR would be passed as that VGPR)
+        asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(uni(val)), "s"(uni(lane)) : "m0");
+#pragma clang diagnostic pop
+        return old;
+    }
+    // strict a < b on (hi, lo) pairs
+    static __device__ __forceinline__ bool lt(uint32_t alo, uint32_t ahi, uint32_t blo, uint32_t bhi) {
+        if (K64) return ahi < bhi || (ahi == bhi && alo < blo);
+        return alo < blo;
+    }
+    template <int L>
+    __device__ __forceinline__ void get(uint32_t pos, uint32_t &lo, uint32_t &hi, uint32_t &it) const {
+        if constexpr (L < 7) {
+            lo = rl(klo[L], pos); hi = K64 ? rl(khi[L], pos) : 0u; it = rl(itm[L], pos);
+        } else if constexpr (L == 7) {
+            const uint32_t ln = pos & 63u;
+            const bool up = pos >= 64u;
+            lo = up ? rl(klo[8], ln) : rl(klo[7], ln);
+            hi = K64 ? (up ? rl(khi[8], ln) : rl(khi[7], ln)) : 0u;
+            it = up ? rl(itm[8], ln) : rl(itm[7], ln);
+        } else {
+            lo = rl(klo[9], 0); hi = K64 ? rl(khi[9], 0) : 0u; it = rl(itm[9], 0);
+        }
+    }
+    template <int L>
+    __device__ __forceinline__ void put(uint32_t pos, uint32_t lo, uint32_t hi, uint32_t it) {
+        if constexpr (L < 7) {
+            klo[L] = wl(lo, pos, klo[L]); if (K64) khi[L] = wl(hi, pos, khi[L]); itm[L] = wl(it, pos, itm[L]);
+        } else if constexpr (L == 7) {
+            const uint32_t ln = pos & 63u;
+            if (pos >= 64u) { klo[8] = wl(lo, ln, klo[8]); if (K64) khi[8] = wl(hi, ln, khi[8]); itm[8] = wl(it, ln, itm[8]); }
+            else { klo[7] = wl(lo, ln, klo[7]); if (K64) khi[7] = wl(hi, ln, khi[7]); itm[7] = wl(it, ln, itm[7]); }
+        } else {
+            klo[9] = wl(lo, 0, klo[9]); if (K64) khi[9] = wl(hi, 0, khi[9]); itm[9] = wl(it, 0, itm[9]);
+        }
+    }
+    // src/min_pq.tpp:29-36: the new entry moves up while its parent's key is STRICTLY greater
+    template <int L>
+    __device__ __forceinline__ void swim(uint32_t pos, uint32_t lo, uint32_t hi, uint32_t it) {
+        if constexpr (L == 0) {
+            put<0>(0, lo, hi, it);
+        } else {
+            uint32_t plo, phi, pit;
+            get<L - 1>(pos >> 1, plo, phi, pit);
+            if (!lt(lo, hi, plo, phi)) { put<L>(pos, lo, hi, it); return; }
+            put<L>(pos, plo, phi, pit);
+            swim<L - 1>(pos >> 1, lo, hi, it);
+        }
+    }
+    __device__ __forceinline__ void push(uint32_t lo, uint32_t hi, uint32_t it) {     // src/min_pq.tpp:4-7
+        const uint32_t i = hn++;
+        const uint32_t level = 31u - uint32_t(__builtin_clz(i + 1u));
+        const uint32_t pos = i + 1u - (1u << level);
+        switch (level) {
+            case 0: swim<0>(pos, lo, hi, it); break;
+            case 1: swim<1>(pos, lo, hi, it); break;
+            case 2: swim<2>(pos, lo, hi, it); break;
+            case 3: swim<3>(pos, lo, hi, it); break;
+            case 4: swim<4>(pos, lo, hi, it); break;
+            case 5: swim<5>(pos, lo, hi, it); break;
+            case 6: swim<6>(pos, lo, hi, it); break;
+            case 7: swim<7>(pos, lo, hi, it); break;
+            default: swim<8>(pos, lo, hi, it); break;
+        }
+    }
+    // src/min_pq.tpp:38-52: the hole at (L, pos) takes the smaller child — the right one only when STRICTLY
+    // smaller than the left — while that child is STRICTLY smaller than the sinking key
+    template <int L>
+    __device__ __forceinline__ void sink(uint32_t pos, uint32_t lo, uint32_t hi, uint32_t it) {
+        if constexpr (L == 8) {
+            put<8>(pos, lo, hi, it);
+        } else {
+            const uint32_t li = ((2u << L) - 1u) + 2u * pos;             // heap index of the left child
+            if (li >= hn) { put<L>(pos, lo, hi, it); return; }
+            uint32_t clo, chi, cit;
+            get<L + 1>(2u * pos, clo, chi, cit);
+            uint32_t right = 0;
+            if (li + 1u < hn) {
+                uint32_t rlo, rhi, rit;
+                get<L + 1>(2u * pos + 1u, rlo, rhi, rit);
+                if (lt(rlo, rhi, clo, chi)) { clo = rlo; chi = rhi; cit = rit; right = 1; }
+            }
+            if (!lt(clo, chi, lo, hi)) { put<L>(pos, lo, hi, it); return; }
+            put<L>(pos, clo, chi, cit);
+            sink<L + 1>(2u * pos + right, lo, hi, it);
+        }
+    }
+    // src/min_pq.tpp:9-15: returns the minimum's item and key; the last entry sinks from the root
+    __device__ __forceinline__ uint32_t pop(uint32_t &mlo, uint32_t &mhi) {
+        uint32_t top;
+        get<0>(0, mlo, mhi, top);
+        --hn;
+        const uint32_t level = 31u - uint32_t(__builtin_clz(hn + 1u));
+        const uint32_t pos = hn + 1u - (1u << level);
+        uint32_t lo, hi, it;
+        switch (level) {
+            case 0: get<0>(pos, lo, hi, it); break;
+            case 1: get<1>(pos, lo, hi, it); break;
+            case 2: get<2>(pos, lo, hi, it); break;
+            case 3: get<3>(pos, lo, hi, it); break;
+            case 4: get<4>(pos, lo, hi, it); break;
+            case 5: get<5>(pos, lo, hi, it); break;
+            case 6: get<6>(pos, lo, hi, it); break;
+            case 7: get<7>(pos, lo, hi, it); break;
+            default: get<8>(pos, lo, hi, it); break;
+        }
+        sink<0>(0, lo, hi, it);
+        return top;
+    }
+};
+
+struct TreeLds {
+    uint16_t *left, *right, *parent, *height;
+    uint8_t *sym;
+    unsigned long long *weight;
+};
+
+// src/huffman.cpp:131-164 for one context: nleaf leaves are already laid out (ascending symbol order) in
+// the node arrays.  Returns nn and the root through the two references; all lanes run the same scalar code
+// and lane 0 writes the node arrays.
+template <bool K64>
+__device__ __forceinline__ void merge_context(const TreeLds &t, uint32_t nleaf, uint32_t lane, uint32_t &nn_out, uint32_t &root_out,
+                                              uint32_t &single_out) {
+    RegHeap<K64> h;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { h.klo[i] = 0; h.khi[i] = 0; h.itm[i] = 0; }
+    for (uint32_t i = 0; i < nleaf; ++i) {                            // :134-138 ascending symbol order
+        const unsigned long long w = t.weight[i];
+        h.push(RegHeap<K64>::uni(uint32_t(w)), RegHeap<K64>::uni(uint32_t(w >> 32)), i);   // height 0
+    }
+    uint32_t nn = nleaf;
+    while (h.hn > 1) {                                                 // :143-151
+        uint32_t alo, ahi, blo, bhi;
+        uint32_t a = h.pop(alo, ahi), b = h.pop(blo, bhi);
+        if ((a >> 16) > (b >> 16)) {                                   // :147-149 the lower subtree goes left
+            uint32_t x = a; a = b; b = x;
+        }
+        const unsigned long long w = ((unsigned long long)(ahi) << 32 | alo) + ((unsigned long long)(bhi) << 32 | blo);
+        const uint32_t ha = a >> 16, hb = b >> 16, hnew = (ha > hb ? ha : hb) + 1u;
+        const uint32_t ia = a & 0xFFFFu, ib = b & 0xFFFFu;
+        if (lane == 0) {
+            t.left[nn] = uint16_t(ia); t.right[nn] = uint16_t(ib); t.parent[nn] = NONE; t.sym[nn] = 0;
+            t.weight[nn] = w; t.height[nn] = uint16_t(hnew);
+            t.parent[ia] = t.parent[ib] = uint16_t(nn);
+        }
+        h.push(uint32_t(w), uint32_t(w >> 32), nn | (hnew << 16));
+        ++nn;
+    }
+    uint32_t rlo, rhi;
+    const uint32_t root = h.pop(rlo, rhi) & 0xFFFFu;                   // :152
+    single_out = 0;
+    if (nleaf == 1) {                                                  // :154-162 one-symbol context
+        if (lane == 0) {
+            const uint8_t s = t.sym[root];
+            for (int k = 0; k < 2; ++k) {
+                t.left[nn + k] = t.right[nn + k] = NONE; t.parent[nn + k] = uint16_t(root); t.height[nn + k] = 0; t.sym[nn + k] = s;
+                t.weight[nn + k] = t.weight[root];
+            }
+            t.left[root] = uint16_t(nn); t.right[root] = uint16_t(nn + 1);
+            t.height[root] = 1;
+        }
+        nn += 2;
+        single_out = 1;
+    }
+    nn_out = nn;
+    root_out = root;
+}
+
+// ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void tree_build_kernel(const unsigned long long *__restrict__ counts, TreeBuildOut o) {
     const uint32_t c = blockIdx.x, lane = threadIdx.x;
     __shared__ unsigned long long cnt[256];
-    __shared__ unsigned long long hkey[260];
-    __shared__ uint16_t hitem[260];
     __shared__ uint16_t left[TB_NODE_STRIDE], right[TB_NODE_STRIDE], parent[TB_NODE_STRIDE], height[TB_NODE_STRIDE];
     __shared__ uint8_t sym[TB_NODE_STRIDE];
     __shared__ unsigned long long weight[TB_NODE_STRIDE];
     __shared__ uint8_t olen[256];
     __shared__ unsigned long long ocode[256];
     __shared__ uint32_t prof[9];
-    __shared__ uint32_t s_nn, s_root, s_single, s_ntab8, s_maxlen, s_tie;
+    __shared__ uint32_t s_nn, s_root, s_single, s_ntab8, s_maxlen;
 
     unsigned long long wsum = 0;
     for (uint32_t i = lane; i < 256; i += 64) {
@@ -48,7 +239,7 @@ __global__ __launch_bounds__(64) void tree_build_kernel(const unsigned long long
     }
     for (int d = 32; d >= 1; d >>= 1) wsum += __shfl_xor(wsum, d);
     if (lane < 9) prof[lane] = 0;
-    if (lane == 0) { s_ntab8 = 0; s_maxlen = 0; s_single = 0; s_tie = 0; }
+    if (lane == 0) { s_ntab8 = 0; s_maxlen = 0; s_single = 0; }
     __syncthreads();
 
     // ---- leaves, in ascending symbol order (src/huffman.cpp:134-138): node id = rank among the non-zero counts
@@ -63,136 +254,17 @@ __global__ __launch_bounds__(64) void tree_build_kernel(const unsigned long long
         }
         nleaf += __popcll(m);
     }
-    // ---- fast path: with pairwise distinct keys at every extraction the heap's pop order IS the sorted
-    // order, whatever its internal mechanics (src/min_pq.tpp), so the merge sequence follows from the
-    // sorted leaves and the queue of merged nodes (whose weights are created in non-decreasing order).
-    // Any equal pair among the three smallest keys of a step makes the reference's choice depend on
-    // the heap layout: such a context is rebuilt by the exact heap emulation below.
-    for (uint32_t i = lane; i < 256; i += 64) {
-        hkey[i] = i < nleaf ? weight[i] : ~0ull;                  // hkey / hitem double as the sort buffer
-        hitem[i] = uint16_t(i);
-    }
     __syncthreads();
-    for (uint32_t k = 2; k <= 256; k <<= 1) {                      // bitonic sort of 256 (key, id) pairs, ascending
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = lane; t < 128; t += 64) {
-                const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
-                const bool up = (lo & k) == 0;
-                const unsigned long long a = hkey[lo], b = hkey[hi];
-                const uint16_t ia = hitem[lo], ib = hitem[hi];
-                const bool gt = a > b || (a == b && ia > ib);
-                if (gt == up) { hkey[lo] = b; hkey[hi] = a; hitem[lo] = ib; hitem[hi] = ia; }
-            }
-            __syncthreads();
+    {
+        const TreeLds t{left, right, parent, height, sym, weight};
+        uint32_t nn = 0, root = 0xFFFFFFFFu, single = 0;
+        if (nleaf > 0) {
+            // 32-bit keys when every weight that can appear (the root's is the context total) fits
+            const bool wide = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(wsum >> 32)))) != 0;
+            if (wide) merge_context<true>(t, nleaf, lane, nn, root, single);
+            else merge_context<false>(t, nleaf, lane, nn, root, single);
         }
-    }
-    if (lane == 0 && nleaf > 1) {
-        uint32_t i1 = 0, i2 = nleaf, nn = nleaf;                   // heads of the leaf queue and of the merged-node queue
-        bool tie = false;
-        auto key1 = [&](uint32_t i) -> unsigned long long { return i < nleaf ? hkey[i] : ~0ull; };
-        auto key2 = [&](uint32_t i) -> unsigned long long { return i < nn ? weight[i] : ~0ull; };
-        for (uint32_t step = 0; step + 1 < nleaf; ++step) {
-            uint32_t pick[2];
-            unsigned long long pk[2];
-            for (int q = 0; q < 2; ++q) {
-                const unsigned long long k1 = key1(i1), k2 = key2(i2);
-                tie |= k1 == k2;                                   // both queues non-empty here or one key is ~0 (counts never reach it)
-                if (k1 < k2) { pick[q] = hitem[i1]; pk[q] = k1; ++i1; } else { pick[q] = i2; pk[q] = k2; ++i2; }
-            }
-            const unsigned long long k3a = key1(i1), k3b = key2(i2);
-            const unsigned long long k3 = k3a < k3b ? k3a : k3b;
-            tie |= pk[0] == pk[1] || pk[1] == k3;
-            uint32_t a = pick[0], b = pick[1];
-            if (height[a] > height[b]) { const uint32_t t = a; a = b; b = t; }     // src/huffman.cpp:147-149
-            left[nn] = uint16_t(a); right[nn] = uint16_t(b); parent[nn] = NONE; sym[nn] = 0;
-            weight[nn] = weight[a] + weight[b];
-            height[nn] = uint16_t((height[a] > height[b] ? height[a] : height[b]) + 1);
-            parent[a] = parent[b] = uint16_t(nn);
-            ++nn;
-        }
-        s_tie = tie ? 1u : 0u;
-        s_nn = nn;
-        s_root = nn - 1;
-    }
-    __syncthreads();
-
-    if (lane == 0 && (nleaf <= 1 || s_tie)) {
-        // ---- exact heap emulation (same comparisons in the same order as swap-based swim/sink)
-        int nn = int(nleaf), hn = 0;
-        for (int i = 0; i < nn; ++i) parent[i] = NONE;             // the fast path may have linked the leaves
-        auto push = [&](unsigned long long key, uint16_t item) {
-            int i = hn++;
-            while (i != 0) {
-                int par = (i - 1) / 2;
-                if (!(hkey[par] > key)) break;                   // strict >: equal keys do not move
-                hkey[i] = hkey[par]; hitem[i] = hitem[par];
-                i = par;
-            }
-            hkey[i] = key; hitem[i] = item;
-        };
-        // Sift-down with the same comparisons in the same order, two levels per LDS round trip: the keys
-        // of both children AND of all four grandchildren are fetched together (the walk is one lane waiting
-        // on LDS latency at every level; entries below the current node are not modified while sinking).
-        auto pop = [&]() -> uint16_t {
-            const uint16_t top = hitem[0];
-            --hn;
-            const unsigned long long key = hkey[hn];
-            const uint16_t item = hitem[hn];
-            int i = 0;
-            for (;;) {
-                const int l = 2 * i + 1, r = l + 1;
-                if (l >= hn) break;
-                // children and grandchildren (indices clamped for the load, validity decided by < hn)
-                auto at = [&](int idx) -> unsigned long long { return hkey[idx < 259 ? idx : 259]; };
-                const unsigned long long kl = at(l), kr = at(r);
-                const unsigned long long kll = at(2 * l + 1), klr = at(2 * l + 2), krl = at(2 * r + 1), krr = at(2 * r + 2);
-                const uint16_t il = hitem[l], ir = hitem[r < 259 ? r : 259];
-                const bool right1 = r < hn && kr < kl;               // right only if strictly smaller
-                const int pick = right1 ? r : l;
-                const unsigned long long k1 = right1 ? kr : kl;
-                if (!(k1 < key)) break;
-                hkey[i] = k1; hitem[i] = right1 ? ir : il;
-                i = pick;
-                const int l2 = 2 * i + 1, r2 = l2 + 1;
-                if (l2 >= hn) break;
-                const unsigned long long kl2 = right1 ? krl : kll, kr2 = right1 ? krr : klr;
-                const bool right2 = r2 < hn && kr2 < kl2;
-                const int pick2 = right2 ? r2 : l2;
-                const unsigned long long k2 = right2 ? kr2 : kl2;
-                if (!(k2 < key)) break;
-                hkey[i] = k2; hitem[i] = hitem[pick2];
-                i = pick2;
-            }
-            hkey[i] = key; hitem[i] = item;
-            return top;
-        };
-        for (int i = 0; i < nn; ++i) push(weight[i], uint16_t(i));   // src/huffman.cpp:134-138 (ascending symbol order)
-        int root = -1;
-        if (hn > 0) {
-            while (hn > 1) {                                      // :143-151
-                uint16_t a = pop(), b = pop();
-                if (height[a] > height[b]) { uint16_t t = a; a = b; b = t; }   // :147-149
-                left[nn] = a; right[nn] = b; parent[nn] = NONE; sym[nn] = 0;
-                weight[nn] = weight[a] + weight[b];
-                height[nn] = uint16_t((height[a] > height[b] ? height[a] : height[b]) + 1);
-                parent[a] = parent[b] = uint16_t(nn);
-                push(weight[nn], uint16_t(nn));
-                ++nn;
-            }
-            root = pop();
-            if (left[root] == NONE) {                             // :154-162 one-symbol context
-                const uint8_t s = sym[root];
-                for (int k = 0; k < 2; ++k) {
-                    left[nn] = right[nn] = NONE; parent[nn] = uint16_t(root); height[nn] = 0; sym[nn] = s; weight[nn] = weight[root];
-                    if (k == 0) left[root] = uint16_t(nn); else right[root] = uint16_t(nn);
-                    ++nn;
-                }
-                height[root] = 1;
-                s_single = 1;
-            }
-        }
-        s_nn = uint32_t(nn);
-        s_root = root < 0 ? 0xFFFFFFFFu : uint32_t(root);
+        if (lane == 0) { s_nn = nn; s_root = root; s_single = single; }
     }
     __syncthreads();
 

@@ -91,12 +91,16 @@ def test_order2_tables_stream_and_round_trip_parity_unpinned(mhc, oracle, name):
     assert blob[0] & 0xF8 == 0x40                                 # the extension's own magic nibble
     assert m.decompress(blob, index=idx, chunk_symbols=256, n_symbols=len(data)) == data
     assert o.decompress(blob) == data
-    # a model loaded from the table file: same device images as the device-built one, same stream
+    # a model loaded from the table file (tables derived on the host) against the device-built one: same
+    # codewords, same first-level decode table and layout, same stream, and it decodes.  (The walk tree and
+    # the node ids in second-level inner entries number the nodes in file order there, creation order here.)
     t = mhc.Model.from_table(table)
     assert t.type == 2 and t.table_bytes() == table
-    for which in (1, 3, 4, 5, 6, 7):
+    for which in (1, 3, 4, 6):
         assert t.image(which) == m.image(which), "image %d differs" % which
+    assert len(t.image(5)) == len(m.image(5))
     assert t.compress(data)[0] == blob
+    assert t.decompress(blob, index=idx, chunk_symbols=256, n_symbols=len(data)) == data
 
 
 @pytest.mark.parametrize("name", ["ipsum", "kat1", "one_Z", "zipf32_512k"])

@@ -131,16 +131,18 @@ def test_device_tree_build_equals_host_build(mhc, oracle, kind):
         assert dev.decompress(blob, index=idx, chunk_symbols=256, n_symbols=len(data)) == data
 
 
-@pytest.mark.parametrize("shape", ["distinct", "one_tie_late", "workspace"])
-def test_device_tree_build_sorted_path_and_heap_fallback(mhc, oracle, shape):
-    """tree_build_kernel takes the sorted two-queue path when no two of the three smallest keys of a merge
-    step are equal, and re-runs the context with the exact heap emulation otherwise.  Large pairwise
-    distinct counts (a 16 GiB histogram's shape) exercise the first, a single late tie between a leaf and a
-    merged node the hand-over; `workspace` builds through mh_dev_model_from_counts_ws."""
+@pytest.mark.parametrize("shape", ["distinct", "one_tie_late", "workspace", "wide_keys"])
+def test_device_tree_build_register_heap(mhc, oracle, shape):
+    """tree_build_kernel keeps the reference's heap in the wave's registers (RegHeap, mh_tree.hip) with 32-bit
+    keys when a context's total count fits and 64-bit keys otherwise.  Large pairwise distinct counts (a
+    16 GiB histogram's shape), a tie between a leaf and a merged node in every third context, counts
+    above 2^32 (`wide_keys`), and the caller-workspace entry point (`workspace`)."""
     rng = np.random.default_rng(7)
     w = 1.0 / np.arange(1, 257) ** 1.1
     p = np.outer(w, w).ravel()
     counts = rng.permutation(65536).astype(np.uint64) + np.floor(p / p.sum() * 2 ** 34).astype(np.uint64) * np.uint64(65536)
+    if shape == "wide_keys":
+        counts = counts * np.uint64(1 << 12) + np.uint64(5)
     if shape == "one_tie_late":
         for c in range(0, 256, 3):       # make one symbol weigh exactly what the two lightest weigh together
             row = counts[c * 256:(c + 1) * 256]
