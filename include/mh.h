@@ -174,6 +174,13 @@ int mh_histogram_o1(const uint8_t *data, size_t n, uint8_t prev0, uint64_t *coun
 /* Replaces construct_table + the order-0 lambda (src/main.cpp:164-171).  counts: 256 entries. */
 int mh_histogram_o0(const uint8_t *data, size_t n, uint64_t *counts);
 
+/* Option for two-pass callers (histogram, then encode, of the SAME host buffer — what the CLI does,
+ * src/main.cpp:173-183 + 204-212): when on, mh_histogram_o0/o1/o2 leave their upload of the input in HBM
+ * (if it fits beside everything else) and the next mh_encode of that buffer — same pointer, size and
+ * sampled content — reads it there, so the data crosses PCIe once.  The caller promises not to modify the
+ * buffer between the two calls.  Off by default; turning it off frees what is held. */
+int mh_set_input_residency(int on);
+
 /* Replaces the body of i_coding_provider::compress (src/coding.cpp:61-94) between the header
  * placeholder and the header rewrite: payload bits only.  *nbits = payload length in bits; payload
  * bytes written = ceil(*nbits / 8), zero padded (src/bitbuffer.cpp:175).  cap must be >=

@@ -33,7 +33,7 @@ EXPORTS = [
     "mh_model_from_table_bits", "mh_model_write_table",
     "mh_model_type", "mh_model_max_code_len", "mh_model_get_code", "mh_model_get_lut", "mh_model_decode_layout",
     "mh_model_image", "mh_model_free",
-    "mh_histogram_o1", "mh_histogram_o0", "mh_histogram_o2", "mh_dev_histogram_o2", "mh_encode", "mh_encode_bound", "mh_stream_header",
+    "mh_set_input_residency", "mh_histogram_o1", "mh_histogram_o0", "mh_histogram_o2", "mh_dev_histogram_o2", "mh_encode", "mh_encode_bound", "mh_stream_header",
     "mh_stream_parse_header", "mh_decode",
     "mh_dev_histogram_workspace", "mh_dev_histogram_o1", "mh_dev_histogram_o0",
     "mh_decode_to", "mh_model_payload_bits", "mh_dev_encode_workspace", "mh_dev_encode", "mh_dev_payload_bits", "mh_dev_encode_at", "mh_dev_decode_workspace", "mh_dev_decode", "mh_dev_decode_dn",

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "mh_kernels.h"
@@ -96,6 +97,110 @@ struct DevBuf {
     hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
     template <typename T> T *as() { return static_cast<T *>(p); }
 };
+
+// ---- pinned staging for the host-buffer calls ---------------------------------------
+// The callers' buffers are pageable (the CLI hands over mmapped files): a plain hipMemcpy from such memory
+// is a single-threaded bounce through the runtime's own staging buffers.  Here a ring of pinned pieces is
+// filled by several host threads (the page-cache copy is what bounds a transfer, not the bus) while the DMA
+// of the previous piece runs, and the same in the other direction.  One ring per process, guarded by a mutex
+// (the host-buffer calls of one process take turns on the bus anyway).
+class PinnedRing {
+public:
+    static constexpr size_t PIECE = size_t(16) << 20;
+    static constexpr int SLOTS = 4;
+    // pageable host -> device, stream-ordered on `st` for the device side; returns when the last piece has been queued
+    hipError_t upload(void *d_dst, const void *h_src, size_t n, hipStream_t st) {
+        std::lock_guard<std::mutex> lock(mu_);
+        hipError_t e = ensure();
+        if (e != hipSuccess) return e;
+        const unsigned char *src = static_cast<const unsigned char *>(h_src);
+        unsigned char *dst = static_cast<unsigned char *>(d_dst);
+        for (size_t off = 0; off < n; off += PIECE, ++seq_) {
+            const size_t len = std::min(PIECE, n - off);
+            const int s = int(seq_ % SLOTS);
+            if ((e = hipEventSynchronize(ev_[s])) != hipSuccess) return e;      // the slot's previous transfer has left it
+            parallel_copy(buf_[s], src + off, len);
+            if ((e = hipMemcpyAsync(dst + off, buf_[s], len, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+            if ((e = hipEventRecord(ev_[s], st)) != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
+    // device -> pageable host; everything queued on `st` before the call is waited for; returns when h_dst is complete
+    hipError_t download(void *h_dst, const void *d_src, size_t n, hipStream_t st) {
+        std::lock_guard<std::mutex> lock(mu_);
+        hipError_t e = ensure();
+        if (e != hipSuccess) return e;
+        unsigned char *dst = static_cast<unsigned char *>(h_dst);
+        const unsigned char *src = static_cast<const unsigned char *>(d_src);
+        const size_t pieces = (n + PIECE - 1) / PIECE;
+        // piece i is copied out of its slot while pieces i+1 .. i+SLOTS-1 are on the bus
+        for (size_t i = 0; i < pieces + SLOTS - 1; ++i) {
+            if (i < pieces) {
+                const size_t off = i * PIECE, len = std::min(PIECE, n - off);
+                const int s = int((seq_ + i) % SLOTS);
+                if (i < size_t(SLOTS) && (e = hipEventSynchronize(ev_[s])) != hipSuccess) return e;
+                if ((e = hipMemcpyAsync(buf_[s], src + off, len, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+                if ((e = hipEventRecord(ev_[s], st)) != hipSuccess) return e;
+            }
+            if (i + 1 >= size_t(SLOTS)) {
+                const size_t j = i + 1 - SLOTS;                                 // oldest piece in flight
+                const size_t off = j * PIECE, len = std::min(PIECE, n - off);
+                const int s = int((seq_ + j) % SLOTS);
+                if ((e = hipEventSynchronize(ev_[s])) != hipSuccess) return e;
+                parallel_copy(dst + off, buf_[s], len);
+            }
+        }
+        seq_ += pieces;
+        return hipSuccess;
+    }
+
+private:
+    hipError_t ensure() {
+        if (ready_) return hipSuccess;
+        for (int i = 0; i < SLOTS; ++i) {
+            hipError_t e = hipHostMalloc(&buf_[i], PIECE, hipHostMallocDefault);
+            if (e != hipSuccess) return e;
+            if ((e = hipEventCreateWithFlags(&ev_[i], hipEventDisableTiming)) != hipSuccess) return e;
+        }
+        unsigned hw = std::thread::hardware_concurrency();
+        threads_ = hw >= 16 ? 6 : hw >= 8 ? 4 : hw >= 4 ? 2 : 1;
+        if (const char *t = getenv("MH_COPY_THREADS")) { const int v = atoi(t); if (v >= 1 && v <= 32) threads_ = v; }
+        ready_ = true;
+        return hipSuccess;
+    }
+    void parallel_copy(void *dst, const void *src, size_t n) const {
+        if (threads_ <= 1 || n < (size_t(1) << 20)) { std::memcpy(dst, src, n); return; }
+        const size_t part = ((n / size_t(threads_)) + 4095) & ~size_t(4095);
+        std::vector<std::thread> pool;
+        for (int t = 1; t < threads_; ++t) {
+            const size_t off = part * size_t(t);
+            if (off >= n) break;
+            pool.emplace_back([=] { std::memcpy(static_cast<unsigned char *>(dst) + off, static_cast<const unsigned char *>(src) + off, std::min(part, n - off)); });
+        }
+        std::memcpy(dst, src, std::min(part, n));
+        for (std::thread &t : pool) t.join();
+    }
+    std::mutex mu_;
+    bool ready_ = false;
+    void *buf_[SLOTS] = {};
+    hipEvent_t ev_[SLOTS] = {};
+    size_t seq_ = 0;
+    int threads_ = 1;
+};
+PinnedRing g_ring;
+
+// small transfers keep the plain call (the ring pays from a few MiB on)
+hipError_t stage_h2d(void *d_dst, const void *h_src, size_t n, hipStream_t st) {
+    if (n < (size_t(4) << 20)) return hipMemcpyAsync(d_dst, h_src, n, hipMemcpyHostToDevice, st);   // pageable: returns after staging
+    return g_ring.upload(d_dst, h_src, n, st);
+}
+hipError_t stage_d2h(void *h_dst, const void *d_src, size_t n, hipStream_t st) {
+    if (n < (size_t(4) << 20)) {
+        hipError_t e = hipMemcpyAsync(h_dst, d_src, n, hipMemcpyDeviceToHost, st);
+        return e != hipSuccess ? e : hipStreamSynchronize(st);
+    }
+    return g_ring.download(h_dst, d_src, n, st);
+}
 
 // Host tables are always built; the device images are uploaded when a device exists.  Without one the
 // model still answers table queries (mh_model_write_table, mh_model_get_code, ...) but every
@@ -833,13 +938,62 @@ static size_t segment_bytes() {
     return s < MH_CHUNK_MAX ? size_t(MH_CHUNK_MAX) : s;
 }
 
+// ---- input residency (mh_set_input_residency): the histogram pass leaves its upload in HBM and the next
+// mh_encode of the same host buffer reads it there, so a compress moves the file over PCIe once.
+namespace {
+struct ResidentInput {
+    std::mutex mu;
+    bool enabled = false;
+    const void *host = nullptr;
+    size_t n = 0;
+    uint64_t sig = 0;
+    void *dev = nullptr;
+    int device = -1;
+    void drop() { if (dev) (void)hipFree(dev); dev = nullptr; host = nullptr; n = 0; }
+} g_resident;
+
+// size + three sampled 4 KiB blocks: guards against a DIFFERENT buffer at a recycled address, not against a
+// caller who edits the buffer in between (the option's contract forbids that)
+uint64_t sample_signature(const uint8_t *p, size_t n) {
+    uint64_t h = 1469598103934665603ull ^ n;
+    auto mix = [&](size_t off) {
+        const size_t len = std::min<size_t>(4096, n - off);
+        for (size_t i = 0; i < len; ++i) { h ^= p[off + i]; h *= 1099511628211ull; }
+    };
+    if (n) { mix(0); mix(n / 2); mix(n - std::min<size_t>(n, 4096)); }
+    return h;
+}
+}  // namespace
+
+int mh_set_input_residency(int on) {
+    std::lock_guard<std::mutex> lock(g_resident.mu);
+    g_resident.enabled = on != 0;
+    if (!on) g_resident.drop();
+    return MH_OK;
+}
+
 static int histogram_host(const uint8_t *data, size_t n, uint8_t prev0, uint64_t *counts, int order) {
     if ((!data && n) || !counts) return MH_ERR_ARG;
     if (!have_device()) return MH_ERR_NO_DEVICE;
     const size_t nc = order == 2 ? (size_t(1) << 24) : order ? 65536 : 256;
     const size_t seg = segment_bytes();
     DevBuf d_data, d_counts, d_hws;
-    HIP_TRY(d_data.alloc(n < seg ? n : seg));
+    // with residency on, the whole input stays on the card (when it leaves half of the free memory alone)
+    uint8_t *d_all = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_resident.mu);
+        g_resident.drop();
+        size_t free_b = 0, total_b = 0;
+        if (g_resident.enabled && n >= seg && hipMemGetInfo(&free_b, &total_b) == hipSuccess && n + (size_t(1) << 30) < free_b / 2) {
+            void *p = nullptr;
+            if (hipMalloc(&p, n + 64) == hipSuccess) {
+                d_all = static_cast<uint8_t *>(p);
+                g_resident.dev = p; g_resident.host = data; g_resident.n = n; g_resident.sig = sample_signature(data, n);
+                (void)hipGetDevice(&g_resident.device);
+            }
+        }
+    }
+    if (!d_all) HIP_TRY(d_data.alloc(n < seg ? n : seg));
     HIP_TRY(d_counts.alloc(nc * 8));
     const size_t hws = order == 1 && n >= (size_t(1) << 20) ? mh_dev_histogram_workspace(n) : 0;   // pays from about a megabyte on
     if (hws) HIP_TRY(d_hws.alloc(hws));
@@ -847,12 +1001,13 @@ static int histogram_host(const uint8_t *data, size_t n, uint8_t prev0, uint64_t
     for (size_t i = 0; i < nc; ++i) counts[i] = 0;
     for (size_t off = 0; off < n || off == 0; off += seg) {
         const size_t len = n - off < seg ? n - off : seg;
-        if (len) HIP_TRY(hipMemcpy(d_data.p, data + off, len, hipMemcpyHostToDevice));
+        uint8_t *d_seg = d_all ? d_all + off : d_data.as<uint8_t>();   // segment sizes are multiples of 8 KiB: aligned
+        if (len) HIP_TRY(stage_h2d(d_seg, data + off, len, nullptr));
         const uint8_t p0 = off ? data[off - 1] : prev0;            // context carried across the seam (src/main.cpp:32,36)
         const uint16_t c0 = off ? uint16_t(data[off - 2] << 8 | data[off - 1]) : uint16_t(prev0 << 8 | prev0);   // segments are >= 8 KiB
-        int rc = order == 2 ? mh_dev_histogram_o2(d_data.as<uint8_t>(), len, c0, d_counts.as<uint64_t>(), nullptr)
-                 : order ? mh_dev_histogram_o1(d_data.as<uint8_t>(), len, p0, d_counts.as<uint64_t>(), hws ? d_hws.p : nullptr, hws, nullptr)
-                         : mh_dev_histogram_o0(d_data.as<uint8_t>(), len, d_counts.as<uint64_t>(), nullptr, 0, nullptr);
+        int rc = order == 2 ? mh_dev_histogram_o2(d_seg, len, c0, d_counts.as<uint64_t>(), nullptr)
+                 : order ? mh_dev_histogram_o1(d_seg, len, p0, d_counts.as<uint64_t>(), hws ? d_hws.p : nullptr, hws, nullptr)
+                         : mh_dev_histogram_o0(d_seg, len, d_counts.as<uint64_t>(), nullptr, 0, nullptr);
         if (rc != MH_OK) return rc;
         HIP_TRY(hipMemcpy(part.data(), d_counts.p, nc * 8, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < nc; ++i) counts[i] += part[i];
@@ -912,7 +1067,20 @@ int mh_encode(const mh_model *m, const uint8_t *data, size_t n, uint8_t prev0, u
     const size_t sidx = index ? size_t(mh_index_entries(slen, chunk_symbols)) : 0;
     const size_t wsb = mh_dev_encode_workspace(slen);
     DevBuf d_data, d_out, d_nbits, d_start, d_index, d_ws;
-    HIP_TRY(d_data.alloc(slen));
+    // the histogram pass may have left this very buffer on the card (mh_set_input_residency): consumed here
+    struct Held { void *p = nullptr; ~Held() { if (p) (void)hipFree(p); } } resident;
+    {
+        std::lock_guard<std::mutex> lock(g_resident.mu);
+        int dev = -1;
+        if (g_resident.dev && g_resident.host == data && g_resident.n == n && hipGetDevice(&dev) == hipSuccess &&
+            dev == g_resident.device && g_resident.sig == sample_signature(data, n)) {
+            resident.p = g_resident.dev;
+            g_resident.dev = nullptr;
+        }
+        g_resident.drop();
+    }
+    const uint8_t *d_all = static_cast<const uint8_t *>(resident.p);
+    if (!d_all) HIP_TRY(d_data.alloc(slen));
     HIP_TRY(d_out.alloc(dcap));
     HIP_TRY(d_nbits.alloc(8));
     HIP_TRY(d_start.alloc(8));
@@ -922,11 +1090,12 @@ int mh_encode(const mh_model *m, const uint8_t *data, size_t n, uint8_t prev0, u
     uint64_t start = 0;                                          // global bit position of the next segment
     for (size_t off = 0; off < n; off += seg) {
         const size_t len = n - off < seg ? n - off : seg;
-        HIP_TRY(hipMemcpy(d_data.p, data + off, len, hipMemcpyHostToDevice));
+        const uint8_t *d_seg = d_all ? d_all + off : d_data.as<uint8_t>();
+        if (!d_all) HIP_TRY(stage_h2d(d_data.p, data + off, len, st));
         HIP_TRY(hipMemcpy(d_start.p, &start, 8, hipMemcpyHostToDevice));
         const uint32_t c0 = m->type == 2 ? (off ? uint32_t(data[off - 2]) << 8 | data[off - 1] : ctx_of_prev0(m, prev0))
                                          : (off ? data[off - 1] : prev0);      // segments are >= 8 KiB, so off >= 2 when not 0
-        int rc = dev_encode_ctx(m, d_data.as<uint8_t>(), len, c0, d_start.as<uint64_t>(), d_out.as<uint8_t>(), dcap,
+        int rc = dev_encode_ctx(m, d_seg, len, c0, d_start.as<uint64_t>(), d_out.as<uint8_t>(), dcap,
                                 d_nbits.as<uint64_t>(), index ? d_index.as<uint64_t>() : nullptr, chunk_symbols, d_ws.p, wsb, st);
         if (rc != MH_OK) return rc;
         rc = mh_dev_status(d_ws.p, st);
@@ -946,7 +1115,7 @@ int mh_encode(const mh_model *m, const uint8_t *data, size_t n, uint8_t prev0, u
                 skip = 1;
             }
             if (nbytes > skip)
-                HIP_TRY(hipMemcpy(out_payload + obyte + skip, d_out.as<uint8_t>() + skip, nbytes - skip, hipMemcpyDeviceToHost));
+                HIP_TRY(stage_d2h(out_payload + obyte + skip, d_out.as<uint8_t>() + skip, nbytes - skip, st));
         }
         if (index) {
             const size_t ne = size_t(mh_index_entries(len, chunk_symbols));
@@ -1002,7 +1171,7 @@ int mh_decode_to(const mh_model *m, const uint8_t *payload, uint64_t nbits, uint
                 pl_cap = need + (need >> 2) + 64;
                 HIP_TRY(d_pl.alloc(pl_cap));
             }
-            if (need) HIP_TRY(hipMemcpy(d_pl.p, payload + hb0, need, hipMemcpyHostToDevice));
+            if (need) HIP_TRY(stage_h2d(d_pl.p, payload + hb0, need, st));
             for (size_t i = 0; i < ne; ++i) {
                 const uint64_t e = index[c0 + i];
                 if ((e & MASK) < pos0) return MH_ERR_CORRUPT;
@@ -1014,7 +1183,7 @@ int mh_decode_to(const mh_model *m, const uint8_t *payload, uint64_t nbits, uint
             if (rc != MH_OK) return rc;
             rc = mh_dev_status(d_dws.p, st);
             if (rc != MH_OK) return rc;
-            HIP_TRY(hipMemcpy(out + off, d_o.p, len, hipMemcpyDeviceToHost));
+            HIP_TRY(stage_d2h(out + off, d_o.p, len, st));
         }
         return MH_OK;
     }
@@ -1022,7 +1191,7 @@ int mh_decode_to(const mh_model *m, const uint8_t *payload, uint64_t nbits, uint
     // there, and the output comes back segment by segment.
     DevBuf d_payload, d_index, d_ws, d_nsym, d_out;
     HIP_TRY(d_payload.alloc(pbytes));
-    if (pbytes) HIP_TRY(hipMemcpy(d_payload.p, payload, pbytes, hipMemcpyHostToDevice));
+    if (pbytes) HIP_TRY(stage_h2d(d_payload.p, payload, pbytes, st));
     // every code is at least one bit: the stream holds at most nbits symbols
     const uint64_t idx_cap = nbits / chunk_symbols + 2;
     HIP_TRY(d_index.alloc(size_t(idx_cap) * 8));
@@ -1061,7 +1230,7 @@ int mh_decode_to(const mh_model *m, const uint8_t *payload, uint64_t nbits, uint
         if (rc != MH_OK) return rc;
         rc = mh_dev_status(d_ws.p, st);
         if (rc != MH_OK) return rc;
-        HIP_TRY(hipMemcpy(out + off, d_out.p, len, hipMemcpyDeviceToHost));
+        HIP_TRY(stage_d2h(out + off, d_out.p, len, st));
     }
     return MH_OK;
 }

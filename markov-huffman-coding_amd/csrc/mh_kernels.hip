@@ -1678,6 +1678,8 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
     auto x_k5d1 = decode_kernel<false, 2, true, 5, 8, 2, 8, 0, false, 512, 1>;
     auto x_k6d1 = decode_kernel<false, 2, true, 6, 8, 2, 8, 0, false, 512, 1>;
     auto x_k6d1o1 = decode_kernel<false, 2, true, 6, 8, 1, 8, 0, false, 512, 1>;
+    auto x_k2w16 = decode_kernel<false, 2, true, 2, 8, 2, 8, 0, false, 1024, 1>;      // 4 waves per SIMD
+    auto x_k3w12 = decode_kernel<false, 2, true, 3, 8, 2, 8, 0, false, 768, 1>;       // 3 waves per SIMD
     // redo pass (one lane per handed-over chunk, runtime table widths)
     auto r_lds = decode_kernel<true, 2, false, 1, 8, 1, 0, 0, true>;
     auto r_l2 = decode_kernel<false, 2, false, 1, 8, 1, 0, 0, true>;
@@ -1686,7 +1688,8 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
         const void *all[] = {(const void *)k_lds2_light[0], (const void *)k_lds2_light[1],
                              (const void *)k_lds4, (const void *)k_lds4_light, (const void *)k_l2, (const void *)k_l2d[0], (const void *)k_l2d[1],
                              (const void *)r_lds, (const void *)r_l2, (const void *)r_l2d,
-                             (const void *)x_k4d1, (const void *)x_k5d1, (const void *)x_k6d1, (const void *)x_k6d1o1};
+                             (const void *)x_k4d1, (const void *)x_k5d1, (const void *)x_k6d1, (const void *)x_k6d1o1,
+                             (const void *)x_k2w16, (const void *)x_k3w12};
         for (const void *f : all) {
             hipError_t r = allow_lds(f, DEC_LDS_MAX);
             if (r != hipSuccess) return r;
@@ -1706,14 +1709,16 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
     const bool wide = p.sec_lds && short_codes && p.n > 0 && p.nbits * 10 > p.n * 8 * 6;      // ratio > 0.6
     static const int variant = getenv("MH_DEC_VARIANT") ? atoi(getenv("MH_DEC_VARIANT")) : 0;
     const bool xvar = variant > 0 && !p.sec_lds && p.direct && p.H != 8;
-    const int xk = variant == 1 ? 4 : variant == 2 ? 5 : 6;
-    const uint64_t per_block = uint64_t(DEC_THREADS) * (xvar ? xk : wide ? 2 : 4);
+    const int xk = variant == 1 ? 4 : variant == 2 ? 5 : variant == 5 ? 2 : variant == 6 ? 3 : 6;
+    const int xthreads = xvar && variant == 5 ? 1024 : xvar && variant == 6 ? 768 : DEC_THREADS;
+    const uint64_t per_block = uint64_t(xthreads) * (xvar ? xk : wide ? 2 : 4);
     uint64_t want = (p.nchunks + per_block - 1) / per_block;
     int grid = int(want > uint64_t(cu_count()) ? uint64_t(cu_count()) : want);
     const int p8 = p.P == 8;
     if (wide) hipLaunchKernelGGL(k_lds4, dim3(grid), dim3(DEC_THREADS), lds, st, p);
     else if (p.sec_lds) hipLaunchKernelGGL(short_codes ? k_lds4_light : k_lds2_light[p8], dim3(grid), dim3(DEC_THREADS), lds, st, p);
-    else if (xvar) hipLaunchKernelGGL(variant == 1 ? x_k4d1 : variant == 2 ? x_k5d1 : variant == 3 ? x_k6d1 : x_k6d1o1, dim3(grid), dim3(DEC_THREADS), lds, st, p);
+    else if (xvar) hipLaunchKernelGGL(variant == 1 ? x_k4d1 : variant == 2 ? x_k5d1 : variant == 3 ? x_k6d1 : variant == 4 ? x_k6d1o1 : variant == 5 ? x_k2w16 : x_k3w12,
+                                      dim3(grid), dim3(xthreads), lds, st, p);
     else if (p.direct) hipLaunchKernelGGL(k_l2d[p.H == 8], dim3(grid), dim3(DEC_THREADS), lds, st, p);
     else hipLaunchKernelGGL(k_l2, dim3(grid), dim3(DEC_THREADS), lds, st, p);
     e = hipGetLastError();

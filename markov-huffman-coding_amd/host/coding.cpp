@@ -8,7 +8,23 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <chrono>
 #include <sstream>
+
+// MH_TIMING=1: one stderr line per stage with the time spent inside it (the first call that touches the
+// device also pays the HIP runtime's start-up, reported separately by tools/cli_rate.py as wall - stages).
+namespace {
+struct StageTimer {
+    const char* what; size_t bytes;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    StageTimer(const char* w, size_t b) : what(w), bytes(b) {}
+    ~StageTimer() {
+        if (!getenv("MH_TIMING")) return;
+        const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        eprintf("[mh-timing] %s %zu bytes %.4f s %.2f GB/s\n", what, bytes, s, bytes / s / 1e9);
+    }
+};
+}  // namespace
 
 // ------------------------------------------------------------------------------------- utils
 
@@ -86,6 +102,7 @@ struct InputView {
     size_t map_len = 0;
     std::vector<unsigned char> own;
     explicit InputView(FILE* f) {
+        if (!f) return;                                              // empty view (placeholder)
         struct stat st;
         long pos = ftell(f);
         if (pos >= 0 && fstat(fileno(f), &st) == 0 && S_ISREG(st.st_mode) && (size_t)st.st_size > (size_t)pos) {
@@ -140,9 +157,32 @@ struct OutputView {
 
 // ------------------------------------------------------------------------ histogram (a1/a2)
 
+// The histogram pass and the encode pass read the same file (src/main.cpp:173-183, then 204-212).  The
+// mapping made for the first is kept for the second, so that the library sees the same buffer twice and
+// its input-residency option (include/mh.h) can serve the second pass from HBM: the file then crosses PCIe once.
+namespace {
+struct KeptInput {
+    InputView* view = nullptr;
+    dev_t dev = 0; ino_t ino = 0; off_t size = 0;
+    void release() { delete view; view = nullptr; }
+} g_kept;
+bool same_file(FILE* f, const KeptInput& k) {
+    struct stat st;
+    return k.view && fstat(fileno(f), &st) == 0 && st.st_dev == k.dev && st.st_ino == k.ino && st.st_size == k.size && ftell(f) == 0;
+}
+}  // namespace
+
 void construct_table(FILE* input_fd, int order, uint64_t* counts64) {
-    InputView all(input_fd);
-    if (order) mh_or_die(mh_histogram_o1(all.data, all.size, MH_PREV0, counts64), "histogram");
+    g_kept.release();
+    struct stat st;
+    const bool regular = fstat(fileno(input_fd), &st) == 0 && S_ISREG(st.st_mode) && ftell(input_fd) == 0;
+    InputView* viewp = new InputView(input_fd);
+    InputView& all = *viewp;
+    if (regular && all.map) { g_kept.view = viewp; g_kept.dev = st.st_dev; g_kept.ino = st.st_ino; g_kept.size = st.st_size; (void)mh_set_input_residency(1); }
+    struct Cleanup { InputView* v; ~Cleanup() { if (g_kept.view != v) delete v; } } cleanup{viewp};
+    StageTimer timer("histogram", all.size);
+    if (order == 2) mh_or_die(mh_histogram_o2(all.data, all.size, counts64), "histogram");
+    else if (order) mh_or_die(mh_histogram_o1(all.data, all.size, MH_PREV0, counts64), "histogram");
     else mh_or_die(mh_histogram_o0(all.data, all.size, counts64), "histogram");
 }
 
@@ -151,7 +191,7 @@ void construct_table(FILE* input_fd, int order, uint64_t* counts64) {
 i_coding_provider::~i_coding_provider() { mh_model_free(model_); }
 
 void i_coding_provider::build_from_counts(const uint64_t* counts, int order) {
-    counts_.assign(counts, counts + (order ? 65536 : 256));     // kept: compress() sizes its output from them
+    counts_.assign(counts, counts + (order == 2 ? (size_t(1) << 24) : order ? 65536 : 256));     // kept: compress() sizes its output from them
     mh_model* m = nullptr;
     mh_or_die(mh_model_from_counts(counts, order, &m), "table build");
     adopt(m);
@@ -206,13 +246,21 @@ static bool valid_chunk(uint64_t c) { return c >= MH_CHUNK_MIN && c <= MH_CHUNK_
 // src/coding.cpp:61-94: header placeholder, payload, header rewrite.  Here the payload comes out of the
 // HIP encoder in one piece, so the header is known before anything is written and no seek is needed.
 void i_coding_provider::compress(FILE* input_fd, FILE* output_fd) {
-    InputView in(input_fd);
+    // the mapping of the histogram pass, when this is the same file read from its start again
+    InputView* kept = same_file(input_fd, g_kept) ? g_kept.view : nullptr;
+    if (kept) fseek(input_fd, 0, SEEK_END);
+    InputView fresh_or_empty(kept ? nullptr : input_fd);
+    const InputView& in = kept ? *kept : fresh_or_empty;
+    struct Release { ~Release() { g_kept.release(); (void)mh_set_input_residency(0); } } release_kept;
+    StageTimer timer("compress", in.size);
     // The file size is known before anything is encoded: histogram of the input . code lengths.  (The
     // histogram that built the tables is reused when there is one; with -e it is taken here.)
     const int order = mh_model_type(model_);
     if (counts_.empty()) {
-        counts_.assign(order ? 65536 : 256, 0);
-        if (order) mh_or_die(mh_histogram_o1(in.data, in.size, MH_PREV0, counts_.data()), "histogram");
+        (void)mh_set_input_residency(1);                             // this histogram's upload serves the encode below
+        counts_.assign(order == 2 ? (size_t(1) << 24) : order ? 65536 : 256, 0);
+        if (order == 2) mh_or_die(mh_histogram_o2(in.data, in.size, counts_.data()), "histogram");
+        else if (order) mh_or_die(mh_histogram_o1(in.data, in.size, MH_PREV0, counts_.data()), "histogram");
         else mh_or_die(mh_histogram_o0(in.data, in.size, counts_.data()), "histogram");
     }
     uint64_t bits = 0;
@@ -284,6 +332,7 @@ void i_coding_provider::decompress(FILE* input_fd, FILE* output_fd) {
     size_t n = 0;
     OutputView out;
     out.file = output_fd;
+    StageTimer timer("decompress", in.size);
     mh_or_die(mh_decode_to(model_, in.data + 1, nbits, MH_PREV0, open_output_cb, &out, &n,
                            have_index ? index.data() : nullptr, have_index ? chunk : 0, have_index ? n_symbols : 0), "decompress");
     if (out.data) out.finish();
@@ -387,6 +436,12 @@ void huffman_table::print_tree() { print_tree_for(0, false, 0, ""); }
 markov_huffman_table::markov_huffman_table(int* counts) { build_from_counts(widen_counts(counts, 65536).data(), 1); }
 markov_huffman_table::markov_huffman_table(const uint64_t* counts) { build_from_counts(counts, 1); }
 markov_huffman_table::markov_huffman_table(bitbuffer& buffer) { build_from_buffer(buffer, 1); }
+
+// order-2 extension (parity unpinned; include/mh.h): 65536 two-byte contexts
+markov2_huffman_table::markov2_huffman_table(const uint64_t* counts) { build_from_counts(counts, 2); }
+markov2_huffman_table::markov2_huffman_table(bitbuffer& buffer) { build_from_buffer(buffer, 2); }
+void markov2_huffman_table::print_table() { eprintf("Error: -g is not available for order-2 tables.\n"); exit(1); }
+void markov2_huffman_table::print_tree() { print_table(); }
 
 void markov_huffman_table::print_table() {                                    // src/markov_huffman.cpp:31-38
     for (int i = 0; i < 256; i++) {

@@ -40,7 +40,8 @@ struct tree_node {
 };
 
 // src/main.cpp:29-39: the histogram pass.  counts64: 65536 entries (order 1) or 256 (order 0),
-// counts[256*prev+c] with prev starting at ' '.  Reads the stream from its current position to EOF.
+// counts[256*prev+c] with prev starting at ' ' (order 2, the extension: 1 << 24 entries, counts[ctx*256+c]).
+// Reads the stream from its current position to EOF.
 void construct_table(FILE* input_fd, int order, uint64_t* counts64);
 
 class i_coding_provider {
@@ -100,6 +101,20 @@ public:
 
 private:
     int get_type() override { return 1; }
+};
+
+// Extension, not in the reference (README.md:158-166 only speculates about it): context = the previous TWO
+// bytes.  Own stream magic and table-file header so that the reference's tools do not mistake either
+// (include/mh.h, "ORDER 2").  Parity unpinned.
+class markov2_huffman_table : public i_coding_provider {
+public:
+    explicit markov2_huffman_table(const uint64_t* counts);   // 1 << 24 counts, counts[ctx * 256 + c]
+    explicit markov2_huffman_table(bitbuffer& buffer);
+    void print_table() override;
+    void print_tree() override;
+
+private:
+    int get_type() override { return 2; }
 };
 
 // src/utils.h:13-21

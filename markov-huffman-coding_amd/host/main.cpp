@@ -32,6 +32,7 @@ static void print_help() {
     eprintf("\n");
     eprintf("\t--index file   chunk-index sidecar for parallel extraction (MI355X extension)\n");
     eprintf("\t--chunk n      symbols per index entry (default 1024)\n");
+    eprintf("\t--order2       contexts of two previous bytes (MI355X extension; own file formats)\n");
     eprintf("\t--device n     HIP device ordinal\n");
 }
 
@@ -43,6 +44,7 @@ struct options {
     const char* encoding_output = nullptr;
     std::string index_path;
     uint32_t chunk = MH_CHUNK_DEFAULT;
+    bool order2 = false;
     int device = -1;
 };
 
@@ -66,6 +68,7 @@ static options parse(int argc, char* argv[]) {
                 o.chunk = (uint32_t)v;
             }
             else if (!strcmp(a, "--device")) o.device = atoi(need(a));
+            else if (!strcmp(a, "--order2")) o.order2 = true;
             else eprintf("Warning: Unknown option %s.\n", a);
             continue;
         }
@@ -145,6 +148,9 @@ int main(int argc, char* argv[]) {
         eprintf("Loading encoding table from file...\n");
         FILE* fd = open_or_die(o.encoding_input, "rb", "encoding input");
         bitbuffer buffer(fd, bitbuffer::read);
+        if (o.order2) {
+            coder = new markov2_huffman_table(buffer);             // its loader checks the order-2 header
+        } else
         // first bit: 0 = Huffman tree, 1 = Markov-Huffman file (src/main.cpp:147-161)
         if (buffer.peek_bit() != !o.simple_huffman) {
             eprintf("Error: Incorrect encoding table provided for current operation; expected %s, found %s.\n",
@@ -152,11 +158,16 @@ int main(int argc, char* argv[]) {
                     buffer.peek_bit() ? "Markov-Huffman" : "simple Huffman");
             exit(1);
         }
-        if (buffer.peek_bit() == 0) coder = new huffman_table(buffer);
+        if (coder) {}
+        else if (buffer.peek_bit() == 0) coder = new huffman_table(buffer);
         else coder = new markov_huffman_table(buffer);
     } else {
-        std::vector<uint64_t> counts(o.simple_huffman ? 256 : 65536);
-        if (o.simple_huffman) {
+        std::vector<uint64_t> counts(o.order2 ? (size_t(1) << 24) : o.simple_huffman ? 256 : 65536);
+        if (o.order2) {
+            eprintf("Building order-2 Markov-Huffman encoding table from input...\n");
+            construct_table(input_fd, 2, counts.data());
+            coder = new markov2_huffman_table(counts.data());
+        } else if (o.simple_huffman) {
             eprintf("Building simple Huffman encoding table from input...\n");
             construct_table(input_fd, 0, counts.data());
             coder = new huffman_table(counts.data());

@@ -120,3 +120,23 @@ def test_large_file_in_segments_and_stdout(tmp_path):
     assert (tmp_path / "d2").read_bytes() == data
     out = run([tmp_path / "c", "-x", "-e", tmp_path / "t"], env=env)          # decoded bytes on stdout
     assert out.returncode == 0 and out.stdout == data
+
+
+def test_order2_extension_round_trip_parity_unpinned(tmp_path, oracle):
+    """--order2 (contexts of two previous bytes; the reference has no such mode, parity unpinned): the CLI's
+    files equal the generalised oracle's, extraction works with and without the index sidecar, and the
+    order-1 extractor refuses the stream."""
+    data = golden()["input_wiki_cpp.txt"]["data"]
+    src = tmp_path / "in"
+    src.write_bytes(data)
+    c, t, idx = tmp_path / "c2", tmp_path / "t2", tmp_path / "c2.idx"
+    assert run([src, "-o", c, "-d", t, "--order2", "--index", idx]).returncode == 0
+    o = oracle.Model.from_data(data, 2)
+    assert c.read_bytes() == o.compress(data)[0]
+    assert t.read_bytes() == o.table_bytes()
+    assert run([c, "-o", tmp_path / "d1", "-x", "-e", t, "--order2", "--index", idx]).returncode == 0
+    assert (tmp_path / "d1").read_bytes() == data
+    assert run([c, "-o", tmp_path / "d2", "-x", "-e", t, "--order2"]).returncode == 0
+    assert (tmp_path / "d2").read_bytes() == data
+    r = run([c, "-o", tmp_path / "d3", "-x", "-e", t])              # order-1 mode, order-2 files
+    assert r.returncode == 1

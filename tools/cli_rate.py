@@ -25,11 +25,20 @@ with open(d + "/in", "wb") as f:
 BIN = os.path.join(ROOT, "bin", "markovhuffman")
 
 
+stages = []
+
+
 def timed(args):
+    """Wall time of the whole process (start-up and HIP initialisation included); the time spent inside
+    the library calls comes back on stderr (MH_TIMING=1) and is collected in `stages`."""
     t = time.perf_counter()
-    r = subprocess.run([BIN] + args)
-    assert r.returncode == 0, args
-    return time.perf_counter() - t
+    r = subprocess.run([BIN] + args, stderr=subprocess.PIPE, env=dict(os.environ, MH_TIMING="1"))
+    assert r.returncode == 0, (args, r.stderr[-500:])
+    wall = time.perf_counter() - t
+    inside = [l.split() for l in r.stderr.decode().splitlines() if l.startswith("[mh-timing]")]
+    stages.append({"args": " ".join(a for a in args if a.startswith("-")), "wall_s": round(wall, 3),
+                   "inside": {l[1]: float(l[4]) for l in inside}})
+    return wall
 
 
 tc = timed([d + "/in", "-o", d + "/c", "-d", d + "/t", "--index", d + "/c.idx"])
@@ -38,6 +47,7 @@ txi = timed([d + "/c", "-o", d + "/di", "-x", "-e", d + "/t", "--index", d + "/c
 same = subprocess.run(["cmp", d + "/in", d + "/d"]).returncode == 0 and subprocess.run(["cmp", d + "/in", d + "/di"]).returncode == 0
 print({"GiB": gib, "compress_s": round(tc, 2), "compress_GBps": round(n / tc / 1e9, 2),
        "decompress_s": round(tx, 2), "decompress_GBps": round(n / tx / 1e9, 2),
-       "decompress_indexed_s": round(txi, 2), "decompress_indexed_GBps": round(n / txi / 1e9, 2), "round_trip_ok": same})
+       "decompress_indexed_s": round(txi, 2), "decompress_indexed_GBps": round(n / txi / 1e9, 2), "round_trip_ok": same,
+       "stages": stages})
 for f in os.listdir(d):
     os.remove(os.path.join(d, f))
