@@ -194,12 +194,17 @@ hipError_t stage_h2d(void *d_dst, const void *h_src, size_t n, hipStream_t st) {
     if (n < (size_t(4) << 20)) return hipMemcpyAsync(d_dst, h_src, n, hipMemcpyHostToDevice, st);   // pageable: returns after staging
     return g_ring.upload(d_dst, h_src, n, st);
 }
+// Device -> caller memory.  Measured on the GPU box (tools/cli_rate.py, 4 GiB): going through the ring costs
+// MORE than the runtime's own pageable path when the destination is a freshly grown file mapping — the
+// runtime pins the destination pages in place (they are allocated in bulk inside the kernel) and lets the
+// DMA engine write them, whereas copying out of the ring takes a user-space page fault per 4 KiB, and several
+// threads doing so contend (compress 2.3 GB/s with the ring against 4.9 GB/s without).  MH_D2H_RING=1 selects
+// the ring for destinations that are already resident.
 hipError_t stage_d2h(void *h_dst, const void *d_src, size_t n, hipStream_t st) {
-    if (n < (size_t(4) << 20)) {
-        hipError_t e = hipMemcpyAsync(h_dst, d_src, n, hipMemcpyDeviceToHost, st);
-        return e != hipSuccess ? e : hipStreamSynchronize(st);
-    }
-    return g_ring.download(h_dst, d_src, n, st);
+    static const bool use_ring = getenv("MH_D2H_RING") && atoi(getenv("MH_D2H_RING")) != 0;
+    if (use_ring && n >= (size_t(4) << 20)) return g_ring.download(h_dst, d_src, n, st);
+    hipError_t e = hipMemcpyAsync(h_dst, d_src, n, hipMemcpyDeviceToHost, st);
+    return e != hipSuccess ? e : hipStreamSynchronize(st);
 }
 
 // Host tables are always built; the device images are uploaded when a device exists.  Without one the

@@ -1322,21 +1322,31 @@ __device__ __forceinline__ LaneIn load_raw2(const uint8_t *__restrict__ data, ui
     return r;
 }
 
-// ---- histogram: counts[ctx * 256 + sym] (64-bit, HBM).  A workgroup keeps 16384 (key, count) slots in LDS:
-// the first key to claim a slot owns it for the whole launch (tags never change once set, so the claim is
-// one compare-and-swap and there is no eviction race); every later occurrence of that key is one LDS add,
-// keys that lose a slot go straight to a 64-bit global atomic.  Skewed sources (text) keep most of their
-// mass in LDS; flat ones degrade to the global-atomic rate.
+// ---- histogram: counts[ctx * 256 + sym] (64-bit, HBM).  A workgroup keeps 16384 (key, count) slots in LDS,
+// an open-addressed table with linear probing: the first key to claim a slot owns it for the whole launch
+// (tags never change once set, so a claim is one compare-and-swap and there is no eviction race); every
+// later occurrence of that key is one LDS add.  A key that finds no slot within its probe limit goes
+// straight to a 64-bit global atomic.  The probing matters more than it looks: text-like sources have a
+// few thousand live keys, and ONE frequent key that loses its slot to an earlier one sends ~1 % of the
+// stream to a single HBM address, where memory-side atomics serialise (first version, no probing: 83 ms
+// per 4 GiB of text with 1.5 % of the symbols on 31 such addresses).  Flat sources (millions of live keys)
+// fill the table at once; from 3/4 occupancy on a key gets two probes, so the misses stay cheap and the
+// kernel degrades to the global-atomic rate over many addresses.
 constexpr int H2_THREADS = 1024;
 constexpr uint32_t H2_SLOTS = 16384;
 constexpr uint32_t H2_EMPTY = 0xFFFFFFFFu;
-constexpr int H2_LDS_BYTES = int(H2_SLOTS) * 8;
+constexpr int H2_LDS_BYTES = int(H2_SLOTS) * 8 + 16;
+constexpr uint32_t H2_PROBES = 8, H2_PROBES_FULL = 2, H2_FULL = H2_SLOTS * 3 / 4;
 
-__device__ __forceinline__ void hist2_add(uint32_t *tag, uint32_t *cnt, unsigned long long *counts, uint32_t key) {
-    const uint32_t slot = (key * 0x9E3779B1u) >> 18;             // 14 bits
-    const uint32_t old = atomicCAS(&tag[slot], H2_EMPTY, key);
-    if (old == H2_EMPTY || old == key) atomicAdd(&cnt[slot], 1u);
-    else atomicAdd(&counts[key], 1ull);
+__device__ __forceinline__ void hist2_add(uint32_t *tag, uint32_t *cnt, uint32_t *used, unsigned long long *counts, uint32_t key,
+                                          uint32_t probes) {
+    uint32_t slot = (key * 0x9E3779B1u) >> 18;                   // 14 bits
+    for (uint32_t p = 0; p < probes; ++p, slot = (slot + 1u) & (H2_SLOTS - 1u)) {
+        const uint32_t old = atomicCAS(&tag[slot], H2_EMPTY, key);
+        if (old == H2_EMPTY) atomicAdd(used, 1u);
+        if (old == H2_EMPTY || old == key) { atomicAdd(&cnt[slot], 1u); return; }
+    }
+    atomicAdd(&counts[key], 1ull);
 }
 
 __global__ __launch_bounds__(H2_THREADS) void hist_o2_kernel(const uint8_t *__restrict__ data, uint64_t n, uint32_t ctx0,
@@ -1344,7 +1354,9 @@ __global__ __launch_bounds__(H2_THREADS) void hist_o2_kernel(const uint8_t *__re
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *tag = reinterpret_cast<uint32_t *>(smem);
     uint32_t *cnt = tag + H2_SLOTS;
+    uint32_t *used = cnt + H2_SLOTS;                             // slots claimed so far
     for (uint32_t i = threadIdx.x; i < H2_SLOTS; i += H2_THREADS) { tag[i] = H2_EMPTY; cnt[i] = 0; }
+    if (threadIdx.x == 0) *used = 0;
     __syncthreads();
     const uint64_t nvec = n >> 4;
     const uint4 *vdata = reinterpret_cast<const uint4 *>(data);
@@ -1357,13 +1369,14 @@ __global__ __launch_bounds__(H2_THREADS) void hist_o2_kernel(const uint8_t *__re
         uint32_t ctx = ((up & 255u) << 8) | (up >> 8);
         if ((threadIdx.x & 63u) == 0) ctx = live ? ctx_before(data, n, v << 4, ctx0) : ctx0;
         if (!live) continue;
+        const uint32_t probes = *used < H2_FULL ? H2_PROBES : H2_PROBES_FULL;
         const uint32_t x[4] = {x4.x, x4.y, x4.z, x4.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint32_t key = (ctx << 8) | ((x[k] >> (8 * j)) & 255u);
-                hist2_add(tag, cnt, counts, key);
+                hist2_add(tag, cnt, used, counts, key, probes);
                 ctx = key & 0xFFFFu;
             }
         }

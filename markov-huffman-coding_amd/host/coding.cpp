@@ -10,6 +10,7 @@
 
 #include <chrono>
 #include <sstream>
+#include <thread>
 
 // MH_TIMING=1: one stderr line per stage with the time spent inside it (the first call that touches the
 // device also pays the HIP runtime's start-up, reported separately by tools/cli_rate.py as wall - stages).
@@ -133,18 +134,40 @@ struct OutputView {
     void* map = nullptr;
     FILE* file = nullptr;
     std::vector<unsigned char> own;
+    // The mapping of a freshly grown file has no pages yet.  A few helper threads ask the kernel to
+    // allocate them in bulk (MADV_POPULATE_WRITE) while the device is still computing, so that the
+    // device-to-host copies find their destination resident instead of faulting it in page by page.
+    std::vector<std::thread> populate;
+    void start_populate() {
+#ifdef MADV_POPULATE_WRITE
+        if (!map || size < (size_t(64) << 20)) return;
+        const size_t threads = 4, step = size_t(32) << 20;
+        const size_t part = ((size / threads) + step - 1) / step * step;
+        for (size_t t = 0; t < threads; ++t) {
+            const size_t lo = t * part, hi = std::min(size, lo + part);
+            if (lo >= hi) break;
+            unsigned char* base = data;
+            populate.emplace_back([base, lo, hi, step] {
+                for (size_t o = lo; o < hi; o += step)
+                    if (madvise(base + o, std::min(step, hi - o), MADV_POPULATE_WRITE) != 0) return;   // old kernel: plain faults do it
+            });
+        }
+#endif
+    }
+    void join_populate() { for (std::thread& t : populate) t.join(); populate.clear(); }
     void open(FILE* f, size_t n) {
         file = f; size = n;
         struct stat st;
         fflush(f);
         if (n && fstat(fileno(f), &st) == 0 && S_ISREG(st.st_mode) && ftell(f) == 0 && ftruncate(fileno(f), (off_t)n) == 0) {
             void* m = mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_SHARED, fileno(f), 0);
-            if (m != MAP_FAILED) { map = m; data = (unsigned char*)m; return; }
+            if (m != MAP_FAILED) { map = m; data = (unsigned char*)m; start_populate(); return; }
         }
         own.assign(n ? n : 1, 0);
         data = own.data();
     }
     void finish() {
+        join_populate();
         if (map) {
             if (munmap(map, size) != 0) { eprintf("Error occurred while writing file.\n"); exit(1); }
             map = nullptr;
