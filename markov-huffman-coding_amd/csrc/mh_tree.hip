@@ -86,17 +86,52 @@ struct RegHeap {
             klo[9] = wl(lo, 0, klo[9]); if (K64) khi[9] = wl(hi, 0, khi[9]); itm[9] = wl(it, 0, itm[9]);
         }
     }
-    // src/min_pq.tpp:29-36: the new entry moves up while its parent's key is STRICTLY greater
+    // Both sifts are written as a read-only phase that follows the whole path with scalar selects, and a
+    // write phase that stores ONE entry per level unconditionally — the moved entry, the sifted key, or
+    // what the slot held anyway.  (Branches with early exits made the compiler copy all thirty heap registers
+    // at every join: ~500 instructions per heap operation, no faster than the first version's LDS heap.)
+
+    // src/min_pq.tpp:4-7 + 29-36: the new entry, appended at (L, pos), moves up while its parent's key is
+    // STRICTLY greater.  Heap order along the root path means the parents that move form one bottom segment.
     template <int L>
-    __device__ __forceinline__ void swim(uint32_t pos, uint32_t lo, uint32_t hi, uint32_t it) {
-        if constexpr (L == 0) {
-            put<0>(0, lo, hi, it);
-        } else {
-            uint32_t plo, phi, pit;
-            get<L - 1>(pos >> 1, plo, phi, pit);
-            if (!lt(lo, hi, plo, phi)) { put<L>(pos, lo, hi, it); return; }
-            put<L>(pos, plo, phi, pit);
-            swim<L - 1>(pos >> 1, lo, hi, it);
+    __device__ __forceinline__ void swim_flat(uint32_t pos, uint32_t lo, uint32_t hi, uint32_t it) {
+        uint32_t alo[L + 1], ahi[L + 1], ait[L + 1];            // ancestors: a*[l] = entry at level l on the root path (l < L)
+        uint32_t moves = 0;                                      // parents that move down (counted from the bottom)
+        bool going = true;
+        alo[L] = lo; ahi[L] = hi; ait[L] = it;
+#pragma unroll
+        for (int l = L - 1; l >= 0; --l) {
+            get_dyn(l, pos >> (L - l), alo[l], ahi[l], ait[l]);
+            going = going && lt(lo, hi, alo[l], ahi[l]);         // parent > key
+            moves += going ? 1u : 0u;
+        }
+        const uint32_t f = uint32_t(L) - moves;                  // level where the new entry comes to rest
+#pragma unroll
+        for (int l = L; l >= 0; --l) {
+            // level l gets: its parent's entry if the parent moved into it, the new entry at level f, else itself
+            const bool from_parent = uint32_t(l) > f;
+            const bool self = uint32_t(l) < f;
+            const uint32_t plo = l > 0 ? alo[l > 0 ? l - 1 : 0] : lo, phi = l > 0 ? ahi[l > 0 ? l - 1 : 0] : hi,
+                           pit = l > 0 ? ait[l > 0 ? l - 1 : 0] : it;
+            const uint32_t wlo = from_parent ? plo : self ? alo[l] : lo;
+            const uint32_t whi = from_parent ? phi : self ? ahi[l] : hi;
+            const uint32_t wit = from_parent ? pit : self ? ait[l] : it;
+            put_dyn(l, pos >> (L - l), wlo, whi, wit);
+        }
+    }
+    // level known at compile time through the unrolled loops above: these forward to get<>/put<>
+    __device__ __forceinline__ void get_dyn(int l, uint32_t pos, uint32_t &lo, uint32_t &hi, uint32_t &it) const {
+        switch (l) {
+            case 0: get<0>(pos, lo, hi, it); break; case 1: get<1>(pos, lo, hi, it); break; case 2: get<2>(pos, lo, hi, it); break;
+            case 3: get<3>(pos, lo, hi, it); break; case 4: get<4>(pos, lo, hi, it); break; case 5: get<5>(pos, lo, hi, it); break;
+            case 6: get<6>(pos, lo, hi, it); break; case 7: get<7>(pos, lo, hi, it); break; default: get<8>(pos, lo, hi, it); break;
+        }
+    }
+    __device__ __forceinline__ void put_dyn(int l, uint32_t pos, uint32_t lo, uint32_t hi, uint32_t it) {
+        switch (l) {
+            case 0: put<0>(pos, lo, hi, it); break; case 1: put<1>(pos, lo, hi, it); break; case 2: put<2>(pos, lo, hi, it); break;
+            case 3: put<3>(pos, lo, hi, it); break; case 4: put<4>(pos, lo, hi, it); break; case 5: put<5>(pos, lo, hi, it); break;
+            case 6: put<6>(pos, lo, hi, it); break; case 7: put<7>(pos, lo, hi, it); break; default: put<8>(pos, lo, hi, it); break;
         }
     }
     __device__ __forceinline__ void push(uint32_t lo, uint32_t hi, uint32_t it) {     // src/min_pq.tpp:4-7
@@ -104,37 +139,46 @@ struct RegHeap {
         const uint32_t level = 31u - uint32_t(__builtin_clz(i + 1u));
         const uint32_t pos = i + 1u - (1u << level);
         switch (level) {
-            case 0: swim<0>(pos, lo, hi, it); break;
-            case 1: swim<1>(pos, lo, hi, it); break;
-            case 2: swim<2>(pos, lo, hi, it); break;
-            case 3: swim<3>(pos, lo, hi, it); break;
-            case 4: swim<4>(pos, lo, hi, it); break;
-            case 5: swim<5>(pos, lo, hi, it); break;
-            case 6: swim<6>(pos, lo, hi, it); break;
-            case 7: swim<7>(pos, lo, hi, it); break;
-            default: swim<8>(pos, lo, hi, it); break;
+            case 0: swim_flat<0>(pos, lo, hi, it); break;
+            case 1: swim_flat<1>(pos, lo, hi, it); break;
+            case 2: swim_flat<2>(pos, lo, hi, it); break;
+            case 3: swim_flat<3>(pos, lo, hi, it); break;
+            case 4: swim_flat<4>(pos, lo, hi, it); break;
+            case 5: swim_flat<5>(pos, lo, hi, it); break;
+            case 6: swim_flat<6>(pos, lo, hi, it); break;
+            case 7: swim_flat<7>(pos, lo, hi, it); break;
+            default: swim_flat<8>(pos, lo, hi, it); break;
         }
     }
-    // src/min_pq.tpp:38-52: the hole at (L, pos) takes the smaller child — the right one only when STRICTLY
-    // smaller than the left — while that child is STRICTLY smaller than the sinking key
-    template <int L>
-    __device__ __forceinline__ void sink(uint32_t pos, uint32_t lo, uint32_t hi, uint32_t it) {
-        if constexpr (L == 8) {
-            put<8>(pos, lo, hi, it);
-        } else {
-            const uint32_t li = ((2u << L) - 1u) + 2u * pos;             // heap index of the left child
-            if (li >= hn) { put<L>(pos, lo, hi, it); return; }
-            uint32_t clo, chi, cit;
-            get<L + 1>(2u * pos, clo, chi, cit);
-            uint32_t right = 0;
-            if (li + 1u < hn) {
-                uint32_t rlo, rhi, rit;
-                get<L + 1>(2u * pos + 1u, rlo, rhi, rit);
-                if (lt(rlo, rhi, clo, chi)) { clo = rlo; chi = rhi; cit = rit; right = 1; }
-            }
-            if (!lt(clo, chi, lo, hi)) { put<L>(pos, lo, hi, it); return; }
-            put<L>(pos, clo, chi, cit);
-            sink<L + 1>(2u * pos + right, lo, hi, it);
+    // src/min_pq.tpp:38-52: the hole at the root takes the smaller child — the right one only when STRICTLY
+    // smaller than the left — while that child is STRICTLY smaller than the sinking key.
+    __device__ __forceinline__ void sink_flat(uint32_t lo, uint32_t hi, uint32_t it) {
+        uint32_t pos[9], clo[9], chi[9], cit[9];                 // the min-child path: entry (clo, chi, cit)[l] at (l, pos[l])
+        pos[0] = 0; clo[0] = lo; chi[0] = hi; cit[0] = it;       // level 0 is the hole itself
+        uint32_t moves = 0;                                      // children that move up
+        bool going = true;
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            const uint32_t li = ((2u << l) - 1u) + 2u * pos[l];  // heap index of the left child
+            uint32_t llo, lhi, lit, rlo, rhi, rit;
+            get_dyn(l + 1, 2u * pos[l], llo, lhi, lit);
+            get_dyn(l + 1, 2u * pos[l] + 1u, rlo, rhi, rit);     // (level 8 holds one entry: both reads return it, the right one is never valid)
+            const bool right = li + 1u < hn && lt(rlo, rhi, llo, lhi);
+            clo[l + 1] = right ? rlo : llo; chi[l + 1] = right ? rhi : lhi; cit[l + 1] = right ? rit : lit;
+            pos[l + 1] = 2u * pos[l] + (right ? 1u : 0u);
+            going = going && li < hn && lt(clo[l + 1], chi[l + 1], lo, hi);
+            moves += going ? 1u : 0u;
+        }
+#pragma unroll
+        for (int l = 0; l <= 8; ++l) {
+            // level l gets: its child's entry if that child moved up, the sinking entry at level `moves`, else itself
+            const bool from_child = uint32_t(l) < moves;
+            const bool self = uint32_t(l) > moves;
+            const int c = l < 8 ? l + 1 : 8;
+            const uint32_t wlo = from_child ? clo[c] : self ? clo[l] : lo;
+            const uint32_t whi = from_child ? chi[c] : self ? chi[l] : hi;
+            const uint32_t wit = from_child ? cit[c] : self ? cit[l] : it;
+            put_dyn(l, pos[l], wlo, whi, wit);
         }
     }
     // src/min_pq.tpp:9-15: returns the minimum's item and key; the last entry sinks from the root
@@ -156,7 +200,7 @@ struct RegHeap {
             case 7: get<7>(pos, lo, hi, it); break;
             default: get<8>(pos, lo, hi, it); break;
         }
-        sink<0>(0, lo, hi, it);
+        sink_flat(lo, hi, it);
         return top;
     }
 };

@@ -11,7 +11,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 gib = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0
 n = int(gib * (1 << 30))
-d = "/tmp/mh_cli_rate"
+# where the files live: tmpfs when there is one (memory-backed, so the figures are the pipeline's and not the
+# box's disk and dirty-page throttling: on /tmp the same binary measured between 2 and 5 GB/s from box to box),
+# MH_RATE_DIR to choose
+d = os.environ.get("MH_RATE_DIR") or ("/dev/shm/mh_cli_rate" if os.path.isdir("/dev/shm") else "/tmp/mh_cli_rate")
 os.makedirs(d, exist_ok=True)
 rng = np.random.default_rng(5)
 w = 1.0 / np.arange(1, 257) ** 1.1
@@ -45,7 +48,7 @@ tc = timed([d + "/in", "-o", d + "/c", "-d", d + "/t", "--index", d + "/c.idx"])
 tx = timed([d + "/c", "-o", d + "/d", "-x", "-e", d + "/t"])
 txi = timed([d + "/c", "-o", d + "/di", "-x", "-e", d + "/t", "--index", d + "/c.idx"])
 same = subprocess.run(["cmp", d + "/in", d + "/d"]).returncode == 0 and subprocess.run(["cmp", d + "/in", d + "/di"]).returncode == 0
-print({"GiB": gib, "compress_s": round(tc, 2), "compress_GBps": round(n / tc / 1e9, 2),
+print({"GiB": gib, "dir": d, "compress_s": round(tc, 2), "compress_GBps": round(n / tc / 1e9, 2),
        "decompress_s": round(tx, 2), "decompress_GBps": round(n / tx / 1e9, 2),
        "decompress_indexed_s": round(txi, 2), "decompress_indexed_GBps": round(n / txi / 1e9, 2), "round_trip_ok": same,
        "stages": stages})
