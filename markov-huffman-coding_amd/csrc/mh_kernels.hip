@@ -33,27 +33,6 @@ using mh::TREE_STRIDE;
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
-// 16-byte streaming accesses of the decoder (payload granules in, decoded bytes out).  MH_EXP_NT (A/B
-// builds, csrc/Makefile `exp`): non-temporal, i.e. past the vector L1, so that the randomly gathered
-// second-level table lines are what stays there.
-typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint4 ld_stream16(const uint4 *p) {
-#ifdef MH_EXP_NT
-    const v4u32 v = __builtin_nontemporal_load(reinterpret_cast<const v4u32 *>(p));
-    return make_uint4(v.x, v.y, v.z, v.w);
-#else
-    return *p;
-#endif
-}
-__device__ __forceinline__ void st_stream16(uint4 *p, const uint4 &v) {
-#ifdef MH_EXP_NTS
-    v4u32 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
-    __builtin_nontemporal_store(t, reinterpret_cast<v4u32 *>(p));
-#else
-    *p = v;
-#endif
-}
-
 // Inclusive prefix sum over the 64 lanes of a wave with DPP row shifts / row broadcasts (7 VALU
 // instructions; the __shfl_up form costs six LDS-crossbar round trips).
 __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
@@ -757,8 +736,10 @@ __device__ __forceinline__ uint32_t decode_one(const uint16_t *prim, const uint3
 // registers).  A block is 2 * GW symbols (<= 16 bits each through the tables = one granule).
 // DEPTH = granules a stream keeps beside `cur`: 2 (`nxt` resident + `pre` in flight: a granule is consumed
 // one block after it was asked for, so the block-boundary loads never make a pop wait) or 1 (`nxt` alone,
-// loaded straight into: eight registers per stream fewer, which is what lets a lane run more streams; the
-// switch cur <- nxt may then wait for a load that was issued at the last block boundary).
+// loaded straight into: eight registers per stream fewer; the switch cur <- nxt may then wait for a load
+// that was issued at the last block boundary).  Measured at 16 GiB Zipf (profiles/r02/decode_variants.md):
+// DEPTH 1 with 4, 5 or 6 streams per lane and 3 or 4 waves per SIMD all land within 2 % of, or behind,
+// DEPTH 2 with 4 streams and 2 waves — the kernel is not short of streams in flight.
 template <int GW, int DEPTH = 2>
 struct LaneStream {
     static constexpr int NQ = GW / 4;      // uint4 loads per granule
@@ -780,7 +761,7 @@ struct LaneStream {
         const uint4 *src = base + uint64_t(NQ) * g;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const uint4 a = ld_stream16(src + q);
+            const uint4 a = src[q];
             dst[4 * q] = a.x; dst[4 * q + 1] = a.y; dst[4 * q + 2] = a.z; dst[4 * q + 3] = a.w;
         }
         ++gnext;
@@ -1126,7 +1107,7 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecParams p) {
                 for (int k = 0; k < K; ++k) {
                     uint4 *o16 = reinterpret_cast<uint4 *>(p.out + ((c0 + uint64_t(k) * NT) << p.chunk_shift)) + burst * OUTB;
 #pragma unroll
-                    for (int u = 0; u < OUTB; ++u) st_stream16(o16 + u, make_uint4(Q[k][u][0], Q[k][u][1], Q[k][u][2], Q[k][u][3]));
+                    for (int u = 0; u < OUTB; ++u) o16[u] = make_uint4(Q[k][u][0], Q[k][u][1], Q[k][u][2], Q[k][u][3]);
                 }
             }
             // every chunk must end exactly where the next one starts (null entries, a wrong table or a
@@ -1443,8 +1424,47 @@ __global__ __launch_bounds__(E_THREADS) void enc2_emit_kernel(EmitParams p) {
         for (int k = 0; k < E_SUBSTEPS; ++k) {
             const uint64_t off = wt * E_WT + uint64_t(k) * E_SUB + lane * E_VEC;
             const LaneIn in = load_raw2(p.data, p.n, off, p.prev0);
-            uint32_t sub_bits;
-            emit_substep_slow<2>(p, nullptr, stage, out32, in.x, head_ctx(in), in.nvalid, lane, off, abs_bits, gbase, cur, seam0, sub_bits);
+            const uint32_t ctx0 = head_ctx(in);
+            // all 16 (length, codeword) pairs of the lane are gathered at once: 32 loads in flight instead of
+            // one dependent round trip per symbol (first version: 150 GB/s, bound by exactly that latency)
+            uint32_t l[16];
+            uint64_t c[16];
+            {
+                const uint32_t x[4] = {in.x.x, in.x.y, in.x.z, in.x.w};
+                uint32_t ctx = ctx0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const uint32_t key = (ctx << 8) | ((x[j >> 2] >> (8 * (j & 3))) & 255u);
+                    const bool valid = uint32_t(j) < in.nvalid;
+                    l[j] = valid ? uint32_t(p.len8[key]) : 0u;
+                    c[j] = valid ? p.code64[key] : 0ull;
+                    ctx = key & 0xFFFFu;
+                }
+            }
+            uint32_t L = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { if (l[j] > 64u) l[j] = 0; L += l[j]; }
+            const uint32_t inc = wave_inclusive_sum(L);
+            uint32_t sub_bits = __builtin_amdgcn_readlane(inc, 63);
+            if (cur + sub_bits <= uint32_t(E_STAGE_WORDS - 3) * 32u) {       // the usual case: the sub-step fits the image
+                const uint32_t exc = inc - L;
+                const uint32_t S = 1u << p.chunk_shift;
+                if (p.index && in.nvalid && ((uint32_t(off) & (S - 1u)) == 0u))
+                    p.index[off >> p.chunk_shift] = (uint64_t(ctx0) << 48) | (abs_bits + exc);
+                uint32_t o = cur + exc;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    if (l[j]) deposit<false>(stage, c[j] << (64u - l[j]), o, 0, 0);
+                    o += l[j];
+                }
+                const uint32_t nfull = (cur + sub_bits) >> 5;
+                flush_words(stage, out32, gbase, nfull, seam0, lane);
+                seam0 = seam0 && nfull == 0;
+                gbase += nfull;
+                cur = (cur + sub_bits) & 31u;
+            } else {                                                          // very long codes: fill and flush in rounds
+                emit_substep_slow<2>(p, nullptr, stage, out32, in.x, ctx0, in.nvalid, lane, off, abs_bits, gbase, cur, seam0, sub_bits);
+            }
             abs_bits += sub_bits;
         }
         if (cur != 0 && lane == 0) {
@@ -1686,13 +1706,6 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
     auto k_lds4_light = decode_kernel<true, 4, false, 4, 8, 2, 8, 0>;
     auto k_l2 = decode_kernel<false, 2, false, 4, 8, 2, 8, 0>;
     void (*k_l2d[2])(DecParams) = {decode_kernel<false, 2, true, 4, 8, 2, 8, 0>, decode_kernel<false, 2, true, 4, 8, 2, 8, 8>};
-    // A/B variants of the L2-direct decoder (MH_DEC_VARIANT=1..): more streams per lane on the shallower FIFO
-    auto x_k4d1 = decode_kernel<false, 2, true, 4, 8, 2, 8, 0, false, 512, 1>;
-    auto x_k5d1 = decode_kernel<false, 2, true, 5, 8, 2, 8, 0, false, 512, 1>;
-    auto x_k6d1 = decode_kernel<false, 2, true, 6, 8, 2, 8, 0, false, 512, 1>;
-    auto x_k6d1o1 = decode_kernel<false, 2, true, 6, 8, 1, 8, 0, false, 512, 1>;
-    auto x_k2w16 = decode_kernel<false, 2, true, 2, 8, 2, 8, 0, false, 1024, 1>;      // 4 waves per SIMD
-    auto x_k3w12 = decode_kernel<false, 2, true, 3, 8, 2, 8, 0, false, 768, 1>;       // 3 waves per SIMD
     // redo pass (one lane per handed-over chunk, runtime table widths)
     auto r_lds = decode_kernel<true, 2, false, 1, 8, 1, 0, 0, true>;
     auto r_l2 = decode_kernel<false, 2, false, 1, 8, 1, 0, 0, true>;
@@ -1700,9 +1713,7 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
     e = once_per_device(&DeviceState::decode_ready, [&] {
         const void *all[] = {(const void *)k_lds2_light[0], (const void *)k_lds2_light[1],
                              (const void *)k_lds4, (const void *)k_lds4_light, (const void *)k_l2, (const void *)k_l2d[0], (const void *)k_l2d[1],
-                             (const void *)r_lds, (const void *)r_l2, (const void *)r_l2d,
-                             (const void *)x_k4d1, (const void *)x_k5d1, (const void *)x_k6d1, (const void *)x_k6d1o1,
-                             (const void *)x_k2w16, (const void *)x_k3w12};
+                             (const void *)r_lds, (const void *)r_l2, (const void *)r_l2d};
         for (const void *f : all) {
             hipError_t r = allow_lds(f, DEC_LDS_MAX);
             if (r != hipSuccess) return r;
@@ -1720,18 +1731,12 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
     // 4 GiB), as they do for low-ratio data (41 %-ratio text 8 % slower with the wide streams).
     const bool short_codes = p.nsec == 0 && p.P == 8;
     const bool wide = p.sec_lds && short_codes && p.n > 0 && p.nbits * 10 > p.n * 8 * 6;      // ratio > 0.6
-    static const int variant = getenv("MH_DEC_VARIANT") ? atoi(getenv("MH_DEC_VARIANT")) : 0;
-    const bool xvar = variant > 0 && !p.sec_lds && p.direct && p.H != 8;
-    const int xk = variant == 1 ? 4 : variant == 2 ? 5 : variant == 5 ? 2 : variant == 6 ? 3 : 6;
-    const int xthreads = xvar && variant == 5 ? 1024 : xvar && variant == 6 ? 768 : DEC_THREADS;
-    const uint64_t per_block = uint64_t(xthreads) * (xvar ? xk : wide ? 2 : 4);
+    const uint64_t per_block = uint64_t(DEC_THREADS) * (wide ? 2 : 4);
     uint64_t want = (p.nchunks + per_block - 1) / per_block;
     int grid = int(want > uint64_t(cu_count()) ? uint64_t(cu_count()) : want);
     const int p8 = p.P == 8;
     if (wide) hipLaunchKernelGGL(k_lds4, dim3(grid), dim3(DEC_THREADS), lds, st, p);
     else if (p.sec_lds) hipLaunchKernelGGL(short_codes ? k_lds4_light : k_lds2_light[p8], dim3(grid), dim3(DEC_THREADS), lds, st, p);
-    else if (xvar) hipLaunchKernelGGL(variant == 1 ? x_k4d1 : variant == 2 ? x_k5d1 : variant == 3 ? x_k6d1 : variant == 4 ? x_k6d1o1 : variant == 5 ? x_k2w16 : x_k3w12,
-                                      dim3(grid), dim3(xthreads), lds, st, p);
     else if (p.direct) hipLaunchKernelGGL(k_l2d[p.H == 8], dim3(grid), dim3(DEC_THREADS), lds, st, p);
     else hipLaunchKernelGGL(k_l2, dim3(grid), dim3(DEC_THREADS), lds, st, p);
     e = hipGetLastError();
