@@ -668,11 +668,15 @@ struct BitCursor {
     __device__ __forceinline__ void drop(uint32_t n) { buf <<= n; cnt -= n; }
 };
 
+typedef int v4i32 __attribute__((ext_vector_type(4)));
 struct DecTables {
     const uint16_t *sec;         // second-level tables: LDS copy (decode_kernel) or global (index builder)
     const uint32_t *tree;        // last-resort walk (HBM/L2)
     uint32_t P;                  // primary width in bits
     uint32_t direct, H;          // uniform L2 tables: inner entry = table id, 2^H entries each
+#ifdef MH_EXP_BUF
+    __amdgpu_buffer_rsrc_t sec_rsrc;   // buffer resource over `sec`: a gather takes a 32-bit byte offset, no 64-bit address
+#endif
 };
 
 // Decodes one symbol (sequential index builder; tables read from global memory).  Returns the symbol,
@@ -940,7 +944,11 @@ __device__ __forceinline__ void decode_step(const uint16_t *prim, const uint32_t
             if (DIRECT && PC == 8 && HC == 8) idx = __builtin_amdgcn_perm(e[k], hi[k], 0x0C050402u);   // e << 8 | byte 2 of hi
             else if (DIRECT) idx = (e[k] << H) | __builtin_amdgcn_ubfe(hi[k], 32u - P - H, H);
             else idx = sb[k] + (e[k] & 0xFFFu) + __builtin_amdgcn_ubfe(hi[k], 32u - P - h, h);
+#ifdef MH_EXP_BUF
+            if (in) e2[k] = uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(t.sec_rsrc, int(idx << 1), 0, 0)));
+#else
             if (in) e2[k] = t.sec[idx];
+#endif
         }
         // leaves carry bit 15 and lanes without a second level hold 0: the larger one is the entry that
         // resolves the symbol; if both are inner the result has no leaf flag and the code is walked
@@ -1036,7 +1044,12 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecParams p) {
 
     // (a hybrid — tables of the frequent contexts in LDS, the rest in L2 — was measured and did not pay:
     //  some lane still needs L2 in every round, and that latency, not the gather width, is what costs)
+#ifdef MH_EXP_BUF
+    const DecTables tabs{SEC_LDS ? lsec : p.sec, p.tree, p.P, p.direct, p.H,
+                         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.sec), 0, int((p.nsec + 8u) * 2u), 0x00020000)};
+#else
     const DecTables tabs{SEC_LDS ? lsec : p.sec, p.tree, p.P, p.direct, p.H};
+#endif
     const uint32_t S = 1u << p.chunk_shift;
     const uint64_t full_chunks = p.n >> p.chunk_shift;          // chunks with exactly S symbols
     if (REDO) {
@@ -1705,14 +1718,21 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
     auto k_lds4 = decode_kernel<true, 4, false, 2, 16, 4, 8, 0>;
     auto k_lds4_light = decode_kernel<true, 4, false, 4, 8, 2, 8, 0>;
     auto k_l2 = decode_kernel<false, 2, false, 4, 8, 2, 8, 0>;
-    void (*k_l2d[2])(DecParams) = {decode_kernel<false, 2, true, 4, 8, 2, 8, 0>, decode_kernel<false, 2, true, 4, 8, 2, 8, 8>};
+    // second-level height H as a template constant where it is common (max code length 10..12 and >= 16): the
+    // table index is then two instructions with immediate operands
+    void (*k_l2d[9])(DecParams) = {decode_kernel<false, 2, true, 4, 8, 2, 8, 0>, decode_kernel<false, 2, true, 4, 8, 2, 8, 0>,
+                                   decode_kernel<false, 2, true, 4, 8, 2, 8, 2>, decode_kernel<false, 2, true, 4, 8, 2, 8, 3>,
+                                   decode_kernel<false, 2, true, 4, 8, 2, 8, 4>, decode_kernel<false, 2, true, 4, 8, 2, 8, 0>,
+                                   decode_kernel<false, 2, true, 4, 8, 2, 8, 0>, decode_kernel<false, 2, true, 4, 8, 2, 8, 0>,
+                                   decode_kernel<false, 2, true, 4, 8, 2, 8, 8>};
     // redo pass (one lane per handed-over chunk, runtime table widths)
     auto r_lds = decode_kernel<true, 2, false, 1, 8, 1, 0, 0, true>;
     auto r_l2 = decode_kernel<false, 2, false, 1, 8, 1, 0, 0, true>;
     auto r_l2d = decode_kernel<false, 2, true, 1, 8, 1, 0, 0, true>;
     e = once_per_device(&DeviceState::decode_ready, [&] {
         const void *all[] = {(const void *)k_lds2_light[0], (const void *)k_lds2_light[1],
-                             (const void *)k_lds4, (const void *)k_lds4_light, (const void *)k_l2, (const void *)k_l2d[0], (const void *)k_l2d[1],
+                             (const void *)k_lds4, (const void *)k_lds4_light, (const void *)k_l2, (const void *)k_l2d[0], (const void *)k_l2d[2],
+                             (const void *)k_l2d[3], (const void *)k_l2d[4], (const void *)k_l2d[8],
                              (const void *)r_lds, (const void *)r_l2, (const void *)r_l2d};
         for (const void *f : all) {
             hipError_t r = allow_lds(f, DEC_LDS_MAX);
@@ -1737,7 +1757,7 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
     const int p8 = p.P == 8;
     if (wide) hipLaunchKernelGGL(k_lds4, dim3(grid), dim3(DEC_THREADS), lds, st, p);
     else if (p.sec_lds) hipLaunchKernelGGL(short_codes ? k_lds4_light : k_lds2_light[p8], dim3(grid), dim3(DEC_THREADS), lds, st, p);
-    else if (p.direct) hipLaunchKernelGGL(k_l2d[p.H == 8], dim3(grid), dim3(DEC_THREADS), lds, st, p);
+    else if (p.direct) hipLaunchKernelGGL(k_l2d[p.H <= 8 ? p.H : 0], dim3(grid), dim3(DEC_THREADS), lds, st, p);
     else hipLaunchKernelGGL(k_l2, dim3(grid), dim3(DEC_THREADS), lds, st, p);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
