@@ -668,15 +668,13 @@ struct BitCursor {
     __device__ __forceinline__ void drop(uint32_t n) { buf <<= n; cnt -= n; }
 };
 
-typedef int v4i32 __attribute__((ext_vector_type(4)));
 struct DecTables {
     const uint16_t *sec;         // second-level tables: LDS copy (decode_kernel) or global (index builder)
     const uint32_t *tree;        // last-resort walk (HBM/L2)
     uint32_t P;                  // primary width in bits
     uint32_t direct, H;          // uniform L2 tables: inner entry = table id, 2^H entries each
-#ifdef MH_EXP_BUF
-    __amdgpu_buffer_rsrc_t sec_rsrc;   // buffer resource over `sec`: a gather takes a 32-bit byte offset, no 64-bit address
-#endif
+    __amdgpu_buffer_rsrc_t sec_rsrc;   // L2-resident second level: buffer resource over `sec` (a gather then takes a 32-bit
+                                       // byte offset instead of a 64-bit address)
 };
 
 // Decodes one symbol (sequential index builder; tables read from global memory).  Returns the symbol,
@@ -938,17 +936,14 @@ __device__ __forceinline__ void decode_step(const uint16_t *prim, const uint32_t
             const bool in = (e[k] & DEC16_LEAF) == 0;
             const uint32_t h = DIRECT ? H : ((e[k] >> 12) & 7u) + 1u;
             // only the lanes that need it take part in the gather: every extra quad of lanes costs the
-            // vector L1 a tag lookup even when it reads a dummy address
+            // vector L1 a tag lookup even when it reads a dummy address.  The direct (L2) layout gathers
+            // through a buffer resource: 32-bit offsets, no 64-bit address per lane
             e2[k] = 0;
             uint32_t idx;
             if (DIRECT && PC == 8 && HC == 8) idx = __builtin_amdgcn_perm(e[k], hi[k], 0x0C050402u);   // e << 8 | byte 2 of hi
             else if (DIRECT) idx = (e[k] << H) | __builtin_amdgcn_ubfe(hi[k], 32u - P - H, H);
             else idx = sb[k] + (e[k] & 0xFFFu) + __builtin_amdgcn_ubfe(hi[k], 32u - P - h, h);
-#ifdef MH_EXP_BUF
-            if (in) e2[k] = uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(t.sec_rsrc, int(idx << 1), 0, 0)));
-#else
-            if (in) e2[k] = t.sec[idx];
-#endif
+            if (in) e2[k] = DIRECT ? uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(t.sec_rsrc, int(idx << 1), 0, 0))) : uint32_t(t.sec[idx]);
         }
         // leaves carry bit 15 and lanes without a second level hold 0: the larger one is the entry that
         // resolves the symbol; if both are inner the result has no leaf flag and the code is walked
@@ -1044,12 +1039,8 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecParams p) {
 
     // (a hybrid — tables of the frequent contexts in LDS, the rest in L2 — was measured and did not pay:
     //  some lane still needs L2 in every round, and that latency, not the gather width, is what costs)
-#ifdef MH_EXP_BUF
     const DecTables tabs{SEC_LDS ? lsec : p.sec, p.tree, p.P, p.direct, p.H,
                          __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.sec), 0, int((p.nsec + 8u) * 2u), 0x00020000)};
-#else
-    const DecTables tabs{SEC_LDS ? lsec : p.sec, p.tree, p.P, p.direct, p.H};
-#endif
     const uint32_t S = 1u << p.chunk_shift;
     const uint64_t full_chunks = p.n >> p.chunk_shift;          // chunks with exactly S symbols
     if (REDO) {
