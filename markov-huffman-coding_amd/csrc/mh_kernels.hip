@@ -547,78 +547,101 @@ __global__ __launch_bounds__(E_THREADS) void enc_emit_kernel(EmitParams p) {
     const uint32_t S = 1u << p.chunk_shift;
     const uint64_t wave0 = uint64_t(blockIdx.x) * E_WAVES + wave;
     const uint64_t nwaves = uint64_t(gridDim.x) * E_WAVES;
-    // input runs one sub-step ahead of the work (software pipeline across sub-steps and wave-tiles)
-    LaneIn ahead = load_raw(p.data, p.n, wave0 * E_WT + lane * E_VEC, p.prev0);
-    for (uint64_t wt = wave0; wt < p.nwt; wt += nwaves) {
-        const uint64_t s = p.wt_start[wt];
-        uint64_t gbase = s >> 5;                 // output dword under image word 0
-        uint32_t cur = uint32_t(s & 31u);        // image bit where the next code goes
-        uint64_t abs_bits = s;                   // absolute bit offset of image bit `cur`
-        bool seam0 = cur != 0;                   // word 0 is shared with the previous wave-tile
+    // Software pipeline over the wave's sub-steps i = 0, 1, ... (sub-step i = piece i % 4 of wave-tile
+    // wave0 + (i / 4) * nwaves): while sub-step i is packed, scanned, deposited and flushed, the 16 codeword
+    // lookups of sub-step i + 1 are already in the LDS queue and the inputs of sub-steps i + 2 and i + 3 are
+    // on their way from HBM.  (With the lookups issued at the top of their own sub-step the wave sat through the LDS
+    // round trip three times per sub-step: lookups, tail word, flush reads.)
+    auto offset_of = [&](uint64_t i) -> uint64_t {
+        return (wave0 + (i >> 2) * nwaves) * E_WT + (i & 3u) * E_SUB + lane * E_VEC;
+    };
+    auto lookup16 = [&](const LaneIn &in, uint32_t pb, uint32_t (&e)[16]) {
+        uint32_t w[16];
+        slots16(in.x, pb, w);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) e[j] = uint32_t(tab[w[j]]);
+    };
+    LaneIn cur_in = load_raw(p.data, p.n, offset_of(0), p.prev0);
+    LaneIn next_in = load_raw(p.data, p.n, offset_of(1), p.prev0);
+    LaneIn next2_in = load_raw(p.data, p.n, offset_of(2), p.prev0);
+    uint32_t cur_pb = head_byte(cur_in);
+    uint32_t E[16];
+    lookup16(cur_in, cur_pb, E);
+    uint64_t gbase = 0, abs_bits = 0;
+    uint32_t cur = 0;
+    bool seam0 = false;
 #pragma unroll 1
-        for (int k = 0; k < E_SUBSTEPS; ++k) {
-            const uint64_t off = wt * E_WT + uint64_t(k) * E_SUB + lane * E_VEC;
-            const LaneIn in = ahead;
-            {
-                const uint64_t nwt_ = (k + 1 < E_SUBSTEPS) ? wt : wt + nwaves;
-                const uint64_t noff = nwt_ * E_WT + uint64_t((k + 1) % E_SUBSTEPS) * E_SUB + lane * E_VEC;
-                ahead = load_raw(p.data, p.n, noff, p.prev0);      // past the end: zeros, nothing is read
-            }
-            const uint4 x = in.x;
-            const uint32_t nvalid = in.nvalid;
-            const uint32_t pb = head_byte(in);
-            uint32_t L = 0;
-            uint64_t g[4]; uint32_t gl[4];
-            uint32_t emax = nvalid == E_VEC ? 0u : 0xFFFFu;   // ragged vectors take the symbol-by-symbol path
-            {
-                uint32_t w[16];
-                slots16(x, pb, w);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    uint32_t e[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        e[j] = uint32_t(tab[w[4 * q + j]]);
-                        emax = e[j] > emax ? e[j] : emax;
-                    }
-                    uint32_t l0 = e[0] >> 12, l1 = e[1] >> 12, l2 = e[2] >> 12, l3 = e[3] >> 12;
-                    uint32_t p01 = ((e[0] & 0xFFFu) << l1) | (e[1] & 0xFFFu);
-                    uint32_t p23 = ((e[2] & 0xFFFu) << l3) | (e[3] & 0xFFFu);
-                    g[q] = (uint64_t(p01) << (l2 + l3)) | p23;
-                    gl[q] = l0 + l1 + l2 + l3;
-                    L += gl[q];
-                }
-            }
-            uint32_t sub_bits;
-            if (__any(emax >= 0xD000u)) {        // wave-uniform: an escape code or a ragged vector somewhere
-                emit_substep_slow<1>(p, tab, stage, out32, x, pb, nvalid, lane, off, abs_bits, gbase, cur, seam0, sub_bits);
-            } else {
-                // exclusive wave scan of the lane totals
-                const uint32_t inc = wave_inclusive_sum(L);
-                sub_bits = __builtin_amdgcn_readlane(inc, 63);
-                const uint32_t exc = inc - L;
-                // chunk index: the lane whose first byte starts a chunk records (context, bit offset)
-                if (p.index && nvalid && ((uint32_t(off) & (S - 1u)) == 0u))
-                    p.index[off >> p.chunk_shift] = (uint64_t(pb) << 56) | (abs_bits + exc);
-                uint32_t o = cur + exc;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (gl[q]) deposit<false>(stage, g[q] << (64u - gl[q]), o, 0, 0);
-                    o += gl[q];
-                }
-                const uint32_t nfull = (cur + sub_bits) >> 5;
-                flush_words(stage, out32, gbase, nfull, seam0, lane);
-                seam0 = seam0 && nfull == 0;
-                gbase += nfull;
-                cur = (cur + sub_bits) & 31u;
-            }
-            abs_bits += sub_bits;
+    for (uint64_t i = 0;; ++i) {
+        const uint64_t wt = wave0 + (i >> 2) * nwaves;
+        if (wt >= p.nwt) break;
+        const uint32_t k = uint32_t(i) & 3u;
+        if (k == 0) {
+            const uint64_t s = p.wt_start[wt];
+            gbase = s >> 5;                      // output dword under image word 0
+            cur = uint32_t(s & 31u);             // image bit where the next code goes
+            abs_bits = s;                        // absolute bit offset of image bit `cur`
+            seam0 = cur != 0;                    // word 0 is shared with the previous wave-tile
         }
+        const uint64_t off = wt * E_WT + uint64_t(k) * E_SUB + lane * E_VEC;
+        // the next sub-steps: input three ahead (its first use, the lookups, comes two sub-steps from now), lookups one ahead
+        const LaneIn in3 = load_raw(p.data, p.n, offset_of(i + 3), p.prev0);      // past the end: zeros, nothing is read
+        const uint32_t next_pb = head_byte(next_in);
+        uint32_t En[16];
+        lookup16(next_in, next_pb, En);
+        // ---- this sub-step
+        const uint4 x = cur_in.x;
+        const uint32_t nvalid = cur_in.nvalid;
+        const uint32_t pb = cur_pb;
+        uint32_t L = 0;
+        uint64_t g[4]; uint32_t gl[4];
+        uint32_t emax = nvalid == E_VEC ? 0u : 0xFFFFu;   // ragged vectors take the symbol-by-symbol path
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t e0 = E[4 * q], e1 = E[4 * q + 1], e2 = E[4 * q + 2], e3 = E[4 * q + 3];
+            uint32_t m01 = e0 > e1 ? e0 : e1, m23 = e2 > e3 ? e2 : e3;
+            m01 = m01 > m23 ? m01 : m23;
+            emax = m01 > emax ? m01 : emax;
+            const uint32_t l0 = e0 >> 12, l1 = e1 >> 12, l2 = e2 >> 12, l3 = e3 >> 12;
+            const uint32_t p01 = ((e0 & 0xFFFu) << l1) | (e1 & 0xFFFu);
+            const uint32_t p23 = ((e2 & 0xFFFu) << l3) | (e3 & 0xFFFu);
+            g[q] = (uint64_t(p01) << (l2 + l3)) | p23;
+            gl[q] = l0 + l1 + l2 + l3;
+            L += gl[q];
+        }
+        uint32_t sub_bits;
+        if (__any(emax >= 0xD000u)) {        // wave-uniform: an escape code or a ragged vector somewhere
+            emit_substep_slow<1>(p, tab, stage, out32, x, pb, nvalid, lane, off, abs_bits, gbase, cur, seam0, sub_bits);
+        } else {
+            // exclusive wave scan of the lane totals
+            const uint32_t inc = wave_inclusive_sum(L);
+            sub_bits = __builtin_amdgcn_readlane(inc, 63);
+            const uint32_t exc = inc - L;
+            // chunk index: the lane whose first byte starts a chunk records (context, bit offset)
+            if (p.index && nvalid && ((uint32_t(off) & (S - 1u)) == 0u))
+                p.index[off >> p.chunk_shift] = (uint64_t(pb) << 56) | (abs_bits + exc);
+            uint32_t o = cur + exc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (gl[q]) deposit<false>(stage, g[q] << (64u - gl[q]), o, 0, 0);
+                o += gl[q];
+            }
+            const uint32_t nfull = (cur + sub_bits) >> 5;
+            flush_words(stage, out32, gbase, nfull, seam0, lane);
+            seam0 = seam0 && nfull == 0;
+            gbase += nfull;
+            cur = (cur + sub_bits) & 31u;
+        }
+        abs_bits += sub_bits;
         // last partial dword of the wave-tile: seam with the next wave-tile (or the stream's end)
-        if (cur != 0 && lane == 0) {
+        if (k == 3u && cur != 0 && lane == 0) {
             atomicOr(&out32[gbase], __builtin_bswap32(stage[0]));
             stage[0] = 0;
         }
+        cur_in = next_in; cur_pb = next_pb;
+        next_in = next2_in;
+        next2_in = in3;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) E[j] = En[j];
     }
 }
 
