@@ -184,6 +184,15 @@ class Codec:
     def encode(self, model, data, prev0, start_bit=None):
         """start_bit: device int64 tensor holding this shard's global start bit (the payload is emitted
         pre-shifted by its low 3 bits so that shards concatenate with one OR-merged seam byte), or None."""
+        if self.order == 1 and not os.environ.get("MH_BENCH_TWO_PASS_ENCODE"):
+            # the histogram of this very buffer is in hist_ws: the encoder prices its regions from it (no length pass)
+            self.check(self.lib.mh_dev_encode_hist(model.handle, data.data_ptr(), self.n, prev0,
+                                                   start_bit.data_ptr() if start_bit is not None else None,
+                                                   self.payload.data_ptr(), self.cap,
+                                                   self.nbits.data_ptr(), self.index.data_ptr(), CHUNK,
+                                                   self.hist_ws.data_ptr(), self.hist_ws_bytes,
+                                                   self.enc_ws.data_ptr(), self.enc_ws_bytes, self.stream()), "encode")
+            return
         self.check(self.lib.mh_dev_encode_at(model.handle, data.data_ptr(), self.n, prev0,
                                              start_bit.data_ptr() if start_bit is not None else None,
                                              self.payload.data_ptr(), self.cap,

@@ -223,7 +223,9 @@ int mh_model_payload_bits(const mh_model *m, const uint64_t *counts, uint64_t *n
 
 /* Optional workspace of mh_dev_histogram_o1 (pass NULL, 0 to do without): with it the workgroups'
  * counters leave as plain stores and are summed by a second kernel instead of 16.7 M device-scope
- * atomics, ~0.5 ms less per call. */
+ * atomics, ~0.5 ms less per call.  A workspace of the full size (16-byte aligned) also keeps what
+ * mh_dev_encode_hist needs: every workgroup counts one contiguous region of the input and leaves that
+ * region's own pair counts behind. */
 size_t mh_dev_histogram_workspace(size_t n);
 /* d_counts (65536 or 256 x uint64) is overwritten. */
 int mh_dev_histogram_o1(const uint8_t *d_data, size_t n, uint8_t prev0, uint64_t *d_counts,
@@ -238,6 +240,21 @@ int mh_dev_encode(const mh_model *m, const uint8_t *d_data, size_t n, uint8_t pr
                   uint8_t *d_payload, size_t cap, uint64_t *d_nbits,
                   uint64_t *d_index, uint32_t chunk_symbols,
                   void *d_ws, size_t ws_bytes, void *stream);
+
+/* mh_dev_encode_at for the compress path, where a histogram of the SAME device buffer was taken just before
+ * (src/main.cpp:173-183, then 204-212): d_hist_ws / hist_ws_bytes is the workspace mh_dev_histogram_o1
+ * filled for (d_data, n, prev0), untouched since.  The encoder then prices each of the histogram's regions from
+ * its pair counts and the code lengths and needs no pass of its own over the input to find where everything
+ * goes: the input is read once.  Same payload, index and *d_nbits as mh_dev_encode_at.  Falls back to
+ * mh_dev_encode_at by itself for models with codes over 12 bits, order-2 models, or a workspace that is too
+ * small; a workspace that holds some other buffer's histogram is reported as MH_ERR_CORRUPT by
+ * mh_dev_status(d_ws) and nothing is written. */
+int mh_dev_encode_hist(const mh_model *m, const uint8_t *d_data, size_t n, uint8_t prev0,
+                       const uint64_t *d_start_bit,
+                       uint8_t *d_payload, size_t cap, uint64_t *d_nbits,
+                       uint64_t *d_index, uint32_t chunk_symbols,
+                       const void *d_hist_ws, size_t hist_ws_bytes,
+                       void *d_ws, size_t ws_bytes, void *stream);
 
 /* Sharded encode (contiguous byte ranges, one rank per shard).  A shard's payload length
  * is known before it is encoded: it is the dot product of the shard's LOCAL histogram with the code

@@ -783,7 +783,7 @@ void mh_model_free(mh_model *m) {
 
 /* ------------------------------------------------------------ device calls */
 
-size_t mh_dev_histogram_workspace(size_t) { return have_device() ? mhk::hist_workspace_bytes() : 64; }
+size_t mh_dev_histogram_workspace(size_t n) { return have_device() ? mhk::hist_workspace_bytes(n) : 64; }
 
 int mh_dev_histogram_o1(const uint8_t *d_data, size_t n, uint8_t prev0, uint64_t *d_counts, void *d_ws, size_t ws_bytes, void *stream) {
     if ((!d_data && n) || !d_counts || !aligned16(d_data)) return MH_ERR_ARG;
@@ -840,6 +840,30 @@ static int dev_encode_ctx(const mh_model *m, const uint8_t *d_data, size_t n, ui
     p.index = reinterpret_cast<unsigned long long *>(d_index);
     p.start_bit = reinterpret_cast<const unsigned long long *>(d_start_bit);
     HIP_TRY(mhk::launch_encode(p, d_ws, static_cast<hipStream_t>(stream)));
+    return MH_OK;
+}
+
+int mh_dev_encode_hist(const mh_model *m, const uint8_t *d_data, size_t n, uint8_t prev0, const uint64_t *d_start_bit,
+                       uint8_t *d_payload, size_t cap, uint64_t *d_nbits, uint64_t *d_index, uint32_t chunk_symbols,
+                       const void *d_hist_ws, size_t hist_ws_bytes, void *d_ws, size_t ws_bytes, void *stream) {
+    if (!m || (!d_data && n) || !d_payload || !d_nbits || !d_ws) return MH_ERR_ARG;
+    // escape codes (> 12 bits) and order-2 models take the regular path; so does a caller without the workspace
+    if (m->type == 2 || m->max_len > mh::ENC16_MAX_LEN || !d_hist_ws || hist_ws_bytes < mhk::hist_workspace_bytes(n))
+        return mh_dev_encode_at(m, d_data, n, prev0, d_start_bit, d_payload, cap, d_nbits, d_index, chunk_symbols, d_ws, ws_bytes, stream);
+    if (!aligned16(d_data) || !aligned16(d_payload) || !aligned16(d_ws) || !aligned16(d_hist_ws)) return MH_ERR_ARG;
+    int shift = chunk_shift_of(d_index ? chunk_symbols : MH_CHUNK_DEFAULT);
+    if (shift < 0) return MH_ERR_ARG;
+    if (ws_bytes < mhk::encode_workspace_bytes(n)) return MH_ERR_CAPACITY;
+    if (!m->d_enc16) return MH_ERR_NO_DEVICE;
+    mhk::EncodeArgs p{};
+    p.order = 1;
+    p.data = d_data; p.n = n; p.prev0 = prev0; p.chunk_shift = uint32_t(shift);
+    p.out = d_payload; p.cap = cap;
+    p.enc16 = m->d_enc16; p.len_slot = m->d_len_slot; p.len8 = m->d_len8; p.code64 = m->d_code64;
+    p.nbits = reinterpret_cast<unsigned long long *>(d_nbits);
+    p.index = reinterpret_cast<unsigned long long *>(d_index);
+    p.start_bit = reinterpret_cast<const unsigned long long *>(d_start_bit);
+    HIP_TRY(mhk::launch_encode_regions(p, d_hist_ws, hist_ws_bytes, d_ws, static_cast<hipStream_t>(stream)));
     return MH_OK;
 }
 

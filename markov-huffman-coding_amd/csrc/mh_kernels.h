@@ -136,13 +136,14 @@ struct TreePackArgs {
 hipError_t launch_tree_build(const unsigned long long *d_counts, int nctx, const TreeBuildOut &o, hipStream_t st);
 hipError_t launch_tree_pack(const TreePackArgs &a, int nctx, hipStream_t st);
 
-size_t hist_workspace_bytes();
+size_t hist_workspace_bytes(uint64_t n);
 hipError_t launch_hist_o1(const uint8_t *d_data, uint64_t n, uint32_t prev0, unsigned long long *d_counts, void *d_ws, size_t ws_bytes,
                           hipStream_t st);
 hipError_t launch_hist_o0(const uint8_t *d_data, uint64_t n, unsigned long long *d_counts, hipStream_t st);
 hipError_t launch_hist_o2(const uint8_t *d_data, uint64_t n, uint32_t ctx0, unsigned long long *d_counts, hipStream_t st);
 size_t encode_workspace_bytes(uint64_t n);
 hipError_t launch_encode(const EncodeArgs &a, void *d_ws, hipStream_t st);
+hipError_t launch_encode_regions(const EncodeArgs &a, const void *d_hist_ws, size_t hist_ws_bytes, void *d_ws, hipStream_t st);
 hipError_t launch_payload_bits(const unsigned long long *d_counts, const uint8_t *d_len8, uint32_t entries, unsigned long long *d_out,
                                hipStream_t st);
 hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st);

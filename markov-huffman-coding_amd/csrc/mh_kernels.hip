@@ -87,31 +87,48 @@ constexpr int HIST_LDS_BYTES = 32768 * 4;
 __device__ __forceinline__ uint32_t hist_slot(uint32_t prev, uint32_t sym) { return (sym << 8) | (prev ^ sym); }
 __device__ __forceinline__ uint32_t hist_slot_prev(uint32_t slot) { return (slot & 255u) ^ (slot >> 8); }
 
-__device__ __forceinline__ void hist_fixup(uint32_t *h, unsigned long long *counts, uint32_t slot) {
+// cross (region mode): the workgroup's list of crossings, [0] = count, then the slots — with the slab it gives
+// the workgroup's own exact pair counts (field + 16384 per listed crossing), which is what lets the encoder
+// price its region without a length pass (enc_region_kernel)
+__device__ __forceinline__ void hist_fixup(uint32_t *h, unsigned long long *counts, uint32_t slot, uint32_t *cross, uint32_t cross_cap) {
     atomicSub(&h[slot & 0x7FFFu], (slot >> 15) ? 0x40000000u : 0x4000u);
     atomicAdd(&counts[hist_slot_prev(slot) * 256u + (slot >> 8)], 16384ull);
+    if (cross) {
+        const uint32_t i = atomicAdd(&cross[0], 1u);
+        if (i < cross_cap) cross[1u + i] = slot;
+    }
 }
 
-__device__ __forceinline__ void hist_add(uint32_t *h, unsigned long long *counts, uint32_t prev, uint32_t sym) {
+__device__ __forceinline__ void hist_add(uint32_t *h, unsigned long long *counts, uint32_t prev, uint32_t sym, uint32_t *cross,
+                                         uint32_t cross_cap) {
     const uint32_t slot = hist_slot(prev, sym);
     const uint32_t inc = (slot >> 15) ? 0x10000u : 1u;
     const uint32_t old = atomicAdd(&h[slot & 0x7FFFu], inc);
-    if (((old + inc) ^ old) & 0xC000C000u) hist_fixup(h, counts, slot);
+    if (((old + inc) ^ old) & 0xC000C000u) hist_fixup(h, counts, slot, cross, cross_cap);
 }
 
 // slab: when not null, every workgroup stores its 32768 LDS words there (plain coalesced stores) and
 // hist_reduce_kernel sums the slabs afterwards; 16.7 M device-scope 64-bit atomics on the same 512 KiB
 // of counters (256 workgroups x 65536) cost ~0.55 ms per call whatever the input size.
+// region_vecs != 0 (region mode, needs the slab): workgroup w counts the CONTIGUOUS vectors
+// [w * region_vecs, (w + 1) * region_vecs) instead of a grid-strided share, and lists its crossings in
+// cross_all + w * (cross_cap + 1).
 __global__ __launch_bounds__(HIST_THREADS) void hist_o1_kernel(const uint8_t *__restrict__ data, uint64_t n,
-                                                              uint32_t prev0, unsigned long long *counts, uint32_t *slab) {
+                                                              uint32_t prev0, unsigned long long *counts, uint32_t *slab,
+                                                              uint64_t region_vecs, uint32_t *cross_all, uint32_t cross_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *h = reinterpret_cast<uint32_t *>(smem);
     for (int i = threadIdx.x; i < 32768 / 4; i += HIST_THREADS) reinterpret_cast<uint4 *>(h)[i] = make_uint4(0, 0, 0, 0);
+    uint32_t *cross = cross_all ? cross_all + size_t(blockIdx.x) * (cross_cap + 1u) : nullptr;
+    if (cross && threadIdx.x == 0) cross[0] = 0;
     __syncthreads();
 
     const uint64_t nvec = n >> 4;  // whole 16-byte vectors
     const uint4 *vdata = reinterpret_cast<const uint4 *>(data);
-    for (uint64_t v = uint64_t(blockIdx.x) * HIST_THREADS + threadIdx.x; v < nvec; v += uint64_t(gridDim.x) * HIST_THREADS) {
+    const uint64_t v_begin = region_vecs ? uint64_t(blockIdx.x) * region_vecs + threadIdx.x : uint64_t(blockIdx.x) * HIST_THREADS + threadIdx.x;
+    const uint64_t v_end = region_vecs ? ((blockIdx.x + 1ull) * region_vecs < nvec ? (blockIdx.x + 1ull) * region_vecs : nvec) : nvec;
+    const uint64_t v_step = region_vecs ? uint64_t(HIST_THREADS) : uint64_t(gridDim.x) * HIST_THREADS;
+    for (uint64_t v = v_begin; v < v_end; v += v_step) {
         const uint4 x4 = vdata[v];
         uint32_t pb = v ? uint32_t(data[v * 16 - 1]) : prev0;
         const uint32_t x[4] = {x4.x, x4.y, x4.z, x4.w};
@@ -140,16 +157,17 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_o1_kernel(const uint8_t *__
         if (newly & 0xC000C000u) {                               // some add of this lane crossed a multiple of 0x4000
 #pragma unroll
             for (int i = 0; i < 16; ++i)
-                if (((old[i] + inc[i]) ^ old[i]) & 0xC000C000u) hist_fixup(h, counts, slot[i]);
+                if (((old[i] + inc[i]) ^ old[i]) & 0xC000C000u) hist_fixup(h, counts, slot[i], cross, cross_cap);
         }
     }
-    // ragged tail (< 16 bytes): one lane of block 0
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // ragged tail (< 16 bytes): one lane of block 0 — in region mode of the workgroup whose region holds that vector
+    const uint32_t tail_block = region_vecs ? uint32_t(nvec / region_vecs) : 0u;
+    if (blockIdx.x == tail_block && threadIdx.x == 0) {
         uint64_t i = nvec << 4;
         uint32_t prev = i ? uint32_t(data[i - 1]) : prev0;
         for (; i < n; ++i) {
             uint32_t c = data[i];
-            hist_add(h, counts, prev, c);
+            hist_add(h, counts, prev, c, cross, cross_cap);
             prev = c;
         }
     }
@@ -643,6 +661,202 @@ __global__ __launch_bounds__(E_THREADS) void enc_emit_kernel(EmitParams p) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) E[j] = En[j];
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// encode without a length pass (after a region-mode histogram of the same data)
+// ------------------------------------------------------------------------------------------------
+// The compress path takes a histogram anyway.  When hist_o1_kernel ran in region mode, every workgroup's slab
+// plus its crossing list ARE the exact pair counts of its contiguous region, so the region's payload length is
+// a dot product with the code lengths (region_bits_kernel), and an exclusive scan over the <= 256 regions gives
+// every region its absolute start bit (region_scan_kernel).  enc_region_kernel then gives each workgroup the
+// same region: it walks it in rounds of 16 KiB (one 1 KiB piece per wave), and inside a round the waves only
+// need each other's bit counts — one LDS exchange — because all 16 deposit into ONE image shared by the
+// workgroup (LDS atomics merge the seams between waves exactly as they merge them between lanes), which the
+// whole workgroup then flushes with coalesced stores.  No second read of the input, no per-tile offsets in
+// HBM: traffic is the algorithmic (1 + r) n.  Three workgroup barriers per round are the price.
+// Only for models without escape codes (max length <= 12); others take the three-kernel path.
+constexpr int R_IMG_WORDS = E_WAVES * (E_STAGE_BITS / 32) + 16;          // 16 pieces of <= 12288 bits + carry + slack
+constexpr int REGION_LDS_BYTES = 131072 + R_IMG_WORDS * 4 + 64;
+constexpr uint64_t HIST_WS_MAGIC = 0x4D48525247303031ull;                 // "MHRRG001"
+
+struct HistHeader { unsigned long long magic, n, data, region_vecs; uint32_t grid, prev0, cross_cap, pad; };
+
+__global__ void hist_header_kernel(HistHeader *hdr, HistHeader v) { *hdr = v; }
+
+// one workgroup per region: bits = sum over pairs of (slab field + 16384 x crossings) x code length
+__global__ __launch_bounds__(1024) void region_bits_kernel(const HistHeader *hdr, HistHeader expect, const uint32_t *slab,
+                                                           const uint32_t *cross_all, const uint8_t *len8,
+                                                           unsigned long long *region_bits, int *status) {
+    __shared__ unsigned long long part[16];
+    const uint32_t w = blockIdx.x, tid = threadIdx.x;
+    if (hdr->magic != HIST_WS_MAGIC || hdr->n != expect.n || hdr->data != expect.data || hdr->region_vecs != expect.region_vecs ||
+        hdr->grid != expect.grid || hdr->prev0 != expect.prev0 || hdr->cross_cap != expect.cross_cap) {
+        if (tid == 0) { atomicExch(status, MHK_STATUS_CORRUPT); region_bits[w] = 0; }   // not the histogram of this input
+        return;
+    }
+    unsigned long long acc = 0;
+    const uint32_t *sl = slab + size_t(w) * 32768u;
+    for (uint32_t i = tid; i < 32768u; i += 1024u) {
+        const uint32_t v = sl[i];
+        const uint32_t s0 = i, s1 = i | 0x8000u;
+        acc += (unsigned long long)(v & 0xFFFFu) * len8[hist_slot_prev(s0) * 256u + (s0 >> 8)];
+        acc += (unsigned long long)(v >> 16) * len8[hist_slot_prev(s1) * 256u + (s1 >> 8)];
+    }
+    const uint32_t *cross = cross_all + size_t(w) * (expect.cross_cap + 1u);
+    const uint32_t nc = cross[0];
+    if (nc > expect.cross_cap && tid == 0) atomicExch(status, MHK_STATUS_CAPACITY);
+    for (uint32_t i = tid; i < (nc < expect.cross_cap ? nc : expect.cross_cap); i += 1024u) {
+        const uint32_t sl2 = cross[1u + i];
+        acc += 16384ull * len8[hist_slot_prev(sl2) * 256u + (sl2 >> 8)];
+    }
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+    if ((tid & 63u) == 0) part[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long t = 0;
+        for (int i = 0; i < 16; ++i) t += part[i];
+        region_bits[w] = t;
+    }
+}
+
+// one block: exclusive scan of the region lengths (<= 1024 regions); total, capacity check, and the dwords that
+// two regions share (or that end the stream) are zeroed: they are completed with atomic ORs
+__global__ __launch_bounds__(SCAN_THREADS) void region_scan_kernel(const unsigned long long *region_bits, uint32_t nregion,
+                                                                   unsigned long long *region_start, const unsigned long long *carry0,
+                                                                   uint8_t *out, uint64_t cap, unsigned long long *nbits, int *status) {
+    __shared__ uint64_t lds[SCAN_THREADS / 64];
+    const uint64_t c0 = carry0 ? (*carry0 & 7ull) : 0;
+    const uint32_t i = threadIdx.x;
+    const uint64_t v = i < nregion ? region_bits[i] : 0;
+    uint64_t total;
+    const uint64_t ex = block_excl_scan(v, lds, total);
+    const uint64_t s = c0 + ex;
+    if (i < nregion) {
+        region_start[i] = s;
+        if (i > 0 && (s & 31u) && ((s >> 5) + 1) * 4 <= cap) reinterpret_cast<uint32_t *>(out)[s >> 5] = 0;
+    }
+    if (i == 0) {
+        const uint64_t end = c0 + total;
+        *nbits = end;
+        if (end > cap * 8) atomicExch(status, MHK_STATUS_CAPACITY);
+        const uint64_t endw = end >> 5;
+        if ((end & 31u) && (endw + 1) * 4 <= cap) reinterpret_cast<uint32_t *>(out)[endw] = 0;
+        else if (end & 31u) for (uint64_t b = endw * 4; b < cap; ++b) out[b] = 0;
+        if ((c0 & 31u) && 4 <= cap) reinterpret_cast<uint32_t *>(out)[0] = 0;      // the shard's own first dword (pre-shift)
+    }
+}
+
+struct RegionParams {
+    const unsigned long long *region_start;
+    uint64_t region_vecs;         // vectors (16 bytes) per region, a multiple of 1024
+    uint64_t nvec_up;             // ceil(n / 16)
+};
+
+__global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, RegionParams rp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t *tab = reinterpret_cast<uint16_t *>(smem);
+    uint32_t *img = reinterpret_cast<uint32_t *>(smem + 131072);
+    uint32_t *sb = img + R_IMG_WORDS;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (int i = tid; i < 8192; i += E_THREADS)
+        reinterpret_cast<uint4 *>(tab)[i] = reinterpret_cast<const uint4 *>(p.enc16)[i];
+    for (int i = tid; i < R_IMG_WORDS; i += E_THREADS) img[i] = 0;
+    __syncthreads();
+    if (*p.status != MHK_STATUS_OK) return;     // capacity overrun or a foreign histogram: write nothing
+
+    const uint64_t v0 = uint64_t(blockIdx.x) * rp.region_vecs;
+    const uint64_t v1 = v0 + rp.region_vecs < rp.nvec_up ? v0 + rp.region_vecs : rp.nvec_up;
+    if (v0 >= v1) return;                        // empty region (uniform for the workgroup)
+    uint32_t *out32 = reinterpret_cast<uint32_t *>(p.out);
+    const uint32_t S = 1u << p.chunk_shift;
+    const uint64_t rounds = (v1 - v0 + E_THREADS - 1) / E_THREADS;
+    const uint64_t s0 = rp.region_start[blockIdx.x];
+    uint64_t gbase = s0 >> 5, abs_round = s0;
+    uint32_t cur = uint32_t(s0 & 31u);
+    bool seam_first = cur != 0;                  // the region's first dword is shared with its predecessor
+
+    auto fetch = [&](uint64_t r) -> LaneIn {
+        const uint64_t v = v0 + r * E_THREADS + tid;
+        LaneIn in = load_raw(p.data, p.n, v < v1 ? v * E_VEC : ~0ull >> 1, p.prev0);   // beyond the region: nothing
+        return in;
+    };
+    auto lookup16 = [&](const LaneIn &in, uint32_t pb, uint32_t (&e)[16]) {
+        uint32_t w[16];
+        slots16(in.x, pb, w);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) e[j] = uint32_t(tab[w[j]]);
+    };
+    LaneIn cur_in = fetch(0), next_in = fetch(1), next2_in = fetch(2);
+    uint32_t cur_pb = head_byte(cur_in);
+    uint32_t E[16];
+    lookup16(cur_in, cur_pb, E);
+#pragma unroll 1
+    for (uint64_t r = 0; r < rounds; ++r) {
+        const LaneIn in3 = fetch(r + 3);
+        const uint32_t next_pb = head_byte(next_in);
+        uint32_t En[16];
+        lookup16(next_in, next_pb, En);
+        const uint32_t nvalid = cur_in.nvalid;
+        if (nvalid != E_VEC) {                   // the stream's ragged last vector, or lanes past the region's end
+#pragma unroll
+            for (int j = 0; j < 16; ++j) E[j] = uint32_t(j) < nvalid ? E[j] : 0u;
+        }
+        uint32_t L = 0;
+        uint64_t g[4]; uint32_t gl[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t e0 = E[4 * q], e1 = E[4 * q + 1], e2 = E[4 * q + 2], e3 = E[4 * q + 3];
+            const uint32_t l0 = e0 >> 12, l1 = e1 >> 12, l2 = e2 >> 12, l3 = e3 >> 12;
+            const uint32_t p01 = ((e0 & 0xFFFu) << l1) | (e1 & 0xFFFu);
+            const uint32_t p23 = ((e2 & 0xFFFu) << l3) | (e3 & 0xFFFu);
+            g[q] = (uint64_t(p01) << (l2 + l3)) | p23;
+            gl[q] = l0 + l1 + l2 + l3;
+            L += gl[q];
+        }
+        const uint32_t inc = wave_inclusive_sum(L);
+        if (lane == 63) sb[wave] = inc;          // the piece's bit count
+        __syncthreads();
+        uint32_t pre = 0, tot = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < uint32_t(E_WAVES); ++u) {
+            const uint32_t t = sb[u];
+            pre += u < wave ? t : 0u;
+            tot += t;
+        }
+        const uint32_t exc = pre + inc - L;      // bits of the round in front of this lane
+        const uint64_t off = (v0 + r * E_THREADS + tid) * E_VEC;
+        if (p.index && nvalid && ((uint32_t(off) & (S - 1u)) == 0u))
+            p.index[off >> p.chunk_shift] = (uint64_t(cur_pb) << 56) | (abs_round + exc);
+        uint32_t o = cur + exc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (gl[q]) deposit<false>(img, g[q] << (64u - gl[q]), o, 0, 0);
+            o += gl[q];
+        }
+        __syncthreads();
+        // the workgroup flushes the image: full words out (coalesced), the partial last word becomes word 0
+        const uint32_t nfull = (cur + tot) >> 5;
+        for (uint32_t j = tid; j < nfull; j += E_THREADS) {
+            const uint32_t v = __builtin_bswap32(img[j]);
+            img[j] = 0;
+            if (j == 0 && seam_first) atomicOr(&out32[gbase], v);
+            else out32[gbase + j] = v;
+        }
+        if (tid == 0 && nfull > 0) { const uint32_t t = img[nfull]; img[nfull] = 0; img[0] = t; }
+        __syncthreads();
+        seam_first = seam_first && nfull == 0;
+        gbase += nfull;
+        cur = (cur + tot) & 31u;
+        abs_round += tot;
+        cur_in = next_in; cur_pb = next_pb;
+        next_in = next2_in;
+        next2_in = in3;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) E[j] = En[j];
+    }
+    // the region's last partial dword: shared with the next region (or the stream's end), zeroed by the scan
+    if (cur != 0 && tid == 0) atomicOr(&out32[gbase], __builtin_bswap32(img[0]));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1544,7 +1758,7 @@ __global__ __launch_bounds__(256) void decode2_kernel(DecParams p) {
 constexpr int MAX_DEVICES = 64;
 struct DeviceState {
     int cu_count = 0;
-    bool hist_ready = false, hist2_ready = false, encode_ready = false, decode_ready = false;
+    bool hist_ready = false, hist2_ready = false, encode_ready = false, region_ready = false, decode_ready = false;
 };
 static DeviceState g_dev[MAX_DEVICES];
 static std::mutex g_dev_mu;
@@ -1580,21 +1794,63 @@ static hipError_t once_per_device(bool DeviceState::*flag, F setup) {
     return e;
 }
 
-size_t hist_workspace_bytes() { return size_t(cu_count()) * 32768u * 4u; }
+// Region mode of the order-1 histogram (and of the encoder that follows it): the input's 16-byte vectors are
+// split into `grid` contiguous regions of region_vecs vectors (a multiple of 1024 = one encoder round).
+// Workspace: [0,256) header | slabs grid x 32768 u32 | crossing lists grid x (1 + cross_cap) u32.
+struct RegionGeom { int grid; uint64_t region_vecs, nvec_up; uint32_t cross_cap; size_t off_slab, off_cross, total; };
+static RegionGeom region_geom(uint64_t n) {
+    RegionGeom g;
+    g.nvec_up = (n + 15) >> 4;
+    const uint64_t want = (g.nvec_up + HIST_THREADS - 1) / HIST_THREADS;
+    const uint64_t cus = uint64_t(cu_count());
+    g.grid = int(want < 1 ? 1 : (want > cus ? cus : want));
+    const uint64_t per = (g.nvec_up + uint64_t(g.grid) - 1) / uint64_t(g.grid);
+    g.region_vecs = ((per + HIST_THREADS - 1) / HIST_THREADS) * HIST_THREADS;
+    if (g.region_vecs == 0) g.region_vecs = HIST_THREADS;
+    g.cross_cap = uint32_t(g.region_vecs * 16 / 16384) + 16u;       // a crossing takes 16384 adds of the workgroup
+    g.off_slab = 256;
+    g.off_cross = g.off_slab + size_t(g.grid) * 32768u * 4u;
+    g.total = (g.off_cross + size_t(g.grid) * (g.cross_cap + 1u) * 4u + 255) & ~size_t(255);
+    return g;
+}
+size_t hist_workspace_bytes(uint64_t n) { return region_geom(n).total; }
 
 hipError_t launch_hist_o1(const uint8_t *d_data, uint64_t n, uint32_t prev0, unsigned long long *d_counts, void *d_ws, size_t ws_bytes,
                           hipStream_t st) {
     hipError_t e = hipMemsetAsync(d_counts, 0, 65536 * sizeof(unsigned long long), st);
-    if (e != hipSuccess || n == 0) return e;
+    if (e != hipSuccess) return e;
+    unsigned char *ws = static_cast<unsigned char *>(d_ws);
+    const bool ws_ok = d_ws && (reinterpret_cast<uintptr_t>(d_ws) & 15u) == 0;
+    const RegionGeom g = region_geom(n);
+    const bool regions = ws_ok && ws_bytes >= g.total;
+    if (regions) {      // the header says whose histogram the workspace holds (the region encoder checks it)
+        HistHeader h{HIST_WS_MAGIC, n, reinterpret_cast<unsigned long long>(d_data), g.region_vecs, uint32_t(g.grid), prev0, g.cross_cap, 0};
+        hipLaunchKernelGGL(hist_header_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<HistHeader *>(ws), h);
+    } else if (ws_ok && ws_bytes >= 256) {
+        e = hipMemsetAsync(ws, 0, 64, st);                      // no longer the histogram of anything
+        if (e != hipSuccess) return e;
+    }
+    if (n == 0) {
+        if (regions) { e = hipMemsetAsync(ws + g.off_cross, 0, size_t(g.grid) * (g.cross_cap + 1u) * 4u, st); if (e != hipSuccess) return e;
+                       e = hipMemsetAsync(ws + g.off_slab, 0, size_t(g.grid) * 32768u * 4u, st); }
+        return e;
+    }
     e = once_per_device(&DeviceState::hist_ready, [] { return allow_lds(reinterpret_cast<const void *>(hist_o1_kernel), HIST_LDS_BYTES); });
     if (e != hipSuccess) return e;
+    if (regions) {
+        uint32_t *slab = reinterpret_cast<uint32_t *>(ws + g.off_slab);
+        hipLaunchKernelGGL(hist_o1_kernel, dim3(g.grid), dim3(HIST_THREADS), HIST_LDS_BYTES, st, d_data, n, prev0, d_counts, slab,
+                           g.region_vecs, reinterpret_cast<uint32_t *>(ws + g.off_cross), g.cross_cap);
+        hipLaunchKernelGGL(hist_reduce_kernel, dim3(32768 / 256), dim3(256), 0, st, slab, uint32_t(g.grid), d_counts);
+        return hipGetLastError();
+    }
     uint64_t nvec = n >> 4;
     uint64_t want = (nvec + HIST_THREADS - 1) / HIST_THREADS;
     int grid = int(want < 1 ? 1 : (want > uint64_t(cu_count()) ? uint64_t(cu_count()) : want));
-    // with a workspace the workgroups' counters go out as plain stores and are summed by a second kernel
-    uint32_t *slab = (d_ws && ws_bytes >= size_t(grid) * 32768u * 4u && (reinterpret_cast<uintptr_t>(d_ws) & 15u) == 0)
-                         ? static_cast<uint32_t *>(d_ws) : nullptr;
-    hipLaunchKernelGGL(hist_o1_kernel, dim3(grid), dim3(HIST_THREADS), HIST_LDS_BYTES, st, d_data, n, prev0, d_counts, slab);
+    // with a (smaller) workspace the workgroups' counters go out as plain stores and are summed by a second kernel
+    uint32_t *slab = (ws_ok && ws_bytes >= 256 + size_t(grid) * 32768u * 4u) ? reinterpret_cast<uint32_t *>(ws + 256) : nullptr;
+    hipLaunchKernelGGL(hist_o1_kernel, dim3(grid), dim3(HIST_THREADS), HIST_LDS_BYTES, st, d_data, n, prev0, d_counts, slab,
+                       uint64_t(0), static_cast<uint32_t *>(nullptr), 0u);
     if (slab) hipLaunchKernelGGL(hist_reduce_kernel, dim3(32768 / 256), dim3(256), 0, st, slab, uint32_t(grid), d_counts);
     return hipGetLastError();
 }
@@ -1634,6 +1890,7 @@ static EncWs enc_ws_layout(uint64_t n) {
     w.off_start = up(w.off_bits + size_t(w.nwt) * 4);
     w.off_blk = up(w.off_start + size_t(w.nwt) * 8);
     w.total = up(w.off_blk + size_t(w.nblk + 1) * 8);
+    if (w.total < 64 + 2 * 1024 * 8) w.total = 64 + 2 * 1024 * 8;      // the region path keeps <= 1024 lengths and starts here
     return w;
 }
 size_t encode_workspace_bytes(uint64_t n) { return enc_ws_layout(n).total; }
@@ -1711,6 +1968,38 @@ hipError_t launch_encode(const EncodeArgs &a, void *d_ws, hipStream_t st) {
     }
     grid = int(want > uint64_t(cu_count()) ? uint64_t(cu_count()) : want);
     hipLaunchKernelGGL(enc_emit_kernel, dim3(grid), dim3(E_THREADS), EMIT_LDS_BYTES, st, ep);
+    return hipGetLastError();
+}
+
+// Encode after a region-mode histogram of the same input (d_hist_ws as launch_hist_o1 left it): no length pass.
+// Order 1/0 models without escape codes only (the caller checks); hipErrorInvalidValue when the workspace
+// cannot be a region histogram of n bytes.  A workspace that holds another input's histogram is caught on
+// the device (status MHK_STATUS_CORRUPT, nothing written).
+hipError_t launch_encode_regions(const EncodeArgs &a, const void *d_hist_ws, size_t hist_ws_bytes, void *d_ws, hipStream_t st) {
+    unsigned char *ws = static_cast<unsigned char *>(d_ws);
+    int *status = reinterpret_cast<int *>(ws);
+    hipError_t e = hipMemsetAsync(ws, 0, 64, st);
+    if (e != hipSuccess) return e;
+    if (a.n == 0) {
+        hipLaunchKernelGGL(empty_payload_kernel, dim3(1), dim3(1), 0, st, a.start_bit, a.nbits, a.out, a.cap);
+        return hipGetLastError();
+    }
+    const RegionGeom g = region_geom(a.n);
+    if (!d_hist_ws || hist_ws_bytes < g.total || g.grid > 1024) return hipErrorInvalidValue;
+    e = once_per_device(&DeviceState::region_ready, [] { return allow_lds(reinterpret_cast<const void *>(enc_region_kernel), REGION_LDS_BYTES); });
+    if (e != hipSuccess) return e;
+    const unsigned char *hws = static_cast<const unsigned char *>(d_hist_ws);
+    unsigned long long *region_bits = reinterpret_cast<unsigned long long *>(ws + 64);
+    unsigned long long *region_start = region_bits + 1024;
+    const HistHeader expect{HIST_WS_MAGIC, a.n, reinterpret_cast<unsigned long long>(a.data), g.region_vecs, uint32_t(g.grid), a.prev0, g.cross_cap, 0};
+    hipLaunchKernelGGL(region_bits_kernel, dim3(g.grid), dim3(1024), 0, st, reinterpret_cast<const HistHeader *>(hws), expect,
+                       reinterpret_cast<const uint32_t *>(hws + g.off_slab), reinterpret_cast<const uint32_t *>(hws + g.off_cross), a.len8,
+                       region_bits, status);
+    hipLaunchKernelGGL(region_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, region_bits, uint32_t(g.grid), region_start, a.start_bit,
+                       a.out, a.cap & ~uint64_t(3), a.nbits, status);
+    EmitParams ep{a.data, a.n, a.prev0, a.chunk_shift, a.out, a.enc16, a.len8, a.code64, nullptr, 0, a.index, status};
+    RegionParams rp{region_start, g.region_vecs, g.nvec_up};
+    hipLaunchKernelGGL(enc_region_kernel, dim3(g.grid), dim3(E_THREADS), REGION_LDS_BYTES, st, ep, rp);
     return hipGetLastError();
 }
 
