@@ -128,7 +128,8 @@ def test_encode_hist_rejects_a_foreign_workspace(mhc):
     hws = int(lib.mh_dev_histogram_workspace(n))
     d_hws = mhc.DeviceBuffer(hws)
     mhc._check(lib.mh_dev_histogram_o1(d_a.ptr, n, 0x20, d_counts.ptr, d_hws.ptr, hws, None), "hist")
-    m = mhc.Model.from_counts(d_counts.download(np.uint64) + np.uint64(1), 1)
+    m = mhc.Model.from_counts(np.full(65536, 7, dtype=np.uint64), 1)      # every pair has an 8-bit code: no escape, no fallback
+    assert m.max_code_len == 8
     cap = lib.mh_encode_bound(m.handle, n) + 64
     d_payload = mhc.DeviceBuffer(cap)
     d_nbits = mhc.DeviceBuffer(8)
