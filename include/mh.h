@@ -205,6 +205,11 @@ int mh_decode(const mh_model *m, const uint8_t *payload, uint64_t nbits, uint8_t
               uint8_t *out, size_t cap, size_t *nbytes,
               const uint64_t *index, uint32_t chunk_symbols, uint64_t n_symbols);
 
+/* Device footprint of the host-buffer calls: bounded by the segment size (256 MiB, MH_SEGMENT_BYTES) for
+ * mh_histogram_*, mh_encode and mh_decode WITH an index.  mh_decode / mh_decode_to WITHOUT an index are the
+ * exception: the whole payload is uploaded, an index of nbits / chunk_symbols + 2 entries is rebuilt beside it,
+ * and the index builder's workspace takes about 28 bytes per 512 bytes of payload — roughly 1.1 x the payload
+ * in total, plus one output segment. */
 /* mh_decode for callers that cannot know the output size beforehand (a stream without an index):
  * get_out(ctx, n) is called exactly once, when the symbol count n is known, and returns where the n
  * bytes go (NULL -> MH_ERR_CAPACITY).  The CLI maps its output file there. */

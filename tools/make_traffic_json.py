@@ -29,8 +29,10 @@ for name, (r, w) in sorted(agg.items()):
     out["%s:%d" % (name, size)] = int(r + w)
     out["%s:%d:read" % (name, size)] = int(r)
     out["%s:%d:write" % (name, size)] = int(w)
-if "enc_len_kernel:%d" % size in out:
-    out["encode_kernel:%d" % size] = sum(out.get("%s:%d" % (k, size), 0) for k in
-                                         ("enc_len_kernel", "enc_emit_kernel", "scan_local_kernel", "scan_top_kernel", "scan_apply_kernel"))
+# the encode stage = every kernel of whichever encoder ran (region path, or length pass + scans + emit)
+enc = ("enc_region_kernel", "region_bits_kernel", "region_scan_kernel",
+       "enc_len_kernel", "enc_emit_kernel", "scan_local_kernel", "scan_top_kernel", "scan_apply_kernel")
+if any("%s:%d" % (k, size) in out for k in enc):
+    out["encode_kernel:%d" % size] = sum(out.get("%s:%d" % (k, size), 0) for k in enc)
 json.dump(out, sys.stdout, indent=1)
 print()
