@@ -2028,8 +2028,6 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
                                    decode_kernel<false, 2, true, 4, 8, 2, 8, 4>, decode_kernel<false, 2, true, 4, 8, 2, 8, 0>,
                                    decode_kernel<false, 2, true, 4, 8, 2, 8, 0>, decode_kernel<false, 2, true, 4, 8, 2, 8, 0>,
                                    decode_kernel<false, 2, true, 4, 8, 2, 8, 8>};
-    // A/B (MH_DEC_VARIANT=1): 64-byte granules on the two-deep FIFO (half the read amplification, 218 VGPRs)
-    auto x_g16 = decode_kernel<false, 2, true, 4, 16, 2, 8, 3, false, 512, 1>;
     // redo pass (one lane per handed-over chunk, runtime table widths)
     auto r_lds = decode_kernel<true, 2, false, 1, 8, 1, 0, 0, true>;
     auto r_l2 = decode_kernel<false, 2, false, 1, 8, 1, 0, 0, true>;
@@ -2038,7 +2036,7 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
         const void *all[] = {(const void *)k_lds2_light[0], (const void *)k_lds2_light[1],
                              (const void *)k_lds4, (const void *)k_lds4_light, (const void *)k_l2, (const void *)k_l2d[0], (const void *)k_l2d[2],
                              (const void *)k_l2d[3], (const void *)k_l2d[4], (const void *)k_l2d[8],
-                             (const void *)r_lds, (const void *)r_l2, (const void *)r_l2d, (const void *)x_g16};
+                             (const void *)r_lds, (const void *)r_l2, (const void *)r_l2d};
         for (const void *f : all) {
             hipError_t r = allow_lds(f, DEC_LDS_MAX);
             if (r != hipSuccess) return r;
@@ -2062,7 +2060,6 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
     const int p8 = p.P == 8;
     if (wide) hipLaunchKernelGGL(k_lds4, dim3(grid), dim3(DEC_THREADS), lds, st, p);
     else if (p.sec_lds) hipLaunchKernelGGL(short_codes ? k_lds4_light : k_lds2_light[p8], dim3(grid), dim3(DEC_THREADS), lds, st, p);
-    else if (p.direct && p.H == 3 && getenv("MH_DEC_VARIANT")) hipLaunchKernelGGL(x_g16, dim3(grid), dim3(DEC_THREADS), lds, st, p);
     else if (p.direct) hipLaunchKernelGGL(k_l2d[p.H <= 8 ? p.H : 0], dim3(grid), dim3(DEC_THREADS), lds, st, p);
     else hipLaunchKernelGGL(k_l2, dim3(grid), dim3(DEC_THREADS), lds, st, p);
     e = hipGetLastError();
