@@ -165,7 +165,7 @@ class Codec:
 
     def histogram(self, data, prev0, n=None):
         if self.order == 2:         # extension (parity unpinned): 65536 two-byte contexts, counts in HBM
-            self.check(self.lib.mh_dev_histogram_o2(data.data_ptr(), self.n if n is None else n, prev0 << 8 | prev0,
+            self.check(self.lib.mh_dev_histogram_o2(data.data_ptr(), self.n if n is None else n, prev0,     # prev0: 16-bit context
                                                     self.counts.data_ptr(), self.stream()), "hist2")
             return
         self.check(self.lib.mh_dev_histogram_o1(data.data_ptr(), self.n if n is None else n, prev0, self.counts.data_ptr(),
@@ -193,11 +193,11 @@ class Codec:
                                                    self.hist_ws.data_ptr(), self.hist_ws_bytes,
                                                    self.enc_ws.data_ptr(), self.enc_ws_bytes, self.stream()), "encode")
             return
-        self.check(self.lib.mh_dev_encode_at(model.handle, data.data_ptr(), self.n, prev0,
-                                             start_bit.data_ptr() if start_bit is not None else None,
-                                             self.payload.data_ptr(), self.cap,
-                                             self.nbits.data_ptr(), self.index.data_ptr(), CHUNK, self.enc_ws.data_ptr(),
-                                             self.enc_ws_bytes, self.stream()), "encode")
+        self.check(self.lib.mh_dev_encode_ctx(model.handle, data.data_ptr(), self.n, prev0,
+                                              start_bit.data_ptr() if start_bit is not None else None,
+                                              self.payload.data_ptr(), self.cap,
+                                              self.nbits.data_ptr(), self.index.data_ptr(), CHUNK, self.enc_ws.data_ptr(),
+                                              self.enc_ws_bytes, self.stream()), "encode")
 
     def decode(self, model):
         """The payload length stays on the device (self.nbits[0], written by the encoder)."""
@@ -302,8 +302,6 @@ def main():
     mhc = entry.load_package()
     mhc.lib()                      # fails loudly if libmhc.so is missing: there is no fallback path
     kind = args.kind or ("uniform" if args.config == 4 else "zipf")
-    if args.order == 2 and world > 1:
-        raise SystemExit("--order 2 runs on one GPU (its 128 MiB histogram all-reduce is not wired up yet)")
     # ---- what each rank holds: bytes [first, first + n) of ONE seeded stream
     if args.total_size is not None:
         mode, total = "strong", args.total_size
@@ -321,17 +319,20 @@ def main():
     seed = {"zipf": 2, "uniform": 3, "text": 1}[kind]     # C2 seed 1, C3 seed 2, C4 seed 3
     data = generate(kind, n, seed, first, device)
     # context of each shard's first byte = last byte of the previous shard (' ' for rank 0)
-    prev0 = 0x20
+    # (order 2: the last TWO bytes; prev0 then is the 16-bit context)
+    prev0 = 0x20 if args.order == 1 else 0x2020
     if world > 1:
-        last = torch.zeros(world, dtype=torch.uint8, device=device)
-        all_gather(last, data[-1:].clone())
+        k = args.order
+        last = torch.zeros(world * k, dtype=torch.uint8, device=device)
+        all_gather(last, data[-k:].clone())
         if rank > 0:
-            prev0 = int(last[rank - 1].item())
+            tail = last[(rank - 1) * k:rank * k].tolist()
+            prev0 = tail[0] if k == 1 else (tail[0] << 8 | tail[1])
     codec = Codec(mhc, n, device, args.order)
     all_bits = torch.zeros(world, dtype=torch.int64, device=device)
     my_bits = torch.zeros(1, dtype=torch.int64, device=device)
     start_bit = torch.zeros(1, dtype=torch.int64, device=device)
-    local_counts = torch.zeros(65536, dtype=torch.int64, device=device)
+    local_counts = torch.zeros(65536 if args.order == 1 else 1 << 24, dtype=torch.int64, device=device)
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
     stage_ms = {"hist": 0.0, "allreduce": 0.0, "tree": 0.0, "encode": 0.0, "decode": 0.0}
@@ -345,7 +346,7 @@ def main():
         e[1].record()
         if world > 1:
             local_counts.copy_(codec.counts)          # the shard's own histogram fixes its payload length
-            all_reduce(codec.counts)                  # the one collective: 512 KiB sum over xGMI
+            all_reduce(codec.counts)                  # the one collective: 512 KiB sum over xGMI (order 2: 128 MiB)
         e[2].record()
         model = codec.build_model()                   # the step's one host wait (16 KiB of table sizes)
         e[3].record()
@@ -439,7 +440,8 @@ def main():
             "config": {"workload": workload, "baseline_config": args.config, "bytes_per_gpu": n, "total_bytes": int(total),
                        "generator": "counter-based splitmix64 (seed %d), byte i = f(seed, i): any shard regenerable alone" % seed
                                     if kind != "text" else "8 MiB of seeded Lorem-Ipsum-style text, tiled",
-                       "sharding": "contiguous byte ranges, histogram all-reduce (RCCL)" if world > 1 else "single GPU"},
+                       "sharding": ("contiguous byte ranges, histogram all-reduce (RCCL, %s)" % ("512 KiB" if args.order == 1 else "128 MiB"))
+                                   if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(kernels[dom][0])},

@@ -278,6 +278,15 @@ int mh_dev_encode_at(const mh_model *m, const uint8_t *d_data, size_t n, uint8_t
                      uint64_t *d_index, uint32_t chunk_symbols,
                      void *d_ws, size_t ws_bytes, void *stream);
 
+/* mh_dev_encode_at with the full start context of the shard: the previous byte (order 0/1 models, ctx0 < 256) or,
+ * for an order-2 model, (byte before previous) << 8 | previous byte — a shard of an order-2 stream starts in
+ * the context of the last TWO bytes of the shard before it. */
+int mh_dev_encode_ctx(const mh_model *m, const uint8_t *d_data, size_t n, uint32_t ctx0,
+                      const uint64_t *d_start_bit,
+                      uint8_t *d_payload, size_t cap, uint64_t *d_nbits,
+                      uint64_t *d_index, uint32_t chunk_symbols,
+                      void *d_ws, size_t ws_bytes, void *stream);
+
 /* 64-byte status block + one uint32 per chunk (list of the chunks whose codes exceed the decode
  * tables and are decoded by a second launch); 0 for an invalid chunk size. */
 size_t mh_dev_decode_workspace(uint64_t nbits, uint64_t n_symbols, uint32_t chunk_symbols);

@@ -36,7 +36,7 @@ EXPORTS = [
     "mh_set_input_residency", "mh_histogram_o1", "mh_histogram_o0", "mh_histogram_o2", "mh_dev_histogram_o2", "mh_encode", "mh_encode_bound", "mh_stream_header",
     "mh_stream_parse_header", "mh_decode",
     "mh_dev_histogram_workspace", "mh_dev_histogram_o1", "mh_dev_histogram_o0",
-    "mh_decode_to", "mh_model_payload_bits", "mh_dev_encode_workspace", "mh_dev_encode", "mh_dev_payload_bits", "mh_dev_encode_at", "mh_dev_encode_hist", "mh_dev_decode_workspace", "mh_dev_decode", "mh_dev_decode_dn",
+    "mh_decode_to", "mh_model_payload_bits", "mh_dev_encode_workspace", "mh_dev_encode", "mh_dev_payload_bits", "mh_dev_encode_at", "mh_dev_encode_ctx", "mh_dev_encode_hist", "mh_dev_decode_workspace", "mh_dev_decode", "mh_dev_decode_dn",
     "mh_dev_build_index_workspace", "mh_dev_build_index", "mh_dev_status",
 ]
 
@@ -102,6 +102,7 @@ def lib():
         l.mh_dev_encode.argtypes = [vp, vp, sz, u8, vp, sz, vp, vp, u32, vp, sz, vp]
         l.mh_dev_payload_bits.argtypes = [vp, vp, vp, vp]
         l.mh_dev_encode_at.argtypes = [vp, vp, sz, u8, vp, vp, sz, vp, vp, u32, vp, sz, vp]
+        l.mh_dev_encode_ctx.argtypes = [vp, vp, sz, u32, vp, vp, sz, vp, vp, u32, vp, sz, vp]
         l.mh_dev_encode_hist.argtypes = [vp, vp, sz, u8, vp, vp, sz, vp, vp, u32, vp, sz, vp, sz, vp]
         l.mh_dev_decode_workspace.argtypes = [u64, u64, u32]
         l.mh_dev_decode_workspace.restype = sz

@@ -869,6 +869,13 @@ int mh_dev_encode_hist(const mh_model *m, const uint8_t *d_data, size_t n, uint8
 
 static uint32_t ctx_of_prev0(const mh_model *m, uint8_t prev0) { return m && m->type == 2 ? (uint32_t(prev0) << 8 | prev0) : prev0; }
 
+int mh_dev_encode_ctx(const mh_model *m, const uint8_t *d_data, size_t n, uint32_t ctx0, const uint64_t *d_start_bit,
+                      uint8_t *d_payload, size_t cap, uint64_t *d_nbits, uint64_t *d_index, uint32_t chunk_symbols,
+                      void *d_ws, size_t ws_bytes, void *stream) {
+    if (m && ctx0 > (m->type == 2 ? 0xFFFFu : 0xFFu)) return MH_ERR_ARG;
+    return dev_encode_ctx(m, d_data, n, ctx0, d_start_bit, d_payload, cap, d_nbits, d_index, chunk_symbols, d_ws, ws_bytes, stream);
+}
+
 int mh_dev_encode_at(const mh_model *m, const uint8_t *d_data, size_t n, uint8_t prev0, const uint64_t *d_start_bit,
                      uint8_t *d_payload, size_t cap, uint64_t *d_nbits, uint64_t *d_index, uint32_t chunk_symbols,
                      void *d_ws, size_t ws_bytes, void *stream) {
