@@ -1716,125 +1716,35 @@ __global__ __launch_bounds__(E_THREADS) void enc2_emit_kernel(EmitParams p) {
 }
 
 // ---- decode: one lane per chunk; p.prim / p.sec / p.sec_base / p.tree are the order-2 tables (general form, P = 8)
-// finishes a symbol whose first-level entry `e` is inner: second level, then the walk (decode_one's tail)
-__device__ __forceinline__ uint32_t decode2_long(const DecParams &p, const DecTables &t, const BitSrc &src, BitCursor &bc,
-                                                 uint32_t ctx, uint32_t e, uint32_t &used, bool &bad) {
-    const uint32_t h = ((e >> 12) & 7u) + 1u;
-    bc.drop(t.P);
-    const uint32_t e2 = t.sec[p.sec_base[ctx] + (e & 0xFFFu) + uint32_t(bc.buf >> (64u - h))];
-    if (e2 & DEC16_LEAF) {
-        const uint32_t len = (e2 >> 8) & 31u;
-        bad |= (len == 0);
-        if (len) { bc.drop(len - t.P); used += len; }
-        return e2 & 255u;
-    }
-    bc.drop(h);
-    uint32_t node = e2 & 0x1FFu, n = t.P + h;
-    const uint32_t *tr = t.tree + ctx * TREE_STRIDE;
-    for (int guard = 0; guard < 256; ++guard) {
-        bc.refill(src);
-        const uint32_t bit = uint32_t(bc.buf >> 63);
-        bc.drop(1); ++n;
-        const uint32_t pair = tr[node];
-        const uint32_t c = bit ? (pair >> 16) : (pair & 0xFFFFu);
-        if (c & TREE_LEAF) { used += n; return c & 255u; }
-        node = c;
-    }
-    bad = true;
-    used += n;
-    return 0;
-}
-
-// K chunks per lane, interleaved: the K first-level gathers of a round are in flight together (one lane per
-// chunk alone waits a whole L2 round trip per symbol: 112 GB/s on 4 GiB of text)
-constexpr int D2_K = 4;
 __global__ __launch_bounds__(256) void decode2_kernel(DecParams p) {
     if (p.d_nbits) { p.nbits = *p.d_nbits; p.payload_bytes = (p.nbits + 7) >> 3; }
     const BitSrc src{p.payload, p.payload_bytes >> 2, p.payload_bytes};
     const DecTables tabs{p.sec, p.tree, p.P, 0u, 0u};
     const uint32_t S = 1u << p.chunk_shift;
-    const uint64_t lanes = uint64_t(gridDim.x) * blockDim.x;
-    const uint64_t full_chunks = p.n >> p.chunk_shift;
-    for (uint64_t c0 = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; c0 < p.nchunks; c0 += lanes * D2_K) {
-        if (c0 + uint64_t(D2_K - 1) * lanes < full_chunks) {
-            // ---- D2_K full chunks c0 + k * lanes
-            BitCursor bc[D2_K];
-            uint32_t ctx[D2_K], q[D2_K];
-            uint64_t pos[D2_K], endpos[D2_K];
-            bool bad = false;
-#pragma unroll
-            for (int k = 0; k < D2_K; ++k) {
-                const uint64_t c = c0 + uint64_t(k) * lanes;
-                const uint64_t entry = p.index[c];
-                pos[k] = entry & IDX2_POS;
-                ctx[k] = uint32_t(entry >> 48);
-                endpos[k] = (c + 1 < p.nchunks) ? (p.index[c + 1] & IDX2_POS) : p.nbits;
-                if (pos[k] > p.nbits || endpos[k] < pos[k] || endpos[k] > p.nbits) { bad = true; pos[k] = 0; endpos[k] = 1; }
-                bc[k].init(src, pos[k]);
-                q[k] = 0;
-            }
-            if (bad) { atomicExch(p.status, MHK_STATUS_CORRUPT); continue; }
-            for (uint32_t i = 0; i < S; ++i) {
-                uint32_t e[D2_K];
-#pragma unroll
-                for (int k = 0; k < D2_K; ++k) {
-                    bc[k].refill(src);
-                    e[k] = p.prim[(ctx[k] << 8) | uint32_t(bc[k].buf >> 56)];
-                }
-#pragma unroll
-                for (int k = 0; k < D2_K; ++k) {
-                    uint32_t used = 0, sym;
-                    if (e[k] & DEC16_LEAF) {
-                        const uint32_t len = (e[k] >> 8) & 31u;
-                        bad |= (len == 0);
-                        bc[k].drop(len); used = len;
-                        sym = e[k] & 255u;
-                    } else {
-                        sym = decode2_long(p, tabs, src, bc[k], ctx[k], e[k], used, bad);
-                    }
-                    pos[k] += used;
-                    ctx[k] = ((ctx[k] << 8) | sym) & 0xFFFFu;
-                    q[k] |= sym << (8u * (i & 3u));
-                    if ((i & 3u) == 3u) {
-                        *reinterpret_cast<uint32_t *>(p.out + ((c0 + uint64_t(k) * lanes) << p.chunk_shift) + i - 3u) = q[k];
-                        q[k] = 0;
-                    }
-                }
-                if (bad) break;
-            }
-#pragma unroll
-            for (int k = 0; k < D2_K; ++k) bad |= pos[k] != endpos[k];
-            if (bad) atomicExch(p.status, MHK_STATUS_CORRUPT);
-            continue;
+    for (uint64_t c = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; c < p.nchunks; c += uint64_t(gridDim.x) * blockDim.x) {
+        const uint64_t entry = p.index[c];
+        uint64_t pos = entry & IDX2_POS;
+        uint32_t ctx = uint32_t(entry >> 48);
+        const uint64_t endpos = (c + 1 < p.nchunks) ? (p.index[c + 1] & IDX2_POS) : p.nbits;
+        const uint64_t first = c << p.chunk_shift;
+        const uint32_t nsym = (p.n - first) >= S ? S : uint32_t(p.n - first);
+        if (pos > p.nbits || endpos < pos || endpos > p.nbits) { atomicExch(p.status, MHK_STATUS_CORRUPT); continue; }
+        BitCursor bc;
+        bc.init(src, pos);
+        bool bad = false;
+        uint8_t *o = p.out + first;
+        uint32_t q = 0;
+        for (uint32_t i = 0; i < nsym; ++i) {
+            uint32_t used = 0;
+            const uint32_t sym = decode_one(p.prim, p.sec_base, tabs, src, bc, ctx, used, bad);
+            if (bad) break;
+            pos += used;
+            ctx = ((ctx << 8) | sym) & 0xFFFFu;
+            q |= sym << (8u * (i & 3u));
+            if ((i & 3u) == 3u) { *reinterpret_cast<uint32_t *>(o + i - 3u) = q; q = 0; }
         }
-        // ---- the stream's end: whatever chunks exist, one at a time
-        for (int k = 0; k < D2_K; ++k) {
-            const uint64_t c = c0 + uint64_t(k) * lanes;
-            if (c >= p.nchunks) break;
-            const uint64_t entry = p.index[c];
-            uint64_t pos = entry & IDX2_POS;
-            uint32_t ctx = uint32_t(entry >> 48);
-            const uint64_t endpos = (c + 1 < p.nchunks) ? (p.index[c + 1] & IDX2_POS) : p.nbits;
-            const uint64_t first = c << p.chunk_shift;
-            const uint32_t nsym = (p.n - first) >= S ? S : uint32_t(p.n - first);
-            if (pos > p.nbits || endpos < pos || endpos > p.nbits) { atomicExch(p.status, MHK_STATUS_CORRUPT); continue; }
-            BitCursor bc;
-            bc.init(src, pos);
-            bool bad = false;
-            uint8_t *o = p.out + first;
-            uint32_t q = 0;
-            for (uint32_t i = 0; i < nsym; ++i) {
-                uint32_t used = 0;
-                const uint32_t sym = decode_one(p.prim, p.sec_base, tabs, src, bc, ctx, used, bad);
-                if (bad) break;
-                pos += used;
-                ctx = ((ctx << 8) | sym) & 0xFFFFu;
-                q |= sym << (8u * (i & 3u));
-                if ((i & 3u) == 3u) { *reinterpret_cast<uint32_t *>(o + i - 3u) = q; q = 0; }
-            }
-            for (uint32_t i = nsym & ~3u; i < nsym && !bad; ++i) o[i] = uint8_t(q >> (8u * (i & 3u)));
-            if (bad || pos != endpos) atomicExch(p.status, MHK_STATUS_CORRUPT);
-        }
+        for (uint32_t i = nsym & ~3u; i < nsym && !bad; ++i) o[i] = uint8_t(q >> (8u * (i & 3u)));
+        if (bad || pos != endpos) atomicExch(p.status, MHK_STATUS_CORRUPT);
     }
 }
 
@@ -2099,7 +2009,7 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
     hipError_t e = hipMemsetAsync(d_ws, 0, 64 + 16, st);
     if (e != hipSuccess || p.nchunks == 0) return e;
     if (p.order == 2) {
-        const uint64_t want2 = (p.nchunks + 256 * D2_K - 1) / (256 * D2_K);
+        const uint64_t want2 = (p.nchunks + 255) / 256;
         const uint64_t cap2 = uint64_t(cu_count()) * 8;
         hipLaunchKernelGGL(decode2_kernel, dim3(unsigned(want2 > cap2 ? cap2 : want2)), dim3(256), 0, st, p);
         return hipGetLastError();
