@@ -982,6 +982,7 @@ __device__ __forceinline__ uint32_t decode_one(const uint16_t *prim, const uint3
 template <int GW, int DEPTH = 2>
 struct LaneStream {
     static constexpr int NQ = GW / 4;      // uint4 loads per granule
+    static constexpr bool PAIR = DEPTH == 3;        // two granules = one aligned 2*GW-dword block per load point
     static constexpr uint32_t BEHIND = DEPTH + 1;   // `cur` holds granule gnext - BEHIND while nxt is full
     const uint4 *base;    // payload (wave-uniform: lives in SGPRs)
     uint32_t glast;       // last readable granule of the payload (wave-uniform)
@@ -990,14 +991,23 @@ struct LaneStream {
     uint32_t ccnt;        // dwords left in cur
     uint32_t nxt[GW];     // following granule (DEPTH 1: possibly still in flight)
     bool nxt_full;
-    uint32_t pre[DEPTH == 2 ? GW : 1];     // DEPTH 2: the one after, possibly still in flight
+    uint32_t pre[DEPTH >= 2 ? GW : 1];     // DEPTH 2: the one after, possibly still in flight
+    // PAIR: `nxt` and `pre` are the two halves of one aligned block, requested together when both are
+    // free: the second half then finds its cache line still there (a granule asked for on its own, 40
+    // symbols later, usually has to fetch the line from memory again).  avail = granules loaded after
+    // `cur` (2: nxt is next; 1: pre is next; 0: both free); nxt_full is not used.
+    uint32_t avail;
 
     uint64_t buf;         // next bits, first at bit 63
     uint32_t cnt;         // valid bits in buf
 
     __device__ __forceinline__ void issue_into(uint32_t (&dst)[GW]) {
         const uint32_t g = gnext < glast ? gnext : glast;
+#ifdef MH_EXP_NOLOAD
+        const uint4 *src = base + uint64_t(NQ) * (g & 1023u);
+#else
         const uint4 *src = base + uint64_t(NQ) * g;
+#endif
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const uint4 a = src[q];
@@ -1010,6 +1020,10 @@ struct LaneStream {
     }
     // wave-synchronous point (block boundary): the only place where loads are issued and awaited
     __device__ __forceinline__ void block_sync() {
+        if constexpr (PAIR) {
+            if (avail == 0) { issue_into(nxt); issue_into(pre); avail = 2; }
+            return;
+        }
         if (!nxt_full) {
             if constexpr (DEPTH == 2) {
 #pragma unroll
@@ -1031,14 +1045,21 @@ struct LaneStream {
 #pragma unroll
             for (int i = 0; i < GW - 1; ++i) cur[i] = cur[i + 1];
             if (--ccnt == 0) {
+                if constexpr (PAIR) {
 #pragma unroll
-                for (int i = 0; i < GW; ++i) cur[i] = nxt[i];
+                    for (int i = 0; i < GW; ++i) cur[i] = avail == 2 ? nxt[i] : pre[i];
+                    --avail;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < GW; ++i) cur[i] = nxt[i];
+                    nxt_full = false;
+                }
                 ccnt = GW;
-                nxt_full = false;
                 if (CHECKED) block_sync();
             }
             return w;
         }
+        static_assert(!PAIR || GW == 8, "pair mode is written for 32-byte granules");
         cur[0] = cur[1]; cur[1] = cur[2]; cur[2] = cur[3];
         --ccnt;
         if ((ccnt & 3u) == 0u) {
@@ -1061,7 +1082,16 @@ struct LaneStream {
         base = reinterpret_cast<const uint4 *>(payload);
         glast = uint32_t((total_bytes - 1) / (GW * 4));       // payloads stay below 2^32 granules (128 GiB)
         gnext = uint32_t(w / GW);
-        if constexpr (DEPTH == 2) {
+        if constexpr (PAIR) {
+            const bool even = (gnext & 1u) == 0;                // the other half of this block comes along
+            issue_into(pre);
+#pragma unroll
+            for (int i = 0; i < GW; ++i) cur[i] = pre[i];
+            ccnt = GW;
+            avail = 0;
+            if (even) { issue_into(pre); avail = 1; }
+            nxt_full = false;
+        } else if constexpr (DEPTH == 2) {
             issue_into(pre);
 #pragma unroll
             for (int i = 0; i < GW; ++i) cur[i] = pre[i];
@@ -1097,7 +1127,7 @@ struct LaneStream {
     // (one more while `nxt` is empty), GW - ccnt of its dwords have gone into the window, cnt bits of
     // the window are still unread
     __device__ __forceinline__ uint32_t position() const {
-        const uint32_t gran = gnext - (nxt_full ? BEHIND : BEHIND - 1u);
+        const uint32_t gran = PAIR ? gnext - avail - 1u : gnext - (nxt_full ? BEHIND : BEHIND - 1u);
         return (gran * GW + (GW - ccnt)) * 32u - cnt;
     }
 };
@@ -1126,13 +1156,19 @@ __device__ __forceinline__ bool walk_long(const DecTables &t, LS &ls, uint32_t p
 // One symbol from each of the lane's K independent streams.  prim and sec_base live in LDS; sec lives
 // in LDS too whenever the model's tables fit (t.sec then points into LDS).  The second-level step is
 // skipped by the whole wave when no lane needs it.
-// REFILL: top the bit windows up first (>= 33 bits).  A table-resolved code is at most P + h <= 16
-// bits, so one refill covers two symbols — four when the model has no code longer than 8 bits.
+// REFILL 1: top the bit windows up first: >= 33 bits unless the window was empty (then 32).  A
+// table-resolved code is at most P + h <= 16 bits, so one refill covers two symbols (two 16-bit codes leave
+// one bit), four when the model has no code longer than 8 bits.  (Three symbols per refill for codes of at
+// most 11 bits — with a second refill for the window that was empty — measured no faster: the kernel is
+// not bound by its instruction count.)
 // A null table entry consumes nothing; the caller detects it because the chunk then ends at the wrong
 // bit offset.
 // pe[k] is the entry that resolved the stream's previous symbol: only its low byte (the symbol) is
 // defined.  PC / HC: P and H when they are known at compile time (8), 0 = read them from `t`.  With
 // both widths at 8 bits the table indices are byte shuffles (one v_perm each).
+#ifndef MH_DEC_UNMASKED
+#define MH_DEC_UNMASKED 1       // 0: the exec-masked gather of round 1 (A/B builds)
+#endif
 template <int PC>
 __device__ __forceinline__ uint32_t prim_index(uint32_t pe, uint32_t hi, uint32_t P) {
     if (PC == 8) return __builtin_amdgcn_perm(pe, hi, 0x0C0C0403u);             // sym << 8 | hi >> 24
@@ -1147,9 +1183,9 @@ __device__ __forceinline__ uint32_t put_byte(uint32_t d, uint32_t e, int j) {
 // WALK: codes longer than both table levels are walked in place.  The K-stream hot loop runs without
 // it (K inlined copies of the walk cost 13 % of the decode time in registers and code): such a stream
 // sets its bit in `redo`, and the kernel hands the chunk to the redo pass.
-template <int K, bool CHECKED, bool REFILL, bool DIRECT, int PC, int HC, bool WALK, typename LS>
+template <int K, bool CHECKED, int REFILL, bool DIRECT, int PC, int HC, bool WALK, typename LS>
 __device__ __forceinline__ void decode_step(const uint16_t *prim, const uint32_t *sec_base, const DecTables &t,
-                                            LS (&ls)[K], uint32_t (&pe)[K], bool &bad, uint32_t &redo) {
+                                            LS (&ls)[K], uint32_t (&pe)[K], bool &bad, uint32_t &redo, uint32_t &leafacc) {
     const uint32_t P = PC ? uint32_t(PC) : t.P;
     const uint32_t H = HC ? uint32_t(HC) : t.H;
     uint32_t hi[K], e[K], sb[K], ef[K];
@@ -1157,13 +1193,46 @@ __device__ __forceinline__ void decode_step(const uint16_t *prim, const uint32_t
 #pragma unroll
         for (int k = 0; k < K; ++k) ls[k].template refill<CHECKED>();
     }
-    uint32_t all = DEC16_LEAF;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         hi[k] = uint32_t(ls[k].buf >> 32);
         e[k] = prim[prim_index<PC>(pe[k], hi[k], P)];
         sb[k] = DIRECT ? 0u : sec_base[pe[k] & 255u];           // independent of e[k]: same latency
     }
+    if (DIRECT && !WALK && MH_DEC_UNMASKED) {
+        // Hot loop of the L2 layout: EVERY lane gathers, with no exec masking and no test whether anyone
+        // needs to.  A leaf entry carries bit 15, so its index is >= 0x8000 << H, past the end of the table
+        // (at most 32767 << H entries): the buffer bounds check answers such a lane with 0 and sends
+        // nothing to the cache.  Unresolved codes are only accumulated (leafacc, shared by the lane's K streams,
+        // loses bit 15); the caller looks at it once per chunk group.  Until then such a stream decodes garbage: every table index stays
+        // in range or bounds-checked, the input FIFO clamps its granule index.
+        uint32_t e2[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            uint32_t idx;
+            if (PC == 8 && HC == 8) idx = __builtin_amdgcn_perm(e[k], hi[k], 0x0C050402u);   // e << 8 | byte 2 of hi
+            else idx = (e[k] << H) | __builtin_amdgcn_ubfe(hi[k], 32u - P - H, H);
+#if defined(MH_EXP_NOGATHER)
+            e2[k] = (e[k] & DEC16_LEAF) ? 0u : (DEC16_LEAF | 0x900u | (idx & 1u));
+#elif defined(MH_EXP_GATHERALL)
+            e2[k] = uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(t.sec_rsrc, int((idx & 0xFFFFu) << 1), 0, 0))) & 1u;
+            e2[k] = (e[k] & DEC16_LEAF) ? 0u : (DEC16_LEAF | 0x900u | e2[k]);
+#else
+            e2[k] = uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(t.sec_rsrc, int(idx << 1), 0, 0)));
+#endif
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            ef[k] = e[k] > e2[k] ? e[k] : e2[k];
+            leafacc &= ef[k];
+            const uint32_t len = __builtin_amdgcn_ubfe(ef[k], 8, 5);
+            ls[k].buf <<= len;
+            ls[k].cnt -= len;
+            pe[k] = ef[k];
+        }
+        return;
+    }
+    uint32_t all = DEC16_LEAF;
 #pragma unroll
     for (int k = 0; k < K; ++k) { ef[k] = e[k]; all &= e[k]; }
     if (__any(all == 0)) {                                      // wave-uniform: some stream hit an inner entry
@@ -1232,8 +1301,9 @@ __device__ __forceinline__ void decode_chunk_single(const uint16_t *lut, const u
     ls[0].init(payload, total_bytes, bitpos);
     bool bad = false;
     uint32_t q = 0, redo = 0;
+    uint32_t leafacc = DEC16_LEAF;                               // only the hot loop defers the check
     for (uint32_t i = 0; i < nsym; ++i) {
-        decode_step<1, true, true, DIRECT, 0, 0, true>(lut, sub_base, t, ls, prev, bad, redo);
+        decode_step<1, true, 1, DIRECT, 0, 0, true>(lut, sub_base, t, ls, prev, bad, redo, leafacc);
         q |= (prev[0] & 255u) << (8u * (i & 3u));
         if ((i & 3u) == 3u) { *reinterpret_cast<uint32_t *>(o + i - 3u) = q; q = 0; }
     }
@@ -1316,41 +1386,50 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecParams p) {
             if (!ok) { atomicExch(p.status, MHK_STATUS_CORRUPT); continue; }
             bool bad = false;
             uint32_t redo = 0;                                   // bit k: stream k met a code the tables do not resolve
+            uint32_t leafacc = DEC16_LEAF;
             for (uint32_t burst = 0; burst < (S >> 4) / OUTB; ++burst) {
-                uint32_t Q[K][OUTB][4];
-#pragma unroll
+                // Q[k] = the stream's burst of OUTB 16-byte pieces; the pieces rotate through it so that the
+                // 16-symbol body below writes a fixed set of registers (the u loop stays rolled: code size)
+                uint32_t Q[K][OUTB][4] = {};
+#pragma unroll 1
                 for (int u = 0; u < OUTB; ++u) {                 // 16 symbols -> one uint4 per stream
                     if (u % BLK16 == 0) {
 #pragma unroll
                         for (int k = 0; k < K; ++k) ls[k].block_sync();
                     }
-                    uint32_t q[K][4];
-                    // 4 x (4 symbols -> one dword); the dwords rotate through q so that indexing stays static
-#pragma unroll 1
-                    for (int jj = 0; jj < 4; ++jj) {
-                        uint32_t d[K];
 #pragma unroll
-                        for (int k = 0; k < K; ++k) d[k] = 0;
+                    for (int k = 0; k < K; ++k)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            if (j % SPR == 0) decode_step<K, false, true, DIRECT, PC, HC, false>(lut, sub_base, tabs, ls, prev, bad, redo);
-                            else decode_step<K, false, false, DIRECT, PC, HC, false>(lut, sub_base, tabs, ls, prev, bad, redo);
+                        for (int t = 0; t + 1 < OUTB; ++t) { Q[k][t][0] = Q[k][t + 1][0]; Q[k][t][1] = Q[k][t + 1][1]; Q[k][t][2] = Q[k][t + 1][2]; Q[k][t][3] = Q[k][t + 1][3]; }
+                    uint32_t d[K];
 #pragma unroll
-                            for (int k = 0; k < K; ++k) d[k] = put_byte(d[k], prev[k], j);
+                    for (int j = 0; j < 16; ++j) {
+                        if ((j & 3) == 0) {
+#pragma unroll
+                            for (int k = 0; k < K; ++k) d[k] = 0;
                         }
+                        if (j % SPR == 0) decode_step<K, false, 1, DIRECT, PC, HC, false>(lut, sub_base, tabs, ls, prev, bad, redo, leafacc);
+                        else decode_step<K, false, 0, DIRECT, PC, HC, false>(lut, sub_base, tabs, ls, prev, bad, redo, leafacc);
 #pragma unroll
-                        for (int k = 0; k < K; ++k) { q[k][0] = q[k][1]; q[k][1] = q[k][2]; q[k][2] = q[k][3]; q[k][3] = d[k]; }
+                        for (int k = 0; k < K; ++k) d[k] = put_byte(d[k], prev[k], j & 3);
+                        if ((j & 3) == 3) {
+#pragma unroll
+                            for (int k = 0; k < K; ++k) Q[k][OUTB - 1][j >> 2] = d[k];
+                        }
                     }
-#pragma unroll
-                    for (int k = 0; k < K; ++k) { Q[k][u][0] = q[k][0]; Q[k][u][1] = q[k][1]; Q[k][u][2] = q[k][2]; Q[k][u][3] = q[k][3]; }
                 }
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
+#ifdef MH_EXP_NOSTORE
+                    uint4 *o16 = reinterpret_cast<uint4 *>(p.out + (((c0 + uint64_t(k) * NT) & 4095u) << p.chunk_shift)) + burst * OUTB;
+#else
                     uint4 *o16 = reinterpret_cast<uint4 *>(p.out + ((c0 + uint64_t(k) * NT) << p.chunk_shift)) + burst * OUTB;
+#endif
 #pragma unroll
                     for (int u = 0; u < OUTB; ++u) o16[u] = make_uint4(Q[k][u][0], Q[k][u][1], Q[k][u][2], Q[k][u][3]);
                 }
             }
+            if (!(leafacc & DEC16_LEAF)) redo = (1u << K) - 1u;  // some stream of this lane: all K chunks go to the redo pass
             // every chunk must end exactly where the next one starts (null entries, a wrong table or a
             // damaged stream all miss it)
 #pragma unroll
@@ -2017,17 +2096,37 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
     // instantiations: <SEC_LDS, SPR, DIRECT, K, GW, OUTB, PC, HC>
     // tables in LDS -> wide (2 streams, 64-byte granules and store bursts) or light (4 streams, 32-byte
     // granules and store bursts: 16-byte stores reach HBM as 32-byte writes, measured -14 %); L2 gathers -> light
-    void (*k_lds2_light[2])(DecParams) = {decode_kernel<true, 2, false, 4, 8, 2, 0, 0>, decode_kernel<true, 2, false, 4, 8, 2, 8, 0>};
+#ifndef MH_LIGHT_OUTB
+#define MH_LIGHT_OUTB 2
+#endif
+#ifndef MH_LIGHT_DEPTH
+#define MH_LIGHT_DEPTH 2
+#endif
+    void (*k_lds2_light[2])(DecParams) = {decode_kernel<true, 2, false, 4, 8, MH_LIGHT_OUTB, 0, 0, false, 512, MH_LIGHT_DEPTH>,
+                                          decode_kernel<true, 2, false, 4, 8, MH_LIGHT_OUTB, 8, 0, false, 512, MH_LIGHT_DEPTH>};
     auto k_lds4 = decode_kernel<true, 4, false, 2, 16, 4, 8, 0>;
-    auto k_lds4_light = decode_kernel<true, 4, false, 4, 8, 2, 8, 0>;
-    auto k_l2 = decode_kernel<false, 2, false, 4, 8, 2, 8, 0>;
+    auto k_lds4_light = decode_kernel<true, 4, false, 4, 8, MH_LIGHT_OUTB, 8, 0, false, 512, MH_LIGHT_DEPTH>;
+    auto k_l2 = decode_kernel<false, 2, false, 4, 8, MH_LIGHT_OUTB, 8, 0, false, 512, MH_LIGHT_DEPTH>;
     // second-level height H as a template constant where it is common (max code length 10..12 and >= 16): the
     // table index is then two instructions with immediate operands
-    void (*k_l2d[9])(DecParams) = {decode_kernel<false, 2, true, 4, 8, 2, 8, 0>, decode_kernel<false, 2, true, 4, 8, 2, 8, 0>,
-                                   decode_kernel<false, 2, true, 4, 8, 2, 8, 2>, decode_kernel<false, 2, true, 4, 8, 2, 8, 3>,
-                                   decode_kernel<false, 2, true, 4, 8, 2, 8, 4>, decode_kernel<false, 2, true, 4, 8, 2, 8, 0>,
-                                   decode_kernel<false, 2, true, 4, 8, 2, 8, 0>, decode_kernel<false, 2, true, 4, 8, 2, 8, 0>,
-                                   decode_kernel<false, 2, true, 4, 8, 2, 8, 8>};
+#ifndef MH_L2D_OUTB
+#define MH_L2D_OUTB 4
+#endif
+#ifndef MH_L2D_DEPTH
+#define MH_L2D_DEPTH 1
+#endif
+#ifndef MH_L2D_K
+#define MH_L2D_K 4
+#endif
+#ifndef MH_L2D_GW
+#define MH_L2D_GW 8
+#endif
+#ifndef MH_L2D_NT
+#define MH_L2D_NT 512
+#endif
+#define L2D(SPRV, HCV) decode_kernel<false, SPRV, true, MH_L2D_K, MH_L2D_GW, MH_L2D_OUTB, 8, HCV, false, MH_L2D_NT, MH_L2D_DEPTH>
+    void (*k_l2d[9])(DecParams) = {L2D(2, 0), L2D(2, 0), L2D(2, 2), L2D(2, 3), L2D(2, 4), L2D(2, 0), L2D(2, 0), L2D(2, 0), L2D(2, 8)};
+#undef L2D
     // redo pass (one lane per handed-over chunk, runtime table widths)
     auto r_lds = decode_kernel<true, 2, false, 1, 8, 1, 0, 0, true>;
     auto r_l2 = decode_kernel<false, 2, false, 1, 8, 1, 0, 0, true>;
@@ -2054,13 +2153,14 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
     // 4 GiB), as they do for low-ratio data (41 %-ratio text 8 % slower with the wide streams).
     const bool short_codes = p.nsec == 0 && p.P == 8;
     const bool wide = p.sec_lds && short_codes && p.n > 0 && p.nbits * 10 > p.n * 8 * 6;      // ratio > 0.6
-    const uint64_t per_block = uint64_t(DEC_THREADS) * (wide ? 2 : 4);
+    const bool l2d = !p.sec_lds && p.direct;
+    const uint64_t per_block = l2d ? uint64_t(MH_L2D_NT) * MH_L2D_K : uint64_t(DEC_THREADS) * (wide ? 2 : 4);
     uint64_t want = (p.nchunks + per_block - 1) / per_block;
     int grid = int(want > uint64_t(cu_count()) ? uint64_t(cu_count()) : want);
     const int p8 = p.P == 8;
     if (wide) hipLaunchKernelGGL(k_lds4, dim3(grid), dim3(DEC_THREADS), lds, st, p);
     else if (p.sec_lds) hipLaunchKernelGGL(short_codes ? k_lds4_light : k_lds2_light[p8], dim3(grid), dim3(DEC_THREADS), lds, st, p);
-    else if (p.direct) hipLaunchKernelGGL(k_l2d[p.H <= 8 ? p.H : 0], dim3(grid), dim3(DEC_THREADS), lds, st, p);
+    else if (p.direct) hipLaunchKernelGGL(k_l2d[p.H <= 8 ? p.H : 0], dim3(grid), dim3(MH_L2D_NT), lds, st, p);
     else hipLaunchKernelGGL(k_l2, dim3(grid), dim3(DEC_THREADS), lds, st, p);
     e = hipGetLastError();
     if (e != hipSuccess) return e;

@@ -471,3 +471,33 @@ def test_large_round_trip_property(mhc, oracle):
     assert nbits == ref_bits
     assert blob == ref
     assert m.decompress(blob, index=idx, chunk_symbols=1024, n_symbols=n) == data
+
+
+@pytest.mark.parametrize("s,max_len", [(0.9, 10), (1.1, 11), (1.2, 12)])
+def test_decode_l2_layout_runs_of_longest_codes(mhc, oracle, s, max_len):
+    """Models whose second-level tables live in L2 (256 Zipf-shaped contexts) and data made almost only of
+    the symbols with the LONGEST codes: the hot loop refills its bit window once per two or three symbols,
+    counting on code-length bounds, and three 11-bit codes in a row need one bit more than a refill of an
+    empty window provides (the round-2 kernel first got that wrong, and only a 16 GiB stream showed it).
+    max_len 10 / 11 / 12 select the three-symbol pattern with a single refill, with a double refill, and
+    the two-symbol pattern."""
+    w = (np.floor((1 << 20) / np.arange(1, 257) ** s) + 1).astype(np.uint64)
+    counts = np.tile(w, 256)
+    m = mhc.Model.from_counts(counts, 1)
+    om = oracle.Model.from_counts(counts, 1)
+    lens = np.asarray(om.codes()[0]).reshape(256, 256)
+    assert lens.max() == max_len and (lens == lens[0]).all()
+    longest = np.flatnonzero(lens[0] == max_len).astype(np.uint8)
+    rng = np.random.default_rng(int(s * 100))
+    n = (8 << 20) + 123
+    data = longest[rng.integers(len(longest), size=n)]
+    # other symbols sprinkled in move the code boundaries through every phase of the 32-bit refill
+    other = rng.random(n) < 0.07
+    data[other] = rng.integers(256, size=int(other.sum()), dtype=np.uint8)
+    data = data.tobytes()
+    blob, nbits, idx = m.compress(data, chunk_symbols=1024)
+    ref, ref_bits = om.compress(data)
+    assert nbits == ref_bits and blob == ref
+    assert m.decompress(blob, index=idx, chunk_symbols=1024, n_symbols=n) == data
+    blob2, nbits2, idx2 = m.compress(data, chunk_symbols=256)
+    assert m.decompress(blob2, index=idx2, chunk_symbols=256, n_symbols=n) == data
