@@ -1003,11 +1003,7 @@ struct LaneStream {
 
     __device__ __forceinline__ void issue_into(uint32_t (&dst)[GW]) {
         const uint32_t g = gnext < glast ? gnext : glast;
-#ifdef MH_EXP_NOLOAD
-        const uint4 *src = base + uint64_t(NQ) * (g & 1023u);
-#else
         const uint4 *src = base + uint64_t(NQ) * g;
-#endif
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const uint4 a = src[q];
@@ -1123,6 +1119,9 @@ struct LaneStream {
             cnt += 32u;
         }
     }
+    // (The same refill as selects instead of masked regions — some lane needs the pop at practically every
+    //  refill point, so the regions run anyway — takes 21 % of the loop's instructions and all but 6 of
+    //  its 52 branches away and measured SLOWER: 26.6 vs 25.7 ms.  The kernel is not bound by what it issues.)
     // position of the next unread bit in the payload, modulo 2^32: `cur` holds granule gnext - BEHIND
     // (one more while `nxt` is empty), GW - ccnt of its dwords have gone into the window, cnt bits of
     // the window are still unread
@@ -1166,9 +1165,6 @@ __device__ __forceinline__ bool walk_long(const DecTables &t, LS &ls, uint32_t p
 // pe[k] is the entry that resolved the stream's previous symbol: only its low byte (the symbol) is
 // defined.  PC / HC: P and H when they are known at compile time (8), 0 = read them from `t`.  With
 // both widths at 8 bits the table indices are byte shuffles (one v_perm each).
-#ifndef MH_DEC_UNMASKED
-#define MH_DEC_UNMASKED 1       // 0: the exec-masked gather of round 1 (A/B builds)
-#endif
 template <int PC>
 __device__ __forceinline__ uint32_t prim_index(uint32_t pe, uint32_t hi, uint32_t P) {
     if (PC == 8) return __builtin_amdgcn_perm(pe, hi, 0x0C0C0403u);             // sym << 8 | hi >> 24
@@ -1183,54 +1179,70 @@ __device__ __forceinline__ uint32_t put_byte(uint32_t d, uint32_t e, int j) {
 // WALK: codes longer than both table levels are walked in place.  The K-stream hot loop runs without
 // it (K inlined copies of the walk cost 13 % of the decode time in registers and code): such a stream
 // sets its bit in `redo`, and the kernel hands the chunk to the redo pass.
+// Hot loop of the L2 (direct) layout, in two halves so that the caller can put its own global loads and
+// stores BETWEEN them: a wave's vector-memory results come back in order, so a granule load or a store
+// burst issued before the step's gathers would stand between the wave and their results for a whole trip
+// to HBM; issued behind them it has until the next step's gathers.
+//   issue:   refill, first-level lookup, second-level reads on their way
+//   consume: the entry that resolves each symbol, window shift
+// EVERY lane gathers, with no exec masking and no test whether anyone needs to.  A leaf entry carries bit
+// 15, so its index is >= 0x8000 << H, past the end of the table (at most 32767 << H entries): the buffer
+// bounds check answers such a lane with 0 and sends nothing to the cache.  Unresolved codes are only
+// accumulated (leafacc, shared by the lane's K streams, loses bit 15); the caller looks at it once per chunk
+// group.  Until then such a stream decodes garbage: every table index stays in range or bounds-checked,
+// the input FIFO clamps its granule index.
+template <int K, int REFILL, int PC, int HC, typename LS>
+__device__ __forceinline__ void direct_issue(const uint16_t *prim, const DecTables &t, LS (&ls)[K], const uint32_t (&pe)[K],
+                                             uint32_t (&e)[K], uint32_t (&e2)[K]) {
+    const uint32_t P = PC ? uint32_t(PC) : t.P;
+    const uint32_t H = HC ? uint32_t(HC) : t.H;
+    uint32_t hi[K];
+    // a stream's first-level lookup leaves right behind its own refill: its LDS latency then runs under the
+    // refills of the streams after it (a wave issues in order, and the refills are branches the compiler
+    // does not move loads across)
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (REFILL) ls[k].template refill<false>();
+        hi[k] = uint32_t(ls[k].buf >> 32);
+        e[k] = prim[prim_index<PC>(pe[k], hi[k], P)];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        uint32_t idx;
+        if (PC == 8 && HC == 8) idx = __builtin_amdgcn_perm(e[k], hi[k], 0x0C050402u);   // e << 8 | byte 2 of hi
+        else idx = (e[k] << H) | __builtin_amdgcn_ubfe(hi[k], 32u - P - H, H);
+        e2[k] = uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(t.sec_rsrc, int(idx << 1), 0, 0)));
+    }
+}
+template <int K, typename LS>
+__device__ __forceinline__ void direct_consume(LS (&ls)[K], uint32_t (&pe)[K], const uint32_t (&e)[K], const uint32_t (&e2)[K],
+                                               uint32_t &leafacc) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const uint32_t ef = e[k] > e2[k] ? e[k] : e2[k];
+        leafacc &= ef;
+        const uint32_t len = __builtin_amdgcn_ubfe(ef, 8, 5);
+        ls[k].buf <<= len;
+        ls[k].cnt -= len;
+        pe[k] = ef;
+    }
+}
+
 template <int K, bool CHECKED, int REFILL, bool DIRECT, int PC, int HC, bool WALK, typename LS>
 __device__ __forceinline__ void decode_step(const uint16_t *prim, const uint32_t *sec_base, const DecTables &t,
                                             LS (&ls)[K], uint32_t (&pe)[K], bool &bad, uint32_t &redo, uint32_t &leafacc) {
     const uint32_t P = PC ? uint32_t(PC) : t.P;
     const uint32_t H = HC ? uint32_t(HC) : t.H;
     uint32_t hi[K], e[K], sb[K], ef[K];
-    if (REFILL) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) ls[k].template refill<CHECKED>();
-    }
+    // a stream's first-level lookup leaves right behind its own refill: its LDS latency then runs under the
+    // refills of the streams after it (a wave issues in order, and the refills are branches the compiler
+    // does not move loads across)
 #pragma unroll
     for (int k = 0; k < K; ++k) {
+        if (REFILL) ls[k].template refill<CHECKED>();
         hi[k] = uint32_t(ls[k].buf >> 32);
         e[k] = prim[prim_index<PC>(pe[k], hi[k], P)];
         sb[k] = DIRECT ? 0u : sec_base[pe[k] & 255u];           // independent of e[k]: same latency
-    }
-    if (DIRECT && !WALK && MH_DEC_UNMASKED) {
-        // Hot loop of the L2 layout: EVERY lane gathers, with no exec masking and no test whether anyone
-        // needs to.  A leaf entry carries bit 15, so its index is >= 0x8000 << H, past the end of the table
-        // (at most 32767 << H entries): the buffer bounds check answers such a lane with 0 and sends
-        // nothing to the cache.  Unresolved codes are only accumulated (leafacc, shared by the lane's K streams,
-        // loses bit 15); the caller looks at it once per chunk group.  Until then such a stream decodes garbage: every table index stays
-        // in range or bounds-checked, the input FIFO clamps its granule index.
-        uint32_t e2[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            uint32_t idx;
-            if (PC == 8 && HC == 8) idx = __builtin_amdgcn_perm(e[k], hi[k], 0x0C050402u);   // e << 8 | byte 2 of hi
-            else idx = (e[k] << H) | __builtin_amdgcn_ubfe(hi[k], 32u - P - H, H);
-#if defined(MH_EXP_NOGATHER)
-            e2[k] = (e[k] & DEC16_LEAF) ? 0u : (DEC16_LEAF | 0x900u | (idx & 1u));
-#elif defined(MH_EXP_GATHERALL)
-            e2[k] = uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(t.sec_rsrc, int((idx & 0xFFFFu) << 1), 0, 0))) & 1u;
-            e2[k] = (e[k] & DEC16_LEAF) ? 0u : (DEC16_LEAF | 0x900u | e2[k]);
-#else
-            e2[k] = uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(t.sec_rsrc, int(idx << 1), 0, 0)));
-#endif
-        }
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            ef[k] = e[k] > e2[k] ? e[k] : e2[k];
-            leafacc &= ef[k];
-            const uint32_t len = __builtin_amdgcn_ubfe(ef[k], 8, 5);
-            ls[k].buf <<= len;
-            ls[k].cnt -= len;
-            pe[k] = ef[k];
-        }
-        return;
     }
     uint32_t all = DEC16_LEAF;
 #pragma unroll
@@ -1311,6 +1323,17 @@ __device__ __forceinline__ void decode_chunk_single(const uint16_t *lut, const u
     if (bad || ls[0].position() != uint32_t(end_bits)) atomicExch(status, MHK_STATUS_CORRUPT);
 }
 
+// one burst of OUTB 16-byte pieces per stream: stream k of the lane decodes chunk c0 + k * NT
+template <int K, int OUTB, int NT>
+__device__ __forceinline__ void store_burst(const DecParams &p, uint64_t c0, const uint32_t (&Q)[K][OUTB][4], uint32_t b) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        uint4 *o16 = reinterpret_cast<uint4 *>(p.out + ((c0 + uint64_t(k) * NT) << p.chunk_shift)) + b * OUTB;
+#pragma unroll
+        for (int u = 0; u < OUTB; ++u) o16[u] = make_uint4(Q[k][u][0], Q[k][u][1], Q[k][u][2], Q[k][u][3]);
+    }
+}
+
 // SEC_LDS  both table levels in LDS (else the second level is gathered from L2)
 // SPR      symbols per window refill (2, or 4 when no code exceeds 8 bits)
 // DIRECT   L2 mode with uniform, directly addressed second-level tables
@@ -1344,8 +1367,8 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecParams p) {
     if (threadIdx.x < 256) sub_base[threadIdx.x] = p.sec_base[threadIdx.x];
     __syncthreads();
 
-    // (a hybrid — tables of the frequent contexts in LDS, the rest in L2 — was measured and did not pay:
-    //  some lane still needs L2 in every round, and that latency, not the gather width, is what costs)
+    // (a hybrid — tables of the frequent contexts in LDS, the rest in L2 — was measured in both rounds and did
+    //  not pay, with the masked and with the bounds-checked gather: 25.42 vs 25.42 ms)
     const DecTables tabs{SEC_LDS ? lsec : p.sec, p.tree, p.P, p.direct, p.H,
                          __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.sec), 0, int((p.nsec + 8u) * 2u), 0x00020000)};
     const uint32_t S = 1u << p.chunk_shift;
@@ -1387,20 +1410,14 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecParams p) {
             bool bad = false;
             uint32_t redo = 0;                                   // bit k: stream k met a code the tables do not resolve
             uint32_t leafacc = DEC16_LEAF;
-            for (uint32_t burst = 0; burst < (S >> 4) / OUTB; ++burst) {
-                // Q[k] = the stream's burst of OUTB 16-byte pieces; the pieces rotate through it so that the
-                // 16-symbol body below writes a fixed set of registers (the u loop stays rolled: code size)
-                uint32_t Q[K][OUTB][4] = {};
+            // Q[k] = the stream's burst of OUTB 16-byte pieces; the pieces rotate through it so that the
+            // 16-symbol body below writes a fixed set of registers (the u loop stays rolled: code size)
+            uint32_t Q[K][OUTB][4] = {};
+            constexpr bool SPLIT = DIRECT && !SEC_LDS;           // table gathers from L2 in every step
+            const uint32_t nburst = (S >> 4) / OUTB;
+            for (uint32_t burst = 0; burst < nburst; ++burst) {
 #pragma unroll 1
                 for (int u = 0; u < OUTB; ++u) {                 // 16 symbols -> one uint4 per stream
-                    if (u % BLK16 == 0) {
-#pragma unroll
-                        for (int k = 0; k < K; ++k) ls[k].block_sync();
-                    }
-#pragma unroll
-                    for (int k = 0; k < K; ++k)
-#pragma unroll
-                        for (int t = 0; t + 1 < OUTB; ++t) { Q[k][t][0] = Q[k][t + 1][0]; Q[k][t][1] = Q[k][t + 1][1]; Q[k][t][2] = Q[k][t + 1][2]; Q[k][t][3] = Q[k][t + 1][3]; }
                     uint32_t d[K];
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
@@ -1408,7 +1425,26 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecParams p) {
 #pragma unroll
                             for (int k = 0; k < K; ++k) d[k] = 0;
                         }
-                        if (j % SPR == 0) decode_step<K, false, 1, DIRECT, PC, HC, false>(lut, sub_base, tabs, ls, prev, bad, redo, leafacc);
+                        uint32_t e[K], e2[K];
+                        if (SPLIT) {
+                            if (j % SPR == 0) direct_issue<K, 1, PC, HC>(lut, tabs, ls, prev, e, e2);
+                            else direct_issue<K, 0, PC, HC>(lut, tabs, ls, prev, e, e2);
+                        }
+                        if (j == 0) {
+                            // the first step of the 16 carries the traffic: the previous burst's stores and the
+                            // streams' next input granules leave behind its table gathers (see direct_issue)
+                            if (u == 0 && burst != 0) store_burst<K, OUTB, NT>(p, c0, Q, burst - 1);
+                            if (u % BLK16 == 0) {
+#pragma unroll
+                                for (int k = 0; k < K; ++k) ls[k].block_sync();
+                            }
+#pragma unroll
+                            for (int k = 0; k < K; ++k)
+#pragma unroll
+                                for (int t = 0; t + 1 < OUTB; ++t) { Q[k][t][0] = Q[k][t + 1][0]; Q[k][t][1] = Q[k][t + 1][1]; Q[k][t][2] = Q[k][t + 1][2]; Q[k][t][3] = Q[k][t + 1][3]; }
+                        }
+                        if (SPLIT) direct_consume<K>(ls, prev, e, e2, leafacc);
+                        else if (j % SPR == 0) decode_step<K, false, 1, DIRECT, PC, HC, false>(lut, sub_base, tabs, ls, prev, bad, redo, leafacc);
                         else decode_step<K, false, 0, DIRECT, PC, HC, false>(lut, sub_base, tabs, ls, prev, bad, redo, leafacc);
 #pragma unroll
                         for (int k = 0; k < K; ++k) d[k] = put_byte(d[k], prev[k], j & 3);
@@ -1418,17 +1454,8 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecParams p) {
                         }
                     }
                 }
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-#ifdef MH_EXP_NOSTORE
-                    uint4 *o16 = reinterpret_cast<uint4 *>(p.out + (((c0 + uint64_t(k) * NT) & 4095u) << p.chunk_shift)) + burst * OUTB;
-#else
-                    uint4 *o16 = reinterpret_cast<uint4 *>(p.out + ((c0 + uint64_t(k) * NT) << p.chunk_shift)) + burst * OUTB;
-#endif
-#pragma unroll
-                    for (int u = 0; u < OUTB; ++u) o16[u] = make_uint4(Q[k][u][0], Q[k][u][1], Q[k][u][2], Q[k][u][3]);
-                }
             }
+            store_burst<K, OUTB, NT>(p, c0, Q, nburst - 1);
             if (!(leafacc & DEC16_LEAF)) redo = (1u << K) - 1u;  // some stream of this lane: all K chunks go to the redo pass
             // every chunk must end exactly where the next one starts (null entries, a wrong table or a
             // damaged stream all miss it)
@@ -2124,6 +2151,7 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
 #ifndef MH_L2D_NT
 #define MH_L2D_NT 512
 #endif
+
 #define L2D(SPRV, HCV) decode_kernel<false, SPRV, true, MH_L2D_K, MH_L2D_GW, MH_L2D_OUTB, 8, HCV, false, MH_L2D_NT, MH_L2D_DEPTH>
     void (*k_l2d[9])(DecParams) = {L2D(2, 0), L2D(2, 0), L2D(2, 2), L2D(2, 3), L2D(2, 4), L2D(2, 0), L2D(2, 0), L2D(2, 0), L2D(2, 8)};
 #undef L2D
