@@ -982,7 +982,6 @@ __device__ __forceinline__ uint32_t decode_one(const uint16_t *prim, const uint3
 template <int GW, int DEPTH = 2>
 struct LaneStream {
     static constexpr int NQ = GW / 4;      // uint4 loads per granule
-    static constexpr bool PAIR = DEPTH == 3;        // two granules = one aligned 2*GW-dword block per load point
     static constexpr uint32_t BEHIND = DEPTH + 1;   // `cur` holds granule gnext - BEHIND while nxt is full
     const uint4 *base;    // payload (wave-uniform: lives in SGPRs)
     uint32_t glast;       // last readable granule of the payload (wave-uniform)
@@ -991,12 +990,7 @@ struct LaneStream {
     uint32_t ccnt;        // dwords left in cur
     uint32_t nxt[GW];     // following granule (DEPTH 1: possibly still in flight)
     bool nxt_full;
-    uint32_t pre[DEPTH >= 2 ? GW : 1];     // DEPTH 2: the one after, possibly still in flight
-    // PAIR: `nxt` and `pre` are the two halves of one aligned block, requested together when both are
-    // free: the second half then finds its cache line still there (a granule asked for on its own, 40
-    // symbols later, usually has to fetch the line from memory again).  avail = granules loaded after
-    // `cur` (2: nxt is next; 1: pre is next; 0: both free); nxt_full is not used.
-    uint32_t avail;
+    uint32_t pre[DEPTH == 2 ? GW : 1];     // DEPTH 2: the one after, possibly still in flight
 
     uint64_t buf;         // next bits, first at bit 63
     uint32_t cnt;         // valid bits in buf
@@ -1016,10 +1010,6 @@ struct LaneStream {
     }
     // wave-synchronous point (block boundary): the only place where loads are issued and awaited
     __device__ __forceinline__ void block_sync() {
-        if constexpr (PAIR) {
-            if (avail == 0) { issue_into(nxt); issue_into(pre); avail = 2; }
-            return;
-        }
         if (!nxt_full) {
             if constexpr (DEPTH == 2) {
 #pragma unroll
@@ -1041,21 +1031,15 @@ struct LaneStream {
 #pragma unroll
             for (int i = 0; i < GW - 1; ++i) cur[i] = cur[i + 1];
             if (--ccnt == 0) {
-                if constexpr (PAIR) {
 #pragma unroll
-                    for (int i = 0; i < GW; ++i) cur[i] = avail == 2 ? nxt[i] : pre[i];
-                    --avail;
-                } else {
-#pragma unroll
-                    for (int i = 0; i < GW; ++i) cur[i] = nxt[i];
-                    nxt_full = false;
-                }
+                for (int i = 0; i < GW; ++i) cur[i] = nxt[i];
+                nxt_full = false;
                 ccnt = GW;
                 if (CHECKED) block_sync();
             }
             return w;
         }
-        static_assert(!PAIR || GW == 8, "pair mode is written for 32-byte granules");
+
         cur[0] = cur[1]; cur[1] = cur[2]; cur[2] = cur[3];
         --ccnt;
         if ((ccnt & 3u) == 0u) {
@@ -1078,16 +1062,7 @@ struct LaneStream {
         base = reinterpret_cast<const uint4 *>(payload);
         glast = uint32_t((total_bytes - 1) / (GW * 4));       // payloads stay below 2^32 granules (128 GiB)
         gnext = uint32_t(w / GW);
-        if constexpr (PAIR) {
-            const bool even = (gnext & 1u) == 0;                // the other half of this block comes along
-            issue_into(pre);
-#pragma unroll
-            for (int i = 0; i < GW; ++i) cur[i] = pre[i];
-            ccnt = GW;
-            avail = 0;
-            if (even) { issue_into(pre); avail = 1; }
-            nxt_full = false;
-        } else if constexpr (DEPTH == 2) {
+        if constexpr (DEPTH == 2) {
             issue_into(pre);
 #pragma unroll
             for (int i = 0; i < GW; ++i) cur[i] = pre[i];
@@ -1126,7 +1101,7 @@ struct LaneStream {
     // (one more while `nxt` is empty), GW - ccnt of its dwords have gone into the window, cnt bits of
     // the window are still unread
     __device__ __forceinline__ uint32_t position() const {
-        const uint32_t gran = PAIR ? gnext - avail - 1u : gnext - (nxt_full ? BEHIND : BEHIND - 1u);
+        const uint32_t gran = gnext - (nxt_full ? BEHIND : BEHIND - 1u);
         return (gran * GW + (GW - ccnt)) * 32u - cnt;
     }
 };
