@@ -674,7 +674,7 @@ __global__ __launch_bounds__(E_THREADS) void enc_emit_kernel(EmitParams p) {
 // need each other's bit counts — one LDS exchange — because all 16 deposit into ONE image shared by the
 // workgroup (LDS atomics merge the seams between waves exactly as they merge them between lanes), which the
 // whole workgroup then flushes with coalesced stores.  No second read of the input, no per-tile offsets in
-// HBM: traffic is the algorithmic (1 + r) n.  Three workgroup barriers per round are the price.
+// HBM: traffic is the algorithmic (1 + r) n.  Two workgroup barriers per round are the price.
 // Only for models without escape codes (max length <= 12); others take the three-kernel path.
 constexpr int R_IMG_WORDS = E_WAVES * (E_STAGE_BITS / 32) + 16;          // 16 pieces of <= 12288 bits + carry + slack
 constexpr int REGION_LDS_BYTES = 131072 + R_IMG_WORDS * 4 + 64;
@@ -844,7 +844,8 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
             else out32[gbase + j] = v;
         }
         if (tid == 0 && nfull > 0) { const uint32_t t = img[nfull]; img[nfull] = 0; img[0] = t; }
-        __syncthreads();
+        // no barrier here: the next round touches the image only behind ITS first barrier (the exchange of the
+        // bit counts), which every wave reaches after its share of this flush
         seam_first = seam_first && nfull == 0;
         gbase += nfull;
         cur = (cur + tot) & 31u;
