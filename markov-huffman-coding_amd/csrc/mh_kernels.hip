@@ -836,14 +836,27 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
         }
         __syncthreads();
         // the workgroup flushes the image: full words out (coalesced), the partial last word becomes word 0
+        // (four words per lane: one 16-byte LDS read, one 16-byte clear, one 16-byte store)
         const uint32_t nfull = (cur + tot) >> 5;
-        for (uint32_t j = tid; j < nfull; j += E_THREADS) {
-            const uint32_t v = __builtin_bswap32(img[j]);
-            img[j] = 0;
-            if (j == 0 && seam_first) atomicOr(&out32[gbase], v);
-            else out32[gbase + j] = v;
+        const uint32_t carry = tid == 0 ? img[nfull] : 0u;       // read before anyone clears it
+        for (uint32_t j = tid * 4u; j < nfull; j += E_THREADS * 4u) {
+            const uint4 w = *reinterpret_cast<const uint4 *>(img + j);
+            *reinterpret_cast<uint4 *>(img + j) = make_uint4(0, 0, 0, 0);
+            const uint32_t v[4] = {__builtin_bswap32(w.x), __builtin_bswap32(w.y), __builtin_bswap32(w.z), __builtin_bswap32(w.w)};
+            if (j + 4u <= nfull && !(j == 0 && seam_first)) {
+                struct __attribute__((packed, aligned(4))) Q4 { uint32_t a, b, c, d; };
+                *reinterpret_cast<Q4 *>(out32 + gbase + j) = Q4{v[0], v[1], v[2], v[3]};
+            } else {
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; ++k) {
+                    if (j + k >= nfull) break;
+                    if (j + k == 0 && seam_first) atomicOr(&out32[gbase], v[k]);
+                    else out32[gbase + j + k] = v[k];
+                }
+            }
         }
-        if (tid == 0 && nfull > 0) { const uint32_t t = img[nfull]; img[nfull] = 0; img[0] = t; }
+        // the partial word moves to the front (when nfull is a multiple of 4 no 16-byte clear covered it)
+        if (tid == 0 && nfull > 0) { img[nfull] = 0; img[0] = carry; }
         // no barrier here: the next round touches the image only behind ITS first barrier (the exchange of the
         // bit counts), which every wave reaches after its share of this flush
         seam_first = seam_first && nfull == 0;
