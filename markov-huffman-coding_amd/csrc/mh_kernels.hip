@@ -817,13 +817,17 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
         const uint32_t inc = wave_inclusive_sum(L);
         if (lane == 63) sb[wave] = inc;          // the piece's bit count
         __syncthreads();
-        uint32_t pre = 0, tot = 0;
-#pragma unroll
-        for (uint32_t u = 0; u < uint32_t(E_WAVES); ++u) {
-            const uint32_t t = sb[u];
-            pre += u < wave ? t : 0u;
-            tot += t;
-        }
+        // bits of the round in front of this wave / in the whole round: every row of 16 lanes scans the 16 counts
+        // (one LDS read, four DPP adds, two readlanes instead of sixteen scalar reads and selects: this sits
+        // between the barrier and the deposits, where the whole workgroup waits for it)
+        static_assert(E_WAVES == 16, "the scan below is one DPP row");
+        uint32_t cs = sb[lane & 15u];
+        cs += uint32_t(__builtin_amdgcn_update_dpp(0, int(cs), 0x111, 0xF, 0xF, true));      // row_shr:1
+        cs += uint32_t(__builtin_amdgcn_update_dpp(0, int(cs), 0x112, 0xF, 0xF, true));      // row_shr:2
+        cs += uint32_t(__builtin_amdgcn_update_dpp(0, int(cs), 0x114, 0xF, 0xF, true));      // row_shr:4
+        cs += uint32_t(__builtin_amdgcn_update_dpp(0, int(cs), 0x118, 0xF, 0xF, true));      // row_shr:8
+        const uint32_t tot = uint32_t(__builtin_amdgcn_readlane(int(cs), 15));
+        const uint32_t pre = wave ? uint32_t(__builtin_amdgcn_readlane(int(cs), int(wave) - 1)) : 0u;
         const uint32_t exc = pre + inc - L;      // bits of the round in front of this lane
         const uint64_t off = (v0 + r * E_THREADS + tid) * E_VEC;
         if (p.index && nvalid && ((uint32_t(off) & (S - 1u)) == 0u))
