@@ -1158,6 +1158,9 @@ __device__ __forceinline__ bool walk_long(const DecTables &t, LS &ls, uint32_t p
 // pe[k] is the entry that resolved the stream's previous symbol: only its low byte (the symbol) is
 // defined.  PC / HC: P and H when they are known at compile time (8), 0 = read them from `t`.  With
 // both widths at 8 bits the table indices are byte shuffles (one v_perm each).
+#ifndef MH_DEC_LAG
+#define MH_DEC_LAG 1              // streams between a first-level lookup and its second-level gather (A/B builds)
+#endif
 template <int PC>
 __device__ __forceinline__ uint32_t prim_index(uint32_t pe, uint32_t hi, uint32_t P) {
     if (PC == 8) return __builtin_amdgcn_perm(pe, hi, 0x0C0C0403u);             // sym << 8 | hi >> 24
@@ -1190,22 +1193,25 @@ __device__ __forceinline__ void direct_issue(const uint16_t *prim, const DecTabl
     const uint32_t P = PC ? uint32_t(PC) : t.P;
     const uint32_t H = HC ? uint32_t(HC) : t.H;
     uint32_t hi[K];
-    // a stream's first-level lookup leaves right behind its own refill: its LDS latency then runs under the
-    // refills of the streams after it (a wave issues in order, and the refills are branches the compiler
-    // does not move loads across)
+    // a stream's first-level lookup leaves right behind its own refill, and its second-level gather MH_DEC_LAG
+    // streams later, as soon as that lookup is back: both latencies then run under the refills of the streams
+    // after it (a wave issues in order, and the refills are branches the compiler does not move loads across)
+    auto gather = [&](int k) __attribute__((always_inline)) {
+        uint32_t idx;
+        if (PC == 8 && HC == 8) idx = __builtin_amdgcn_perm(e[k], hi[k], 0x0C050402u);   // e << 8 | byte 2 of hi
+        else idx = (e[k] << H) | __builtin_amdgcn_ubfe(hi[k], 32u - P - H, H);
+        e2[k] = uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(t.sec_rsrc, int(idx << 1), 0, 0)));
+    };
+    constexpr int LAG = MH_DEC_LAG < K ? MH_DEC_LAG : K;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         if (REFILL) ls[k].template refill<false>();
         hi[k] = uint32_t(ls[k].buf >> 32);
         e[k] = prim[prim_index<PC>(pe[k], hi[k], P)];
+        if (k >= LAG) gather(k - LAG);
     }
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        uint32_t idx;
-        if (PC == 8 && HC == 8) idx = __builtin_amdgcn_perm(e[k], hi[k], 0x0C050402u);   // e << 8 | byte 2 of hi
-        else idx = (e[k] << H) | __builtin_amdgcn_ubfe(hi[k], 32u - P - H, H);
-        e2[k] = uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(t.sec_rsrc, int(idx << 1), 0, 0)));
-    }
+    for (int k = K - LAG; k < K; ++k) gather(k);
 }
 template <int K, typename LS>
 __device__ __forceinline__ void direct_consume(LS (&ls)[K], uint32_t (&pe)[K], const uint32_t (&e)[K], const uint32_t (&e2)[K],
