@@ -78,3 +78,58 @@ def test_random_case(mhc, oracle, monkeypatch, seed):
     if n >= 2048 and order == 1:                     # device-built model = host-built model
         md = mhc.Model.from_data(data, 1)
         assert md.compress(data)[0] == blob
+
+
+def l2_layout_case(mhc, oracle, seed):
+    """One random case for the decoder's L2 ("direct") layout: 256 contexts whose second-level tables cannot
+    fit LDS (Zipf-shaped counts with a random exponent -> longest code 9..16 bits, a random rank permutation
+    per context so that the contexts' tables differ), data that mixes the model's own distribution with runs
+    of the longest codes, a few MiB so that the lanes run their K full chunks.  Returns a description."""
+    rng = np.random.default_rng(70000 + seed)
+    s = float(rng.uniform(0.85, 1.9))
+    base = np.floor((1 << 22) / np.arange(1, 257) ** s) + 1
+    counts = np.empty((256, 256), dtype=np.uint64)
+    perms = np.empty((256, 256), dtype=np.int64)
+    for c in range(256):
+        perms[c] = rng.permutation(256) if rng.random() < 0.5 else np.roll(np.arange(256), int(rng.integers(256)))
+        counts[c, perms[c]] = base.astype(np.uint64)
+    counts = counts.reshape(-1)
+    m = mhc.Model.from_counts(counts, 1)
+    om = oracle.Model.from_counts(counts, 1)
+    lens = np.asarray(om.codes()[0]).reshape(256, 256)
+    n = int(rng.integers(2 << 20, 6 << 20)) + int(rng.integers(0, 2000))
+    # a first-order walk: next symbol = the context's r-th most likely symbol, r Zipf-distributed or, in
+    # bursts, drawn from the tail (the longest codes)
+    w = 1.0 / np.arange(1, 257) ** s
+    ranks = rng.choice(256, size=n, p=w / w.sum())
+    tail = rng.random(n) < float(rng.choice([0.0, 0.05, 0.5]))
+    ranks[tail] = rng.integers(200, 256, size=int(tail.sum()))
+    data = np.empty(n, dtype=np.uint8)
+    prev = 0x20
+    # vectorising a Markov walk needs the previous output: do it in blocks with a python loop over a coarse
+    # stride only (the context of the block's first symbol), the rest uses the permutation of that context's
+    # successor — cheap and still context-dependent
+    blk = 4096
+    for off in range(0, n, blk):
+        r = ranks[off:off + blk]
+        out = perms[prev][r]
+        # re-map every symbol through the permutation of its true predecessor for a prefix of the block
+        k = min(64, len(r))
+        p = prev
+        for i in range(k):
+            out[i] = perms[p][r[i]]
+            p = int(out[i])
+        data[off:off + blk] = out
+        prev = int(out[-1])
+    data = data.tobytes()
+    chunk = int(rng.choice([256, 512, 1024, 2048]))
+    blob, nbits, idx = m.compress(data, chunk_symbols=chunk)
+    ref, ref_bits = om.compress(data)
+    assert nbits == ref_bits and blob == ref
+    assert m.decompress(blob, index=idx, chunk_symbols=chunk, n_symbols=n) == data
+    return "s=%.2f maxlen=%d n=%d chunk=%d ratio=%.3f" % (s, int(lens.max()), n, chunk, nbits / 8 / n)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_l2_layout_case(mhc, oracle, seed):
+    l2_layout_case(mhc, oracle, seed)
