@@ -128,9 +128,24 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_o1_kernel(const uint8_t *__
     const uint64_t v_begin = region_vecs ? uint64_t(blockIdx.x) * region_vecs + threadIdx.x : uint64_t(blockIdx.x) * HIST_THREADS + threadIdx.x;
     const uint64_t v_end = region_vecs ? ((blockIdx.x + 1ull) * region_vecs < nvec ? (blockIdx.x + 1ull) * region_vecs : nvec) : nvec;
     const uint64_t v_step = region_vecs ? uint64_t(HIST_THREADS) : uint64_t(gridDim.x) * HIST_THREADS;
+    // the next trip's vector is loaded before this trip's adds; the byte in front of a lane's vector is the
+    // previous lane's last byte (a lane shuffle) except in lane 0 of a wave, which loads it
+    const bool lane0 = (threadIdx.x & 63u) == 0;
+    uint4 nx4 = make_uint4(0, 0, 0, 0);
+    uint32_t nhead = prev0;
+    if (v_begin < v_end) {
+        nx4 = vdata[v_begin];
+        if (lane0 && v_begin) nhead = uint32_t(data[v_begin * 16 - 1]);
+    }
     for (uint64_t v = v_begin; v < v_end; v += v_step) {
-        const uint4 x4 = vdata[v];
-        uint32_t pb = v ? uint32_t(data[v * 16 - 1]) : prev0;
+        const uint4 x4 = nx4;
+        const uint32_t head = nhead;
+        if (v + v_step < v_end) {
+            nx4 = vdata[v + v_step];
+            if (lane0) nhead = uint32_t(data[(v + v_step) * 16 - 1]);
+        }
+        const uint32_t up = __shfl_up(x4.w >> 24, 1);
+        uint32_t pb = lane0 ? head : up;
         const uint32_t x[4] = {x4.x, x4.y, x4.z, x4.w};
         // The kernel is VALU-bound (measured: 13.6 instructions per symbol at 77 % VALU utilisation with
         // the previous slot hash), so the per-symbol work is kept to: one byte shuffle for the slot, the
