@@ -999,8 +999,9 @@ __device__ __forceinline__ uint32_t decode_one(const uint16_t *prim, const uint3
 //  (2) vmcnt retires in order.  A load issued by SOME lane in a round sits in front of that round's
 //      table gather for the WHOLE wave, so per-lane "refill when empty" loads put an HBM latency into
 //      every round.  Loads are therefore issued only at block boundaries (every 16 symbols, all lanes
-//      together) and consumed one block later: `pre` is in flight, `nxt` is resident, `cur` feeds the
-//      bit window; inside a block a granule switch is register-to-register.
+//      together; in the L2 layout right BEHIND the first step's gathers) and consumed a block later:
+//      `nxt` (and with DEPTH 2 `pre`) is in flight or resident, `cur` feeds the bit window; inside a
+//      block a granule switch is register-to-register.
 // A block of 16 symbols decoded through the tables consumes at most 16 * 16 = 256 bits = one granule,
 // and a block starts with `nxt` full, so the hot path never runs dry; longer codes (the walk) and the
 // set-up use the checked pop.
@@ -1011,7 +1012,8 @@ __device__ __forceinline__ uint32_t decode_one(const uint16_t *prim, const uint3
 // loaded straight into: eight registers per stream fewer; the switch cur <- nxt may then wait for a load
 // that was issued at the last block boundary).  Measured at 16 GiB Zipf (profiles/r02/decode_variants.md):
 // DEPTH 1 with 4, 5 or 6 streams per lane and 3 or 4 waves per SIMD all land within 2 % of, or behind,
-// DEPTH 2 with 4 streams and 2 waves — the kernel is not short of streams in flight.
+// DEPTH 2 with 4 streams and 2 waves — the kernel is not short of streams in flight.  The L2 layout runs
+// DEPTH 1: the eight registers per stream hold a 64-byte store burst instead (25.3 vs 29.4 ms).
 template <int GW, int DEPTH = 2>
 struct LaneStream {
     static constexpr int NQ = GW / 4;      // uint4 loads per granule
@@ -1354,10 +1356,11 @@ __device__ __forceinline__ void store_burst(const DecParams &p, uint64_t c0, con
 // K        independent streams (chunks) per lane
 // GW       dwords per input granule (8 = 32 B, 16 = 64 B)
 // OUTB     16-byte stores per output burst (1 = 16 B, 4 = 64 B contiguous per stream)
-// Models whose tables live in LDS are bound by how the streams touch HBM (measured: 32-byte granules
-// re-fetch every 128-byte line four times, 16-byte stores double the write traffic), so they run
-// K = 2 with 64-byte granules and 64-byte store bursts; models that gather from L2 are bound by that
-// latency and run K = 4 with the lighter 32-byte / 16-byte streams.
+// Models whose tables live in LDS and whose codes are all <= 8 bits are bound by how the streams touch HBM
+// (measured: 32-byte granules re-fetch every 128-byte line four times, 16-byte stores double the write
+// traffic), so they run K = 2 with 64-byte granules and 64-byte store bursts; with a second level the
+// dependent lookups dominate and K = 4 with 32-byte granules wins (32-byte bursts with both levels in LDS,
+// 64-byte bursts on a two-slot FIFO with the second level in L2: see launch_decode).
 template <bool SEC_LDS, int SPR, bool DIRECT, int K, int GW, int OUTB, int PC, int HC, bool REDO = false, int NT = 512, int DEPTH = 2>
 __global__ __launch_bounds__(NT) void decode_kernel(DecParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2134,9 +2137,11 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
         hipLaunchKernelGGL(decode2_kernel, dim3(unsigned(want2 > cap2 ? cap2 : want2)), dim3(256), 0, st, p);
         return hipGetLastError();
     }
-    // instantiations: <SEC_LDS, SPR, DIRECT, K, GW, OUTB, PC, HC>
+    // instantiations: <SEC_LDS, SPR, DIRECT, K, GW, OUTB, PC, HC[, REDO, NT, DEPTH]>
     // tables in LDS -> wide (2 streams, 64-byte granules and store bursts) or light (4 streams, 32-byte
-    // granules and store bursts: 16-byte stores reach HBM as 32-byte writes, measured -14 %); L2 gathers -> light
+    // granules and store bursts: 16-byte stores reach HBM as 32-byte writes, measured -14 %; 64-byte bursts
+    // measured the same as 32-byte ones here: 4 GiB text 4.24 vs 4.27 ms); L2 gathers -> 4 streams, 32-byte
+    // granules, 64-byte bursts.  The MH_LIGHT_* / MH_L2D_* macros exist for A/B builds (csrc/Makefile `exp`).
 #ifndef MH_LIGHT_OUTB
 #define MH_LIGHT_OUTB 2
 #endif
