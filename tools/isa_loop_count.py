@@ -12,7 +12,7 @@ out = "/tmp/isa_loop_count.s"
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", src, "-o", out] + sys.argv[2:],
                       stderr=subprocess.DEVNULL)
 lines = open(out).read().split("\n")
-start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and name in l and l.rstrip().endswith(":") is False and ":" in l and not l.startswith("\t"))
+start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and name in l)      # the kernel's label line
 end = next(i for i in range(start + 1, len(lines)) if lines[i].startswith(".Lfunc_end"))
 body = lines[start:end]
 lab = {}
@@ -27,4 +27,4 @@ for i, l in enumerate(body):
         b = body[t:i + 1]
         c = lambda pat: sum(1 for x in b if re.match(r"\s+" + pat, x))
         if i - t > 200:
-            print(f"loop {t}-{i}: valu {c('v_')} salu {c('s_')} lds {c('ds_')} vmem {c('(global|buffer|flat)_')} branch {c('s_c?branch')} waitcnt {c('s_waitcnt')}")
+            print(f"loop {t + start}-{i + start}: valu {c('v_')} salu {c('s_')} lds {c('ds_')} vmem {c('(global|buffer|flat)_')} branch {c('s_c?branch')} waitcnt {c('s_waitcnt')}")
