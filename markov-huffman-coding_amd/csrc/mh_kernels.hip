@@ -941,6 +941,7 @@ struct BitCursor {
         }
     }
     __device__ __forceinline__ void drop(uint32_t n) { buf <<= n; cnt -= n; }
+    __device__ __forceinline__ uint64_t window() const { return buf; }
 };
 
 struct DecTables {
@@ -955,10 +956,11 @@ struct DecTables {
 // Decodes one symbol (sequential index builder; tables read from global memory).  Returns the symbol,
 // or 0 with *bad set on a null table entry (corrupt stream / context missing from the table).
 // *used accumulates the bits consumed.
+template <typename CUR>
 __device__ __forceinline__ uint32_t decode_one(const uint16_t *prim, const uint32_t *sec_base, const DecTables &t,
-                                               const BitSrc &src, BitCursor &bc, uint32_t prev, uint32_t &used, bool &bad) {
+                                               const BitSrc &src, CUR &bc, uint32_t prev, uint32_t &used, bool &bad) {
     bc.refill(src);                                        // >= 33 bits: enough for P + 8
-    uint32_t e = prim[(prev << t.P) | uint32_t(bc.buf >> (64u - t.P))];
+    uint32_t e = prim[(prev << t.P) | uint32_t(bc.window() >> (64u - t.P))];
     if (e & DEC16_LEAF) {                                  // code of <= P bits (src/coding.cpp:150-156)
         uint32_t len = (e >> 8) & 31u;
         bad |= (len == 0);
@@ -969,7 +971,7 @@ __device__ __forceinline__ uint32_t decode_one(const uint16_t *prim, const uint3
     const uint32_t h = t.direct ? t.H : ((e >> 12) & 7u) + 1u;
     bc.drop(t.P);
     const uint32_t tbase = t.direct ? (e << t.H) : sec_base[prev] + (e & 0xFFFu);
-    uint32_t e2 = t.sec[tbase + uint32_t(bc.buf >> (64u - h))];
+    uint32_t e2 = t.sec[tbase + uint32_t(bc.window() >> (64u - h))];
     if (e2 & DEC16_LEAF) {
         uint32_t len = (e2 >> 8) & 31u;                     // total length, P included
         bad |= (len == 0);
@@ -982,7 +984,7 @@ __device__ __forceinline__ uint32_t decode_one(const uint16_t *prim, const uint3
     const uint32_t *tr = t.tree + prev * TREE_STRIDE;
     for (int guard = 0; guard < 256; ++guard) {
         bc.refill(src);
-        uint32_t bit = uint32_t(bc.buf >> 63);
+        uint32_t bit = uint32_t(bc.window() >> 63);
         bc.drop(1); ++n;
         uint32_t pair = tr[node];
         uint32_t c = bit ? (pair >> 16) : (pair & 0xFFFFu);
@@ -1844,6 +1846,16 @@ __global__ __launch_bounds__(E_THREADS) void enc2_emit_kernel(EmitParams p) {
 }
 
 // ---- decode: one lane per chunk; p.prim / p.sec / p.sec_base / p.tree are the order-2 tables (general form, P = 8)
+// BitCursor's face over the 32-byte-granule FIFO of the order-1 decoder: a lane's payload arrives in aligned
+// 32-byte pieces (a dword at a time costs a 128-byte line per load once the lanes' streams are a chunk apart)
+struct GranuleCursor {
+    LaneStream<8, 2> ls;
+    __device__ __forceinline__ void init(const BitSrc &src, uint64_t bitpos) { ls.init(src.p, src.bytes, bitpos); }
+    __device__ __forceinline__ void refill(const BitSrc &) { ls.template refill<true>(); }
+    __device__ __forceinline__ void drop(uint32_t n) { ls.buf <<= n; ls.cnt -= n; }
+    __device__ __forceinline__ uint64_t window() const { return ls.buf; }
+};
+
 __global__ __launch_bounds__(256) void decode2_kernel(DecParams p) {
     if (p.d_nbits) { p.nbits = *p.d_nbits; p.payload_bytes = (p.nbits + 7) >> 3; }
     const BitSrc src{p.payload, p.payload_bytes >> 2, p.payload_bytes};
@@ -1856,22 +1868,40 @@ __global__ __launch_bounds__(256) void decode2_kernel(DecParams p) {
         const uint64_t endpos = (c + 1 < p.nchunks) ? (p.index[c + 1] & IDX2_POS) : p.nbits;
         const uint64_t first = c << p.chunk_shift;
         const uint32_t nsym = (p.n - first) >= S ? S : uint32_t(p.n - first);
-        if (pos > p.nbits || endpos < pos || endpos > p.nbits) { atomicExch(p.status, MHK_STATUS_CORRUPT); continue; }
-        BitCursor bc;
+        if (pos >= p.nbits || endpos < pos || endpos > p.nbits) { atomicExch(p.status, MHK_STATUS_CORRUPT); continue; }
+        GranuleCursor bc;
         bc.init(src, pos);
         bool bad = false;
         uint8_t *o = p.out + first;
-        uint32_t q = 0;
-        for (uint32_t i = 0; i < nsym; ++i) {
+        // 64 symbols -> one 64-byte burst (four 16-byte stores back to back: whole HBM bursts even when the line
+        // is evicted between two bursts; dword stores reach HBM as partial writes)
+        uint32_t i = 0;
+        for (; i + 64u <= nsym && !bad; i += 64u) {
+            uint32_t w[16];
+#pragma unroll
+            for (int d = 0; d < 16; ++d) {
+                uint32_t q = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    uint32_t used = 0;
+                    const uint32_t sym = decode_one(p.prim, p.sec_base, tabs, src, bc, ctx, used, bad);
+                    pos += used;
+                    ctx = ((ctx << 8) | sym) & 0xFFFFu;
+                    q |= sym << (8 * b);
+                }
+                w[d] = q;
+            }
+            uint4 *o16 = reinterpret_cast<uint4 *>(o + i);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) o16[u] = make_uint4(w[4 * u], w[4 * u + 1], w[4 * u + 2], w[4 * u + 3]);
+        }
+        for (; i < nsym && !bad; ++i) {                          // the ragged last chunk
             uint32_t used = 0;
             const uint32_t sym = decode_one(p.prim, p.sec_base, tabs, src, bc, ctx, used, bad);
-            if (bad) break;
             pos += used;
             ctx = ((ctx << 8) | sym) & 0xFFFFu;
-            q |= sym << (8u * (i & 3u));
-            if ((i & 3u) == 3u) { *reinterpret_cast<uint32_t *>(o + i - 3u) = q; q = 0; }
+            o[i] = uint8_t(sym);
         }
-        for (uint32_t i = nsym & ~3u; i < nsym && !bad; ++i) o[i] = uint8_t(q >> (8u * (i & 3u)));
         if (bad || pos != endpos) atomicExch(p.status, MHK_STATUS_CORRUPT);
     }
 }
