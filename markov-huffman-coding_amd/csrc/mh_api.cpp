@@ -39,6 +39,7 @@ struct mh_model {
     uint8_t *d_len8 = nullptr;
     uint8_t *d_len_slot = nullptr;
     uint64_t *d_code64 = nullptr;
+    uint64_t *d_enc64 = nullptr;           // order 2: len << 56 | code (mhk::launch_enc64_pack), part of d_build
     uint16_t *d_prim = nullptr;
     uint16_t *d_sec = nullptr;
     uint32_t *d_sec_base = nullptr;
@@ -496,13 +497,13 @@ bool is_o2_table(const uint8_t *b, size_t n) {
     return std::memcmp(b + 33, O2_MAGIC, 4) == 0;
 }
 
-struct Build2Layout { size_t off[11], total; };
+struct Build2Layout { size_t off[12], total; };
 Build2Layout build2_layout() {
     const size_t nn = size_t(O2_CTX) * mhk::TB_NODE_STRIDE, ne = size_t(O2_CTX) * 256;
-    const size_t sizes[11] = {ne, ne * 8, ne * 4, ne * 2, size_t(O2_CTX) * 4, nn * 2, nn * 2, nn, nn, size_t(O2_CTX) * mhk::TB_META_STRIDE * 4, 256};
+    const size_t sizes[12] = {ne, ne * 8, ne * 4, ne * 2, size_t(O2_CTX) * 4, nn * 2, nn * 2, nn, nn, size_t(O2_CTX) * mhk::TB_META_STRIDE * 4, 256, ne * 8};
     Build2Layout L;
     size_t total = 0;
-    for (int i = 0; i < 11; ++i) { L.off[i] = total; total += (sizes[i] + 255) & ~size_t(255); }
+    for (int i = 0; i < 12; ++i) { L.off[i] = total; total += (sizes[i] + 255) & ~size_t(255); }
     L.total = total;
     return L;
 }
@@ -518,6 +519,7 @@ void place2(mh_model *m, unsigned char *b, const Build2Layout &L, uint8_t **node
     m->d_node_sym = b + L.off[7];
     *node_height = b + L.off[8];
     m->d_meta = reinterpret_cast<uint32_t *>(b + L.off[9]);
+    m->d_enc64 = reinterpret_cast<uint64_t *>(b + L.off[11]);
 }
 
 // counts (1 << 24, device) -> 65536 trees, codes and decode tables, all on the device
@@ -536,6 +538,7 @@ int dev_model_build2(const uint64_t *d_counts, hipStream_t st, mh_model **out) {
     mhk::TreeBuildOut tb{m->d_len8, reinterpret_cast<unsigned long long *>(m->d_code64), nullptr, nullptr,
                          m->d_node_left, m->d_node_right, m->d_node_sym, d_node_height, m->d_meta, O2_HCAP};
     HIP_TRY_M(mhk::launch_tree_build(reinterpret_cast<const unsigned long long *>(d_counts), int(O2_CTX), tb, st));
+    HIP_TRY_M(mhk::launch_enc64_pack(m->d_len8, m->d_code64, m->d_enc64, uint64_t(O2_CTX) * 256, st));
     std::vector<uint32_t> meta(size_t(O2_CTX) * mhk::TB_META_STRIDE);
     HIP_TRY_M(hipMemcpyAsync(meta.data(), m->d_meta, meta.size() * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY_M(hipStreamSynchronize(st));
@@ -616,6 +619,8 @@ int model2_from_table(const uint8_t *bytes, size_t n, mh_model **out) {
     HIP_TRY_M(hipMemset(m->d_sec_own, 0, sec_bytes));
     HIP_TRY_M(hipMemcpy(m->d_len8, len8.data(), ne, hipMemcpyHostToDevice));
     HIP_TRY_M(hipMemcpy(m->d_code64, code64.data(), ne * 8, hipMemcpyHostToDevice));
+    HIP_TRY_M(mhk::launch_enc64_pack(m->d_len8, m->d_code64, m->d_enc64, uint64_t(ne), nullptr));
+    HIP_TRY_M(hipStreamSynchronize(nullptr));
     HIP_TRY_M(hipMemcpy(m->d_tree, tree.data(), ne * 4, hipMemcpyHostToDevice));
     HIP_TRY_M(hipMemcpy(m->d_prim, prim.data(), ne * 2, hipMemcpyHostToDevice));
     HIP_TRY_M(hipMemcpy(m->d_sec_base, sec_base.data(), size_t(O2_CTX) * 4, hipMemcpyHostToDevice));
@@ -835,7 +840,7 @@ static int dev_encode_ctx(const mh_model *m, const uint8_t *d_data, size_t n, ui
     p.order = m->type == 2 ? 2 : 1;
     p.data = d_data; p.n = n; p.prev0 = ctx0; p.chunk_shift = uint32_t(shift);
     p.out = d_payload; p.cap = cap;
-    p.enc16 = m->d_enc16; p.len_slot = m->d_len_slot; p.len8 = m->d_len8; p.code64 = m->d_code64;
+    p.enc16 = m->d_enc16; p.len_slot = m->d_len_slot; p.len8 = m->d_len8; p.code64 = m->d_code64; p.enc64 = m->type == 2 ? m->d_enc64 : nullptr;
     p.nbits = reinterpret_cast<unsigned long long *>(d_nbits);
     p.index = reinterpret_cast<unsigned long long *>(d_index);
     p.start_bit = reinterpret_cast<const unsigned long long *>(d_start_bit);
@@ -859,7 +864,7 @@ int mh_dev_encode_hist(const mh_model *m, const uint8_t *d_data, size_t n, uint8
     p.order = 1;
     p.data = d_data; p.n = n; p.prev0 = prev0; p.chunk_shift = uint32_t(shift);
     p.out = d_payload; p.cap = cap;
-    p.enc16 = m->d_enc16; p.len_slot = m->d_len_slot; p.len8 = m->d_len8; p.code64 = m->d_code64;
+    p.enc16 = m->d_enc16; p.len_slot = m->d_len_slot; p.len8 = m->d_len8; p.code64 = m->d_code64; p.enc64 = m->type == 2 ? m->d_enc64 : nullptr;
     p.nbits = reinterpret_cast<unsigned long long *>(d_nbits);
     p.index = reinterpret_cast<unsigned long long *>(d_index);
     p.start_bit = reinterpret_cast<const unsigned long long *>(d_start_bit);

@@ -23,6 +23,7 @@ struct EncodeArgs {
     const uint8_t *len_slot;      // 65536 code lengths, slot order (length pass)
     const uint8_t *len8;          // 65536, prev*256+sym
     const uint64_t *code64;       // 65536, prev*256+sym
+    const uint64_t *enc64;        // order 2, optional: len << 56 | code per (ctx, sym), len 255 = longer than 56 bits (see len8 / code64)
     unsigned long long *nbits;    // out: payload bits
     unsigned long long *index;    // out: chunk index or nullptr
     const unsigned long long *start_bit;   // device: global bit position of this payload (low 3 bits used) or nullptr
@@ -56,6 +57,7 @@ struct EmitParams {
     const uint16_t *enc16;
     const uint8_t *len8;
     const uint64_t *code64;
+    const uint64_t *enc64;        // order 2 only (EncodeArgs)
     const unsigned long long *wt_start;
     uint64_t nwt;
     unsigned long long *index;
@@ -146,6 +148,8 @@ hipError_t launch_encode(const EncodeArgs &a, void *d_ws, hipStream_t st);
 hipError_t launch_encode_regions(const EncodeArgs &a, const void *d_hist_ws, size_t hist_ws_bytes, void *d_ws, hipStream_t st);
 hipError_t launch_payload_bits(const unsigned long long *d_counts, const uint8_t *d_len8, uint32_t entries, unsigned long long *d_out,
                                hipStream_t st);
+// enc64[i] = len8[i] << 56 | code64[i] (len <= 56), else 0xFF << 56: one gather per symbol in the order-2 encoder
+hipError_t launch_enc64_pack(const uint8_t *len8, const uint64_t *code64, uint64_t *enc64, uint64_t n, hipStream_t st);
 hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st);
 size_t build_index_workspace_bytes(uint64_t nbits);
 hipError_t launch_build_index(IdxParams p, void *d_ws, hipStream_t st);

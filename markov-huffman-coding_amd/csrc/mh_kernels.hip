@@ -1800,8 +1800,21 @@ __global__ __launch_bounds__(E_THREADS) void enc2_emit_kernel(EmitParams p) {
             // one dependent round trip per symbol (first version: 150 GB/s, bound by exactly that latency)
             uint32_t l[16];
             uint64_t c[16];
-            {
-                const uint32_t x[4] = {in.x.x, in.x.y, in.x.z, in.x.w};
+            const uint32_t x[4] = {in.x.x, in.x.y, in.x.z, in.x.w};
+            bool escape = p.enc64 == nullptr;
+            if (p.enc64) {                       // one 8-byte gather per symbol: length in the top byte
+                uint32_t ctx = ctx0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const uint32_t key = (ctx << 8) | ((x[j >> 2] >> (8 * (j & 3))) & 255u);
+                    const uint64_t e = uint32_t(j) < in.nvalid ? p.enc64[key] : 0ull;
+                    l[j] = uint32_t(e >> 56);
+                    c[j] = e & 0x00FFFFFFFFFFFFFFull;
+                    escape = escape || l[j] == 255u;
+                    ctx = key & 0xFFFFu;
+                }
+            }
+            if (__any(escape)) {                 // a code of more than 56 bits somewhere in the wave (or no packed table)
                 uint32_t ctx = ctx0;
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
@@ -2119,7 +2132,7 @@ hipError_t launch_encode(const EncodeArgs &a, void *d_ws, hipStream_t st) {
     ScanParams sp{wt_start, blk_sum, L.nwt, L.nblk, a.out, a.cap & ~uint64_t(3), a.nbits, status};
     hipLaunchKernelGGL(scan_apply_kernel, dim3(unsigned(L.nblk)), dim3(SCAN_THREADS), 0, st, sp);
 
-    EmitParams ep{a.data, a.n, a.prev0, a.chunk_shift, a.out, a.enc16, a.len8, a.code64, wt_start, L.nwt, a.index, status};
+    EmitParams ep{a.data, a.n, a.prev0, a.chunk_shift, a.out, a.enc16, a.len8, a.code64, a.enc64, wt_start, L.nwt, a.index, status};
     if (a.order == 2) {                                      // no table in LDS: two workgroups per CU
         hipLaunchKernelGGL(enc2_emit_kernel, dim3(grid), dim3(E_THREADS), E_WAVES * E_STAGE_WORDS * 4, st, ep);
         return hipGetLastError();
@@ -2155,9 +2168,21 @@ hipError_t launch_encode_regions(const EncodeArgs &a, const void *d_hist_ws, siz
                        region_bits, status);
     hipLaunchKernelGGL(region_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, region_bits, uint32_t(g.grid), region_start, a.start_bit,
                        a.out, a.cap & ~uint64_t(3), a.nbits, status);
-    EmitParams ep{a.data, a.n, a.prev0, a.chunk_shift, a.out, a.enc16, a.len8, a.code64, nullptr, 0, a.index, status};
+    EmitParams ep{a.data, a.n, a.prev0, a.chunk_shift, a.out, a.enc16, a.len8, a.code64, nullptr, nullptr, 0, a.index, status};
     RegionParams rp{region_start, g.region_vecs, g.nvec_up};
     hipLaunchKernelGGL(enc_region_kernel, dim3(g.grid), dim3(E_THREADS), REGION_LDS_BYTES, st, ep, rp);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void enc64_pack_kernel(const uint8_t *len8, const unsigned long long *code64, unsigned long long *enc64, uint64_t n) {
+    for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += uint64_t(gridDim.x) * 256) {
+        const uint32_t l = len8[i];
+        enc64[i] = l <= 56u ? ((unsigned long long)(l) << 56) | code64[i] : 0xFF00000000000000ull;
+    }
+}
+hipError_t launch_enc64_pack(const uint8_t *len8, const uint64_t *code64, uint64_t *enc64, uint64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(enc64_pack_kernel, dim3(unsigned(cu_count()) * 8u), dim3(256), 0, st, len8,
+                       reinterpret_cast<const unsigned long long *>(code64), reinterpret_cast<unsigned long long *>(enc64), n);
     return hipGetLastError();
 }
 
