@@ -1890,23 +1890,28 @@ __global__ __launch_bounds__(256) void decode2_kernel(DecParams p) {
         // is evicted between two bursts; dword stores reach HBM as partial writes)
         uint32_t i = 0;
         for (; i + 64u <= nsym && !bad; i += 64u) {
-            uint32_t w[16];
+            uint4 Q[4] = {};                                      // the pieces rotate through Q: the 16-symbol body stays rolled
+#pragma unroll 1
+            for (int u = 0; u < 4; ++u) {
+                uint32_t w[4];
 #pragma unroll
-            for (int d = 0; d < 16; ++d) {
-                uint32_t q = 0;
+                for (int d = 0; d < 4; ++d) {
+                    uint32_t q = 0;
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    uint32_t used = 0;
-                    const uint32_t sym = decode_one(p.prim, p.sec_base, tabs, src, bc, ctx, used, bad);
-                    pos += used;
-                    ctx = ((ctx << 8) | sym) & 0xFFFFu;
-                    q |= sym << (8 * b);
+                    for (int b = 0; b < 4; ++b) {
+                        uint32_t used = 0;
+                        const uint32_t sym = decode_one(p.prim, p.sec_base, tabs, src, bc, ctx, used, bad);
+                        pos += used;
+                        ctx = ((ctx << 8) | sym) & 0xFFFFu;
+                        q |= sym << (8 * b);
+                    }
+                    w[d] = q;
                 }
-                w[d] = q;
+                Q[0] = Q[1]; Q[1] = Q[2]; Q[2] = Q[3]; Q[3] = make_uint4(w[0], w[1], w[2], w[3]);
             }
             uint4 *o16 = reinterpret_cast<uint4 *>(o + i);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) o16[u] = make_uint4(w[4 * u], w[4 * u + 1], w[4 * u + 2], w[4 * u + 3]);
+            for (int u = 0; u < 4; ++u) o16[u] = Q[u];
         }
         for (; i < nsym && !bad; ++i) {                          // the ragged last chunk
             uint32_t used = 0;
