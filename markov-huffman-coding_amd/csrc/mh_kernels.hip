@@ -1694,9 +1694,14 @@ __device__ __forceinline__ void hist2_add(uint32_t *tag, uint32_t *cnt, uint32_t
                                           uint32_t probes) {
     uint32_t slot = (key * 0x9E3779B1u) >> 18;                   // 14 bits
     for (uint32_t p = 0; p < probes; ++p, slot = (slot + 1u) & (H2_SLOTS - 1u)) {
-        const uint32_t old = atomicCAS(&tag[slot], H2_EMPTY, key);
-        if (old == H2_EMPTY) atomicAdd(used, 1u);
-        if (old == H2_EMPTY || old == key) { atomicAdd(&cnt[slot], 1u); return; }
+        // a plain read first: once its tag is set (tags never change) a key costs one read, which the LDS broadcasts
+        // to all the lanes that ask for the same slot, and one add — not a compare-and-swap that serialises them
+        uint32_t t = __hip_atomic_load(&tag[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (t == H2_EMPTY) {
+            t = atomicCAS(&tag[slot], H2_EMPTY, key);
+            if (t == H2_EMPTY) { atomicAdd(used, 1u); t = key; }
+        }
+        if (t == key) { atomicAdd(&cnt[slot], 1u); return; }
     }
     atomicAdd(&counts[key], 1ull);
 }
