@@ -1148,6 +1148,16 @@ struct LaneStream {
     }
 };
 
+// BitCursor's face over the 32-byte-granule FIFO of the order-1 decoder: a lane's payload arrives in aligned
+// 32-byte pieces (a dword at a time costs a 128-byte line per load once the lanes' streams are a chunk apart)
+struct GranuleCursor {
+    LaneStream<8, 2> ls;
+    __device__ __forceinline__ void init(const BitSrc &src, uint64_t bitpos) { ls.init(src.p, src.bytes, bitpos); }
+    __device__ __forceinline__ void refill(const BitSrc &) { ls.template refill<true>(); }
+    __device__ __forceinline__ void drop(uint32_t n) { ls.buf <<= n; ls.cnt -= n; }
+    __device__ __forceinline__ uint64_t window() const { return ls.buf; }
+};
+
 // Walk for codes longer than P + h (rare).  `skip` = P + h bits of the window have NOT been consumed.
 // Returns false on a corrupt stream.
 template <typename LS>
@@ -1527,7 +1537,7 @@ __device__ __forceinline__ uint64_t walk_segment(const IdxParams &p, const DecTa
     count = 0;
     bad = false;
     if (pos >= seg_end) return start;
-    BitCursor bc;
+    GranuleCursor bc;                                       // (dword reads cost a cache line each here: lanes are a segment apart)
     bc.init(src, pos);
     while (pos < seg_end) {
         on_symbol(count, prev, pos);
@@ -1864,16 +1874,6 @@ __global__ __launch_bounds__(E_THREADS) void enc2_emit_kernel(EmitParams p) {
 }
 
 // ---- decode: one lane per chunk; p.prim / p.sec / p.sec_base / p.tree are the order-2 tables (general form, P = 8)
-// BitCursor's face over the 32-byte-granule FIFO of the order-1 decoder: a lane's payload arrives in aligned
-// 32-byte pieces (a dword at a time costs a 128-byte line per load once the lanes' streams are a chunk apart)
-struct GranuleCursor {
-    LaneStream<8, 2> ls;
-    __device__ __forceinline__ void init(const BitSrc &src, uint64_t bitpos) { ls.init(src.p, src.bytes, bitpos); }
-    __device__ __forceinline__ void refill(const BitSrc &) { ls.template refill<true>(); }
-    __device__ __forceinline__ void drop(uint32_t n) { ls.buf <<= n; ls.cnt -= n; }
-    __device__ __forceinline__ uint64_t window() const { return ls.buf; }
-};
-
 __global__ __launch_bounds__(256) void decode2_kernel(DecParams p) {
     if (p.d_nbits) { p.nbits = *p.d_nbits; p.payload_bytes = (p.nbits + 7) >> 3; }
     const BitSrc src{p.payload, p.payload_bytes >> 2, p.payload_bytes};
