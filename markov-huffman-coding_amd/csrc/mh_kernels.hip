@@ -2345,15 +2345,27 @@ hipError_t launch_build_index(IdxParams p, void *d_ws, hipStream_t st) {
     // whose context ' ' has a single successor), so the classes are tried in turn with a short budget each;
     // the right one converges in two or three passes.  If none does, the last instance runs on to the pass
     // cap and the sequential walk below is the last resort.
+    // An instance is given up when it stops making progress, not after a fixed number of passes: on the wrong
+    // residue class every pass re-decodes (nearly) every segment, on the right one the count of changed segments
+    // falls geometrically — but how fast depends on the model: 8-bit codes in 256 contexts (random bytes) merge
+    // two trajectories with probability 1/256 per symbol, i.e. 86 % per 512-symbol segment, and need ten passes
+    // where text needs three (a fixed budget of five sent exactly that case, 1 GiB of random bytes, through all
+    // eight classes and then to the one-lane walk: minutes).
     bool converged = false;
     const uint32_t nphase = g > 1 ? (g < 16u ? g : 16u) : 1u;
-    uint32_t it = 0;
-    for (uint32_t phase = 0; phase < nphase && !converged; ++phase) {
-        const bool last_instance = phase + 1 == nphase;
-        const uint32_t budget_end = last_instance ? IDX_MAX_PASSES : (it + 5 < IDX_MAX_PASSES ? it + 5 : IDX_MAX_PASSES);
+    uint32_t it = 0, best_phase = 0;
+    unsigned int best_changed = ~0u;
+    // instances 0 .. nphase - 1 are given up when they stall; instance nphase re-runs the class that got furthest
+    // with whatever is left of the pass budget (nphase == 1: the only class runs to the end at once)
+    for (uint32_t inst = 0; inst <= nphase && !converged && it < IDX_MAX_PASSES; ++inst) {
+        if (inst == nphase && nphase == 1) break;
+        const bool to_the_end = nphase == 1 || inst == nphase;
+        const uint32_t phase = inst == nphase ? best_phase : inst;
         bool first = true;
-        while (it < budget_end && !converged) {
-            const uint32_t batch_end = it + 8 < budget_end ? it + 8 : budget_end;
+        unsigned int prev_changed = 0;                           // changed segments at the end of the previous batch
+        while (it < IDX_MAX_PASSES && !converged) {
+            const uint32_t batch = first ? 3u : 4u;
+            const uint32_t batch_end = it + batch < IDX_MAX_PASSES ? it + batch : IDX_MAX_PASSES;
             for (; it < batch_end; ++it) {
                 hipLaunchKernelGGL(index_sync_kernel, dim3(grid), dim3(256), 0, st, p, it, first ? 1u : 0u, phase);
                 first = false;
@@ -2364,6 +2376,15 @@ hipError_t launch_build_index(IdxParams p, void *d_ws, hipStream_t st) {
             e = hipStreamSynchronize(st);
             if (e != hipSuccess) return e;
             converged = last == 0;
+            // no progress over a whole batch (less than a quarter fewer changes), or after the first three passes
+            // still every second segment changing: the wrong class
+            const bool stalled = prev_changed != 0 && uint64_t(last) * 4u > uint64_t(prev_changed) * 3u;
+            const bool hopeless = prev_changed == 0 && uint64_t(last) * 2u > p.nseg;
+            prev_changed = last;
+            if (!converged && !to_the_end && (stalled || hopeless)) {
+                if (last < best_changed) { best_changed = last; best_phase = phase; }
+                break;
+            }
         }
     }
     if (!converged) {      // segments that never re-synchronise: do it the slow, certain way

@@ -263,3 +263,31 @@ def test_index_free_decode_fixed_length_codes(mhc, oracle, symbols, n):
     blob, _ = o.compress(data)
     m = mhc.Model.from_table(o.table_bytes())
     assert m.decompress(blob) == data
+
+
+def test_index_free_decode_of_random_bytes_under_fixed_length_codes(mhc, oracle):
+    """A stream without an index whose model has 8-bit codes in every one of 256 contexts, each context with its
+    own code assignment (what ~1 GiB of random bytes gives: below that the counts still differ enough for mixed
+    7/8/9-bit codes).  Code boundaries sit on a lattice of 8 bits and two decodes from different contexts only
+    merge when they happen to produce the same symbol (1/256 per symbol), so the segment iteration needs about
+    ten passes on the right residue class; the first version gave every class five passes and then walked the
+    whole payload on one lane (1 GiB: minutes).  64 MiB here: the one-lane walk would take seconds, the
+    segment iteration takes a few tens of milliseconds — the time bound tells them apart."""
+    import time
+    c = np.arange(256, dtype=np.uint64)
+    counts = (100000 + ((c[None, :] * 7 + c[:, None] * 13) % 5)).astype(np.uint64).reshape(-1)
+    om = oracle.Model.from_counts(counts, 1)
+    lens = np.asarray(om.codes()[0]).reshape(256, 256)
+    codes = np.asarray(om.codes()[1]).reshape(256, 256)
+    assert (lens == 8).all() and (codes[0] != codes[1]).any()          # fixed length, context-dependent assignment
+    n = 64 << 20
+    data = np.random.default_rng(77).integers(0, 256, n, dtype=np.uint8).tobytes()
+    blob, nbits = om.compress(data)
+    assert nbits == 8 * n
+    m = mhc.Model.from_table(om.table_bytes())
+    assert m.decompress(blob[:1 + (1 << 20)]) == data[:1 << 20]          # warm-up (first HIP calls, allocations)
+    t0 = time.perf_counter()
+    out = m.decompress(blob)
+    dt = time.perf_counter() - t0
+    assert out == data
+    assert dt < 2.5, "index-free decode of 64 MiB took %.1f s: the one-lane walk instead of the segment iteration?" % dt
