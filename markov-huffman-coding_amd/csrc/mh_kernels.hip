@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 
@@ -1612,6 +1613,91 @@ __global__ __launch_bounds__(256) void index_fill_kernel(IdxParams p) {
         atomicExch(p.status, MHK_STATUS_CORRUPT);
 }
 
+// ---- streams the segment iteration cannot synchronise: fixed-length codes with context-dependent assignment
+// Two decodes that start in different contexts only ever agree again if they happen to produce the same symbol;
+// with few symbols they may never (ABCABC...: every context has one successor; 0/1 data whose two contexts map
+// the bit to opposite symbols), and the iteration then repairs one segment per pass.  But when EVERY code of
+// every live context has the same length g (the first symbol's context aside), positions are known without
+// decoding — symbol k >= 1 starts at l0 + (k - 1) g — and only the context chain is missing.  That chain is a
+// composition of maps "context at the start of a group of 2^20 symbols -> context at its end":
+//   index_ctx_scan_kernel   per context: is it live, its one code length (0: mixed or longer than P), does it
+//                           emit the stream's start context
+//   index_group_map_kernel  one thread per (group, live start context): the group's end context
+//   index_group_chain_kernel one thread: the true start context of every group
+//   index_group_fill_kernel one thread per group: the index entries of its chunks
+// Work: (live contexts + 1) x one decode, instead of a one-lane walk of the whole payload (1 GiB of "ABC": 223 s).
+__global__ __launch_bounds__(256) void index_ctx_scan_kernel(IdxParams p, uint32_t *info) {
+    const uint32_t c = threadIdx.x, span = 1u << p.P;
+    // a leaf entry carries its code length in bits 8..12; length 0 is the null entry of a context without codes
+    uint32_t live = 0, len = 0, mixed = 0, emits = 0, all_leaf = 1;
+    for (uint32_t w = 0; w < span; ++w) {
+        const uint32_t e = p.prim[(c << p.P) | w];
+        const uint32_t l = (e >> 8) & 31u;
+        if ((e & DEC16_LEAF) && l != 0) {
+            live = 1;
+            if (len == 0) len = l; else if (l != len) mixed = 1;
+            if ((e & 255u) == p.prev0) emits = 1;
+        } else {
+            all_leaf = 0;                                        // null, or an inner entry (codes longer than P)
+        }
+    }
+    info[c] = live | ((live && !mixed && all_leaf) ? len << 8 : 0u) | (emits << 16);
+}
+struct IdxFixed { const uint8_t *live; uint32_t nlive, l0, g, shift; uint64_t nsym, ngroups; uint8_t *gmap, *gstart; };   // a group = 1 << shift symbols
+__device__ __forceinline__ uint64_t idx_fixed_pos(const IdxFixed &f, uint64_t k) { return k == 0 ? 0 : f.l0 + (k - 1) * uint64_t(f.g); }
+__global__ __launch_bounds__(256) void index_group_map_kernel(IdxParams p, IdxFixed f) {
+    const uint64_t t = uint64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (t >= f.ngroups * f.nlive) return;
+    const uint64_t grp = t / f.nlive;
+    const uint32_t start_ctx = grp == 0 ? p.prev0 : f.live[t % f.nlive];
+    if (grp == 0 && t % f.nlive != 0) return;                   // group 0 starts in the stream's own context only
+    const uint64_t k0 = grp << f.shift;
+    const uint64_t k1 = (k0 + (1ull << f.shift)) < f.nsym ? k0 + (1ull << f.shift) : f.nsym;
+    const BitSrc src{p.payload, p.payload_bytes >> 2, p.payload_bytes};
+    const DecTables tabs{p.sec, p.tree, p.P, p.direct, p.H};
+    GranuleCursor bc;
+    bc.init(src, idx_fixed_pos(f, k0));
+    uint32_t prev = start_ctx;
+    bool bad = false;
+    for (uint64_t k = k0; k < k1 && !bad; ++k) {
+        uint32_t used = 0;
+        prev = decode_one(p.prim, p.sec_base, tabs, src, bc, prev, used, bad);
+    }
+    f.gmap[grp * 256 + start_ctx] = uint8_t(prev);              // a start that runs into a null entry is never the true one
+}
+__global__ void index_group_chain_kernel(IdxParams p, IdxFixed f) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    uint32_t s = p.prev0;
+    for (uint64_t grp = 0; grp < f.ngroups; ++grp) { f.gstart[grp] = uint8_t(s); s = f.gmap[grp * 256 + s]; }
+}
+__global__ __launch_bounds__(64) void index_group_fill_kernel(IdxParams p, IdxFixed f) {
+    const uint64_t grp = uint64_t(blockIdx.x) * 64 + threadIdx.x;
+    if (grp >= f.ngroups) return;
+    const uint64_t k0 = grp << f.shift;
+    const uint64_t k1 = (k0 + (1ull << f.shift)) < f.nsym ? k0 + (1ull << f.shift) : f.nsym;
+    const uint64_t smask = (1ull << p.chunk_shift) - 1;
+    const BitSrc src{p.payload, p.payload_bytes >> 2, p.payload_bytes};
+    const DecTables tabs{p.sec, p.tree, p.P, p.direct, p.H};
+    GranuleCursor bc;
+    uint64_t pos = idx_fixed_pos(f, k0);
+    bc.init(src, pos);
+    uint32_t prev = f.gstart[grp];
+    bool bad = false, overflow = false;
+    for (uint64_t k = k0; k < k1 && !bad; ++k) {
+        if ((k & smask) == 0) {
+            const uint64_t ci = k >> p.chunk_shift;
+            if (ci < p.index_cap) p.index[ci] = st_pack(prev, pos); else overflow = true;
+        }
+        uint32_t used = 0;
+        prev = decode_one(p.prim, p.sec_base, tabs, src, bc, prev, used, bad);
+        pos += used;
+    }
+    if (overflow) atomicExch(p.status, MHK_STATUS_CAPACITY);
+    // every code had the length the positions assumed, and the stream ends where its last code ends
+    if (bad || pos != idx_fixed_pos(f, k1) || (k1 == f.nsym && pos != p.nbits)) atomicExch(p.status, MHK_STATUS_CORRUPT);
+    if (k1 == f.nsym) *p.n_symbols = f.nsym;
+}
+
 // Sequential fallback (one lane) for streams whose segments refuse to synchronise: walks the whole
 // payload once.  The loop condition is the reference's `while(bi < length)` (src/coding.cpp:124).
 template <int ORDER>
@@ -2387,7 +2473,60 @@ hipError_t launch_build_index(IdxParams p, void *d_ws, hipStream_t st) {
             }
         }
     }
-    if (!converged) {      // segments that never re-synchronise: do it the slow, certain way
+    if (!converged && L.nseg < 256) {                            // (a workspace too small to hold the maps: a small stream)
+        hipLaunchKernelGGL(build_index_kernel<1>, dim3(1), dim3(64), 0, st, p);
+        return hipGetLastError();
+    }
+    if (!converged) {      // segments that never re-synchronise
+        // fixed-length codes (see index_ctx_scan_kernel): positions are arithmetic, the context chain is composed
+        // from per-group maps.  The per-segment arrays of the workspace are free again and hold the maps.
+        uint32_t *info = reinterpret_cast<uint32_t *>(p.seg_sym_start);
+        hipLaunchKernelGGL(index_ctx_scan_kernel, dim3(1), dim3(256), 0, st, p, info);
+        uint32_t h[256];
+        e = hipMemcpyAsync(h, info, sizeof h, hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) return e;
+        e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return e;
+        uint8_t live[256];
+        uint32_t nlive = 0, gfix = 0;
+        bool fixed = true, emits_prev0 = false;
+        for (uint32_t c = 0; c < 256; ++c) {
+            if (!(h[c] & 1u)) continue;
+            live[nlive++] = uint8_t(c);
+            const uint32_t l = (h[c] >> 8) & 255u;
+            if (c == p.prev0) continue;                          // the first symbol's context: looked at below
+            if (l == 0 || (gfix != 0 && l != gfix)) fixed = false;
+            gfix = gfix ? gfix : l;
+            emits_prev0 = emits_prev0 || ((h[c] >> 16) & 1u);
+        }
+        const uint32_t l0 = (h[p.prev0 & 255u] & 1u) ? (h[p.prev0 & 255u] >> 8) & 255u : 0u;
+        if (gfix == 0) gfix = l0;                                // the start context is the only live one
+        // the start context may have its own length if the stream never comes back to it
+        if (l0 == 0 || (l0 != gfix && (emits_prev0 || ((h[p.prev0 & 255u] >> 16) & 1u)))) fixed = false;
+        const uint64_t nsym = fixed && gfix && p.nbits >= l0 && (p.nbits - l0) % gfix == 0 ? (p.nbits - l0) / gfix + 1 : 0;
+        // groups as small as the workspace allows (256 bytes of map each), but not below one chunk or 16 Ki symbols:
+        // more groups = more threads for the two passes, and the chain over the groups is a single thread
+        uint32_t shift = p.chunk_shift > 14u ? p.chunk_shift : 14u;
+        uint64_t ngroups = (nsym + (1ull << shift) - 1) >> shift;
+        while (shift < 30u && (ngroups * 256 > L.off_used - L.off_end || ngroups > L.off_count - L.off_used)) {
+            ++shift;
+            ngroups = (nsym + (1ull << shift) - 1) >> shift;
+        }
+        const bool room = ngroups * 256 <= L.off_used - L.off_end && ngroups <= L.off_count - L.off_used;
+        if (p.order != 2 && fixed && nsym && room) {
+            uint8_t *d_live = reinterpret_cast<uint8_t *>(p.seg_count);
+            e = hipMemcpyAsync(d_live, live, nlive, hipMemcpyHostToDevice, st);
+            if (e != hipSuccess) return e;
+            e = hipStreamSynchronize(st);                        // `live` is on this stack frame
+            if (e != hipSuccess) return e;
+            IdxFixed f{d_live, nlive, l0, gfix, shift, nsym, ngroups, reinterpret_cast<uint8_t *>(p.seg_end_state), reinterpret_cast<uint8_t *>(p.seg_used)};
+            const uint64_t nthreads = ngroups * nlive;
+            hipLaunchKernelGGL(index_group_map_kernel, dim3(unsigned((nthreads + 255) / 256)), dim3(256), 0, st, p, f);
+            hipLaunchKernelGGL(index_group_chain_kernel, dim3(1), dim3(64), 0, st, p, f);
+            hipLaunchKernelGGL(index_group_fill_kernel, dim3(unsigned((ngroups + 63) / 64)), dim3(64), 0, st, p, f);
+            return hipGetLastError();
+        }
+        // the slow, certain way: one lane walks the payload
         if (p.order == 2) hipLaunchKernelGGL(build_index_kernel<2>, dim3(1), dim3(64), 0, st, p);
         else hipLaunchKernelGGL(build_index_kernel<1>, dim3(1), dim3(64), 0, st, p);
         return hipGetLastError();

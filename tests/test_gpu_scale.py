@@ -291,3 +291,38 @@ def test_index_free_decode_of_random_bytes_under_fixed_length_codes(mhc, oracle)
     dt = time.perf_counter() - t0
     assert out == data
     assert dt < 2.5, "index-free decode of 64 MiB took %.1f s: the one-lane walk instead of the segment iteration?" % dt
+
+
+@pytest.mark.parametrize("kind", ["period3", "two_symbols_crossed"])
+def test_index_free_decode_of_streams_whose_contexts_never_merge(mhc, oracle, kind):
+    """Streams without an index on which two decodes from different contexts never agree again: "ABCABC..."
+    (every context has one successor) and 0/1 data whose two contexts map the same bit to opposite symbols.
+    The segment iteration repairs one segment per pass there; all codes have one length, so the index builder
+    composes per-group context maps instead (positions are arithmetic).  The one-lane walk this replaces takes
+    ~14 s for these 64 Mi symbols (223 s per Gi): the time bound tells them apart."""
+    import time
+    n = 64 << 20
+    if kind == "period3":
+        data = np.tile(np.frombuffer(b"ABC", dtype=np.uint8), n // 3 + 1)[:n].tobytes()
+        om = oracle.Model.from_data(data, 1)
+    else:
+        counts = np.zeros((256, 256), dtype=np.uint64)
+        counts[0x20, 48] = 1
+        counts[48, 48], counts[48, 49] = 5, 3
+        counts[49, 48], counts[49, 49] = 3, 5
+        om = oracle.Model.from_counts(counts.reshape(-1), 1)
+        l8, c64 = om.codes()
+        c64 = np.asarray(c64).reshape(256, 256)
+        assert c64[48, 48] != c64[49, 48]                      # the same symbol, opposite bits in the two contexts
+        d = np.random.default_rng(5).integers(0, 2, n, dtype=np.uint8) + 48
+        d[0] = 48                                                # the only successor the start context ' ' has in this model
+        data = d.tobytes()
+    blob, nbits = om.compress(data)
+    assert nbits == n
+    m = mhc.Model.from_table(om.table_bytes())
+    assert m.decompress(blob[:1 + (1 << 17)]) == data[:1 << 20]          # warm-up
+    t0 = time.perf_counter()
+    out = m.decompress(blob)
+    dt = time.perf_counter() - t0
+    assert out == data
+    assert dt < 5.0, "index-free decode of 64 Mi symbols took %.1f s: the one-lane walk?" % dt
