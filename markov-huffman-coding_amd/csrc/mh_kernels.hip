@@ -1701,11 +1701,22 @@ __global__ __launch_bounds__(64) void index_group_fill_kernel(IdxParams p, IdxFi
 // Sequential fallback (one lane) for streams whose segments refuse to synchronise: walks the whole
 // payload once.  The loop condition is the reference's `while(bi < length)` (src/coding.cpp:124).
 template <int ORDER>
-__global__ void build_index_kernel(IdxParams p) {
+__global__ __launch_bounds__(64) void build_index_kernel(IdxParams p) {
+    // order 1: the first-level table goes to LDS first (the walk is one dependent lookup per symbol: 208 ns from
+    // L2, a third of that from LDS), the payload comes through the 32-byte-granule FIFO
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint16_t *prim = p.prim;
+    if (ORDER == 1) {
+        uint16_t *lut = reinterpret_cast<uint16_t *>(smem);
+        for (uint32_t k = threadIdx.x; k < (256u << p.P) / 8u; k += 64u)
+            reinterpret_cast<uint4 *>(lut)[k] = reinterpret_cast<const uint4 *>(p.prim)[k];
+        __syncthreads();
+        prim = lut;
+    }
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     const BitSrc src{p.payload, p.payload_bytes >> 2, p.payload_bytes};
     const DecTables tabs{p.sec, p.tree, p.P, p.direct, p.H};
-    BitCursor bc;
+    GranuleCursor bc;
     bc.init(src, 0);
     uint64_t bi = 0, nsym = 0;
     uint32_t prev = p.prev0;                                // order 2: the 16-bit context
@@ -1718,7 +1729,7 @@ __global__ void build_index_kernel(IdxParams p) {
             p.index[ci] = (uint64_t(prev) << (ORDER == 2 ? 48 : 56)) | bi;
         }
         uint32_t used = 0;
-        const uint32_t sym = decode_one(p.prim, p.sec_base, tabs, src, bc, prev, used, bad);
+        const uint32_t sym = decode_one(prim, p.sec_base, tabs, src, bc, prev, used, bad);
         if (bad) break;
         prev = ORDER == 2 ? (((prev << 8) | sym) & 0xFFFFu) : sym;
         bi += used;
@@ -2025,7 +2036,7 @@ __global__ __launch_bounds__(256) void decode2_kernel(DecParams p) {
 constexpr int MAX_DEVICES = 64;
 struct DeviceState {
     int cu_count = 0;
-    bool hist_ready = false, hist2_ready = false, encode_ready = false, region_ready = false, decode_ready = false;
+    bool hist_ready = false, hist2_ready = false, encode_ready = false, region_ready = false, decode_ready = false, index_ready = false;
 };
 static DeviceState g_dev[MAX_DEVICES];
 static std::mutex g_dev_mu;
@@ -2418,6 +2429,9 @@ hipError_t launch_build_index(IdxParams p, void *d_ws, hipStream_t st) {
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(p.n_symbols, 0, 8, st);
     if (e != hipSuccess || p.nbits == 0) return e;
+    e = once_per_device(&DeviceState::index_ready, [] { return allow_lds(reinterpret_cast<const void *>(build_index_kernel<1>), 131072); });
+    if (e != hipSuccess) return e;
+    if (p.P > 8) return hipErrorInvalidValue;
     if (p.order == 2) {            // order 2: the one-lane walk (the segment passes assume a one-byte context)
         hipLaunchKernelGGL(build_index_kernel<2>, dim3(1), dim3(64), 0, st, p);
         return hipGetLastError();
@@ -2474,7 +2488,7 @@ hipError_t launch_build_index(IdxParams p, void *d_ws, hipStream_t st) {
         }
     }
     if (!converged && L.nseg < 256) {                            // (a workspace too small to hold the maps: a small stream)
-        hipLaunchKernelGGL(build_index_kernel<1>, dim3(1), dim3(64), 0, st, p);
+        hipLaunchKernelGGL(build_index_kernel<1>, dim3(1), dim3(64), (size_t(256) << p.P) * 2, st, p);
         return hipGetLastError();
     }
     if (!converged) {      // segments that never re-synchronise
@@ -2528,7 +2542,7 @@ hipError_t launch_build_index(IdxParams p, void *d_ws, hipStream_t st) {
         }
         // the slow, certain way: one lane walks the payload
         if (p.order == 2) hipLaunchKernelGGL(build_index_kernel<2>, dim3(1), dim3(64), 0, st, p);
-        else hipLaunchKernelGGL(build_index_kernel<1>, dim3(1), dim3(64), 0, st, p);
+        else hipLaunchKernelGGL(build_index_kernel<1>, dim3(1), dim3(64), (size_t(256) << p.P) * 2, st, p);
         return hipGetLastError();
     }
     unsigned long long *blk_sum = reinterpret_cast<unsigned long long *>(ws + L.off_blk);
