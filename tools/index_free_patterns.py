@@ -11,6 +11,7 @@ import __graft_entry__ as entry  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=1 << 30)
 ap.add_argument("--only", default="")
+ap.add_argument("--no-index-build", action="store_true", help="only the regular round trip (encode, decode with the encoder's index)")
 a = ap.parse_args()
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
@@ -42,6 +43,12 @@ for name, make in patterns.items():
     codec.encode(model, data, 0x20)
     torch.cuda.synchronize()
     nbits = int(codec.nbits[0].item())
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); codec.decode(model); e1.record(); torch.cuda.synchronize()
+    rt = bool(torch.equal(codec.decoded, data)) and lib.mh_dev_status(codec.dec_ws.data_ptr(), codec.stream()) == 0
+    print("%-12s round trip with the encoder's index: %s, decode %.2f ms" % (name, rt, e0.elapsed_time(e1)), flush=True)
+    if a.no_index_build:
+        continue
     ws_bytes = int(lib.mh_dev_build_index_workspace(max(nbits, 1)))
     ws = torch.empty(max(ws_bytes, 64), dtype=torch.uint8, device=dev)
     idx2 = torch.zeros_like(codec.index)
