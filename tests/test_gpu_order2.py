@@ -137,3 +137,33 @@ def test_order2_large_text_round_trip_parity_unpinned(mhc, oracle):
     ref, ref_bits = oracle.Model.from_data(data, 2).compress(data)
     assert nbits == ref_bits and blob == ref
     assert m.decompress(blob, index=idx, chunk_symbols=1024, n_symbols=n) == data
+
+
+def test_order2_codes_longer_than_the_packed_entry_parity_unpinned(mhc, oracle):
+    """Fibonacci-weighted successors in every context: code lengths up to ~60 bits.  The encoder's packed
+    `length << 56 | code` entries hold codes of at most 56 bits; longer ones carry the escape length and are
+    fetched from the two full tables (and the decoder walks the tree for them)."""
+    fib = [1, 1]
+    while len(fib) < 60:
+        fib.append(fib[-1] + fib[-2])
+    row = np.zeros(256, dtype=np.uint64)
+    row[:60] = np.array(fib, dtype=np.uint64)
+    counts = np.tile(row, 65536)
+    m = mhc.Model.from_counts(counts, 2)
+    o = oracle.Model.from_counts(counts, 2)
+    lo, co = o.codes_o2()
+    lg, cg = m.codes_o2()
+    assert np.array_equal(lg, lo) and np.array_equal(cg, co)
+    lens = np.asarray(lo).reshape(65536, 256)
+    assert lens.max() > 56 and lens.max() <= 64
+    rng = np.random.default_rng(3)
+    n = (1 << 20) + 5
+    # mostly the frequent symbols (short codes), with the rare ones (longest codes) sprinkled in
+    data = (59 - np.minimum(rng.geometric(0.5, size=n) - 1, 59)).astype(np.uint8)
+    rare = rng.random(n) < 0.02
+    data[rare] = rng.integers(0, 8, size=int(rare.sum()), dtype=np.uint8)
+    data = data.tobytes()
+    blob, nbits, idx = m.compress(data, chunk_symbols=256)
+    ref, ref_bits = o.compress(data)
+    assert (nbits, blob) == (ref_bits, ref)
+    assert m.decompress(blob, index=idx, chunk_symbols=256, n_symbols=n) == data
