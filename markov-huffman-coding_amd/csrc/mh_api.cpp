@@ -950,6 +950,7 @@ int mh_dev_build_index(const mh_model *m, const uint8_t *d_payload, uint64_t nbi
     p.P = uint32_t(m->dec_bits);
     p.direct = m->dec_direct ? 1u : 0u; p.H = uint32_t(m->dec_h);
     p.len_gcd = m->len_gcd;
+    p.max_len = uint32_t(m->max_len > 0 ? m->max_len : 1);
     HIP_TRY(mhk::launch_build_index(p, d_ws, static_cast<hipStream_t>(stream)));
     return MH_OK;
 }

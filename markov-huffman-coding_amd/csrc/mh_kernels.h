@@ -110,6 +110,7 @@ struct IdxParams {
     unsigned long long *seg_end_state, *seg_used, *seg_sym_start;
     uint32_t *seg_count;
     uint32_t len_gcd;             // gcd of the model's code lengths (0/1: none)
+    uint32_t max_len;             // the model's longest code (bits)
     uint32_t seg_bits;
     uint64_t nseg;
 };

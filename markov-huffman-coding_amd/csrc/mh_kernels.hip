@@ -1698,6 +1698,89 @@ __global__ __launch_bounds__(64) void index_group_fill_kernel(IdxParams p, IdxFi
     if (k1 == f.nsym) *p.n_symbols = f.nsym;
 }
 
+// ---- the same for mixed code lengths: maps over BIT groups from (context, offset of the first code behind the
+// group's start) to (context, overshoot past its end, symbols decoded).  A run-structured stream (0...01...12...:
+// two successors per context, so decodes from different contexts never merge; the start context ' ' adds a third
+// and 2-bit codes, so positions are not arithmetic) costs (live contexts x longest code) decodes here instead of
+// the one-lane walk.  Map entry: end context | overshoot << 8 | symbols << 16, bit 63 = ran into a null entry.
+struct IdxState { const uint8_t *live; const uint8_t *inv; uint32_t nlive, maxlen, shift; uint64_t ngroups;
+                  unsigned long long *map; uint16_t *gstart; unsigned long long *gbase; };   // a group = 1 << shift bits
+constexpr unsigned long long IDX_STATE_BAD = 1ull << 63;
+__device__ __forceinline__ unsigned long long idx_state_walk(const IdxParams &p, uint64_t pos, uint64_t end, uint32_t ctx, bool last) {
+    const BitSrc src{p.payload, p.payload_bytes >> 2, p.payload_bytes};
+    const DecTables tabs{p.sec, p.tree, p.P, p.direct, p.H};
+    GranuleCursor bc;
+    bc.init(src, pos);
+    uint32_t nsym = 0;
+    bool bad = false;
+    while (pos < end) {
+        uint32_t used = 0;
+        ctx = decode_one(p.prim, p.sec_base, tabs, src, bc, ctx, used, bad);
+        if (bad) return IDX_STATE_BAD;
+        pos += used;
+        ++nsym;
+    }
+    if (last && pos != end) return IDX_STATE_BAD;                // the stream must end with its last code
+    return (unsigned long long)(ctx) | ((unsigned long long)(pos - end) << 8) | ((unsigned long long)(nsym) << 16);
+}
+__global__ __launch_bounds__(256) void index_state_map_kernel(IdxParams p, IdxState f) {
+    const uint64_t per = uint64_t(f.nlive) * f.maxlen;
+    const uint64_t t = uint64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (t >= f.ngroups * per) return;
+    const uint64_t grp = t / per;
+    const uint32_t ci = uint32_t((t % per) / f.maxlen), o = uint32_t(t % f.maxlen);
+    const uint64_t begin = (grp << f.shift) + o;
+    const bool last = grp + 1 == f.ngroups;
+    const uint64_t end = last ? p.nbits : (grp + 1) << f.shift;
+    f.map[t] = begin < end ? idx_state_walk(p, begin, end, f.live[ci], last) : IDX_STATE_BAD;
+}
+__global__ void index_state_chain_kernel(IdxParams p, IdxState f) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    uint32_t ci = f.inv[p.prev0 & 255u], o = 0;
+    unsigned long long base = 0;
+    for (uint64_t grp = 0; grp < f.ngroups; ++grp) {
+        f.gstart[grp] = uint16_t(ci | (o << 8));
+        f.gbase[grp] = base;
+        const unsigned long long e = (ci < f.nlive && o < f.maxlen) ? f.map[(grp * f.nlive + ci) * f.maxlen + o] : IDX_STATE_BAD;
+        if (e & IDX_STATE_BAD) {                                 // the true chain itself runs into nothing: not this table's stream
+            atomicExch(p.status, MHK_STATUS_CORRUPT);
+            for (uint64_t r = grp + 1; r < f.ngroups; ++r) { f.gstart[r] = 0xFFFFu; f.gbase[r] = base; }
+            break;
+        }
+        base += (e >> 16) & 0xFFFFFFFFull;
+        ci = f.inv[e & 255u];                                    // 255 for a symbol without codes of its own: fine at the very end only
+        o = uint32_t(e >> 8) & 255u;
+    }
+    *p.n_symbols = base;
+}
+__global__ __launch_bounds__(64) void index_state_fill_kernel(IdxParams p, IdxState f) {
+    const uint64_t grp = uint64_t(blockIdx.x) * 64 + threadIdx.x;
+    if (grp >= f.ngroups || f.gstart[grp] == 0xFFFFu) return;
+    const uint32_t ci = f.gstart[grp] & 255u, o = f.gstart[grp] >> 8;
+    const bool last = grp + 1 == f.ngroups;
+    const uint64_t end = last ? p.nbits : (grp + 1) << f.shift;
+    const uint64_t smask = (1ull << p.chunk_shift) - 1;
+    const BitSrc src{p.payload, p.payload_bytes >> 2, p.payload_bytes};
+    const DecTables tabs{p.sec, p.tree, p.P, p.direct, p.H};
+    GranuleCursor bc;
+    uint64_t pos = (grp << f.shift) + o, k = f.gbase[grp];
+    bc.init(src, pos);
+    uint32_t prev = f.live[ci];
+    bool bad = false, overflow = false;
+    while (pos < end && !bad) {
+        if ((k & smask) == 0) {
+            const uint64_t cidx = k >> p.chunk_shift;
+            if (cidx < p.index_cap) p.index[cidx] = st_pack(prev, pos); else overflow = true;
+        }
+        uint32_t used = 0;
+        prev = decode_one(p.prim, p.sec_base, tabs, src, bc, prev, used, bad);
+        pos += used;
+        ++k;
+    }
+    if (overflow) atomicExch(p.status, MHK_STATUS_CAPACITY);
+    if (bad || (last && pos != end)) atomicExch(p.status, MHK_STATUS_CORRUPT);
+}
+
 // Sequential fallback (one lane) for streams whose segments refuse to synchronise: walks the whole
 // payload once.  The loop condition is the reference's `while(bi < length)` (src/coding.cpp:124).
 template <int ORDER>
@@ -2539,6 +2622,34 @@ hipError_t launch_build_index(IdxParams p, void *d_ws, hipStream_t st) {
             hipLaunchKernelGGL(index_group_chain_kernel, dim3(1), dim3(64), 0, st, p, f);
             hipLaunchKernelGGL(index_group_fill_kernel, dim3(unsigned((ngroups + 63) / 64)), dim3(64), 0, st, p, f);
             return hipGetLastError();
+        }
+        // mixed code lengths: maps over bit groups from (context, offset) states (index_state_map_kernel)
+        if (p.order != 2 && nlive > 0 && p.max_len >= 1 && p.max_len <= 32) {
+            const uint32_t maxlen = p.max_len;
+            const size_t map_room = L.off_count - L.off_end;         // the per-segment end / used arrays
+            const size_t aux_room = L.off_blk - L.off_count;         // counts and symbol starts: live lists, group starts, bases
+            uint32_t shift = 16;
+            uint64_t ngroups = (p.nbits + (1ull << shift) - 1) >> shift;
+            auto fits = [&](uint64_t ng) { return ng * nlive * maxlen * 8 <= map_room && 1024 + ng * 2 + 64 + ng * 8 <= aux_room; };
+            while (shift < 40u && !fits(ngroups)) { ++shift; ngroups = (p.nbits + (1ull << shift) - 1) >> shift; }
+            if (fits(ngroups) && (1ull << shift) > maxlen) {
+                uint8_t inv[256];
+                for (uint32_t c = 0; c < 256; ++c) inv[c] = 255;
+                for (uint32_t i = 0; i < nlive; ++i) inv[live[i]] = uint8_t(i);
+                unsigned char *aux = ws + L.off_count;
+                e = hipMemcpyAsync(aux, live, 256, hipMemcpyHostToDevice, st);
+                if (e == hipSuccess) e = hipMemcpyAsync(aux + 256, inv, 256, hipMemcpyHostToDevice, st);
+                if (e == hipSuccess) e = hipStreamSynchronize(st);   // the two arrays are on this stack frame
+                if (e != hipSuccess) return e;
+                const size_t gstart_off = 1024, gbase_off = (gstart_off + ngroups * 2 + 63) & ~size_t(63);
+                IdxState f{aux, aux + 256, nlive, maxlen, shift, ngroups, reinterpret_cast<unsigned long long *>(ws + L.off_end),
+                           reinterpret_cast<uint16_t *>(aux + gstart_off), reinterpret_cast<unsigned long long *>(aux + gbase_off)};
+                const uint64_t nthreads = ngroups * nlive * maxlen;
+                hipLaunchKernelGGL(index_state_map_kernel, dim3(unsigned((nthreads + 255) / 256)), dim3(256), 0, st, p, f);
+                hipLaunchKernelGGL(index_state_chain_kernel, dim3(1), dim3(64), 0, st, p, f);
+                hipLaunchKernelGGL(index_state_fill_kernel, dim3(unsigned((ngroups + 63) / 64)), dim3(64), 0, st, p, f);
+                return hipGetLastError();
+            }
         }
         // the slow, certain way: one lane walks the payload
         if (p.order == 2) hipLaunchKernelGGL(build_index_kernel<2>, dim3(1), dim3(64), 0, st, p);
