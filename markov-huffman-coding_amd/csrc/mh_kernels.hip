@@ -15,7 +15,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 
