@@ -1525,6 +1525,11 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecParams p) {
 // counts and one more pass emit the regular chunk index.
 constexpr uint64_t ST_POS = 0x00FFFFFFFFFFFFFFull;
 __device__ __forceinline__ uint64_t st_pack(uint32_t prev, uint64_t pos) { return (uint64_t(prev) << 56) | pos; }
+// a state = context | bit position, packed like an index entry: order 1 context << 56, order 2 (two bytes) << 48
+__device__ __forceinline__ uint32_t st_shift(const IdxParams &p) { return p.order == 2 ? 48u : 56u; }
+__device__ __forceinline__ uint64_t st_make(const IdxParams &p, uint32_t ctx, uint64_t pos) { return (uint64_t(ctx) << st_shift(p)) | pos; }
+__device__ __forceinline__ uint64_t st_pos(const IdxParams &p, uint64_t s) { return s & ((1ull << st_shift(p)) - 1ull); }
+__device__ __forceinline__ uint32_t st_ctx(const IdxParams &p, uint64_t s) { return uint32_t(s >> st_shift(p)); }
 
 // Decodes from `start` until the bit position reaches seg_end.  Returns the end state; *count = symbols
 // whose code starts before seg_end.  ON_SYMBOL(k, prev_before, pos_before) is called per symbol.
@@ -1532,8 +1537,8 @@ __device__ __forceinline__ uint64_t st_pack(uint32_t prev, uint64_t pos) { retur
 template <typename F>
 __device__ __forceinline__ uint64_t walk_segment(const IdxParams &p, const DecTables &tabs, const BitSrc &src, uint64_t start,
                                                  uint64_t seg_end, uint32_t &count, bool &bad, F on_symbol) {
-    uint64_t pos = start & ST_POS;
-    uint32_t prev = uint32_t(start >> 56);
+    uint64_t pos = st_pos(p, start);
+    uint32_t prev = st_ctx(p, start);
     count = 0;
     bad = false;
     if (pos >= seg_end) return start;
@@ -1544,11 +1549,11 @@ __device__ __forceinline__ uint64_t walk_segment(const IdxParams &p, const DecTa
         uint32_t used = 0;
         uint32_t sym = decode_one(p.prim, p.sec_base, tabs, src, bc, prev, used, bad);
         if (bad) break;
-        prev = sym;
+        prev = p.order == 2 ? (((prev << 8) | sym) & 0xFFFFu) : sym;
         pos += used;
         ++count;
     }
-    return st_pack(prev, pos);
+    return st_make(p, prev, pos);
 }
 
 // `first`: first pass of an instance (every segment starts from its guess, at bit i * seg_bits + phase);
@@ -1559,8 +1564,8 @@ __global__ __launch_bounds__(256) void index_sync_kernel(IdxParams p, uint32_t i
     if (i >= p.nseg) return;
     const uint64_t seg_end = ((i + 1) * p.seg_bits) < p.nbits ? ((i + 1) * p.seg_bits) : p.nbits;
     uint64_t start;
-    if (i == 0) start = st_pack(p.prev0, 0);
-    else if (first) start = st_pack(0x20, i * p.seg_bits + phase);
+    if (i == 0) start = st_make(p, p.prev0, 0);
+    else if (first) start = st_make(p, p.order == 2 ? 0x2020u : 0x20u, i * p.seg_bits + phase);
     else start = __hip_atomic_load(&p.seg_end_state[i - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!first && start == p.seg_used[i]) return;                      // same input as last time
     const BitSrc src{p.payload, p.payload_bytes >> 2, p.payload_bytes};
@@ -1568,7 +1573,7 @@ __global__ __launch_bounds__(256) void index_sync_kernel(IdxParams p, uint32_t i
     uint32_t count;
     bool bad;
     uint64_t end = walk_segment(p, tabs, src, start, seg_end, count, bad, [](uint32_t, uint32_t, uint64_t) {});
-    if (bad) end = st_pack(uint32_t(end >> 56), seg_end);              // a guess that ran into nothing: park it
+    if (bad) end = st_make(p, st_ctx(p, end), seg_end);                // a guess that ran into nothing: park it
     __hip_atomic_store(&p.seg_end_state[i], (unsigned long long)end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     p.seg_used[i] = start;
     p.seg_count[i] = count;
@@ -1591,7 +1596,7 @@ __global__ __launch_bounds__(256) void index_fill_kernel(IdxParams p) {
     const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= p.nseg) return;
     const uint64_t seg_end = ((i + 1) * p.seg_bits) < p.nbits ? ((i + 1) * p.seg_bits) : p.nbits;
-    const uint64_t start = i == 0 ? st_pack(p.prev0, 0) : p.seg_end_state[i - 1];
+    const uint64_t start = i == 0 ? st_make(p, p.prev0, 0) : p.seg_end_state[i - 1];
     const uint64_t base = p.seg_sym_start[i];
     const uint64_t smask = (1ull << p.chunk_shift) - 1;
     const BitSrc src{p.payload, p.payload_bytes >> 2, p.payload_bytes};
@@ -1602,13 +1607,13 @@ __global__ __launch_bounds__(256) void index_fill_kernel(IdxParams p) {
         const uint64_t g = base + k;
         if ((g & smask) == 0) {
             const uint64_t ci = g >> p.chunk_shift;
-            if (ci < p.index_cap) p.index[ci] = st_pack(prev, pos); else overflow = true;
+            if (ci < p.index_cap) p.index[ci] = st_make(p, prev, pos); else overflow = true;
         }
     });
     if (overflow) atomicExch(p.status, MHK_STATUS_CAPACITY);
     // with true start states a null entry, a mismatch with the converged end state, or a stream that does
     // not end exactly at nbits (src/coding.cpp:124,158) means the stream does not belong to this table
-    if (bad || end != p.seg_end_state[i] || count != p.seg_count[i] || (i + 1 == p.nseg && (end & ST_POS) != p.nbits))
+    if (bad || end != p.seg_end_state[i] || count != p.seg_count[i] || (i + 1 == p.nseg && st_pos(p, end) != p.nbits))
         atomicExch(p.status, MHK_STATUS_CORRUPT);
 }
 
@@ -2514,10 +2519,6 @@ hipError_t launch_build_index(IdxParams p, void *d_ws, hipStream_t st) {
     e = once_per_device(&DeviceState::index_ready, [] { return allow_lds(reinterpret_cast<const void *>(build_index_kernel<1>), 131072); });
     if (e != hipSuccess) return e;
     if (p.P > 8) return hipErrorInvalidValue;
-    if (p.order == 2) {            // order 2: the one-lane walk (the segment passes assume a one-byte context)
-        hipLaunchKernelGGL(build_index_kernel<2>, dim3(1), dim3(64), 0, st, p);
-        return hipGetLastError();
-    }
     const unsigned grid = unsigned((p.nseg + 255) / 256);
     const uint64_t nblk = (p.nseg + SCAN_BLOCK - 1) / SCAN_BLOCK;
     // One instance of the iteration = a first pass from guessed starts + passes that chase the changes.
@@ -2569,8 +2570,9 @@ hipError_t launch_build_index(IdxParams p, void *d_ws, hipStream_t st) {
             }
         }
     }
-    if (!converged && L.nseg < 256) {                            // (a workspace too small to hold the maps: a small stream)
-        hipLaunchKernelGGL(build_index_kernel<1>, dim3(1), dim3(64), (size_t(256) << p.P) * 2, st, p);
+    if (!converged && (L.nseg < 256 || p.order == 2)) {          // a workspace too small to hold the maps (a small stream); order 2
+        if (p.order == 2) hipLaunchKernelGGL(build_index_kernel<2>, dim3(1), dim3(64), 0, st, p);
+        else hipLaunchKernelGGL(build_index_kernel<1>, dim3(1), dim3(64), (size_t(256) << p.P) * 2, st, p);
         return hipGetLastError();
     }
     if (!converged) {      // segments that never re-synchronise

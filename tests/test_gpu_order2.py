@@ -105,7 +105,7 @@ def test_order2_tables_stream_and_round_trip_parity_unpinned(mhc, oracle, name):
 
 @pytest.mark.parametrize("name", ["ipsum", "kat1", "one_Z", "zipf32_512k"])
 def test_order2_decode_without_index_parity_unpinned(mhc, oracle, name):
-    """No sidecar: the one-lane index walk (order 2 has no parallel index builder yet)."""
+    """No sidecar: the index builder's segment iteration with two-byte contexts (small streams: few segments)."""
     data = CASES[name]()
     o = oracle.Model.from_data(data, 2)
     blob, _ = o.compress(data)
@@ -137,6 +137,13 @@ def test_order2_large_text_round_trip_parity_unpinned(mhc, oracle):
     ref, ref_bits = oracle.Model.from_data(data, 2).compress(data)
     assert nbits == ref_bits and blob == ref
     assert m.decompress(blob, index=idx, chunk_symbols=1024, n_symbols=n) == data
+    # and without the sidecar: the segment iteration of the order-1 index builder with two-byte contexts (the one-lane
+    # walk it replaced takes ~10 s for these 32 Mi symbols)
+    import time
+    t0 = time.perf_counter()
+    assert m.decompress(blob) == data
+    dt = time.perf_counter() - t0
+    assert dt < 4.0, "order-2 decode without an index took %.1f s: the one-lane walk?" % dt
 
 
 def test_order2_codes_longer_than_the_packed_entry_parity_unpinned(mhc, oracle):
