@@ -146,6 +146,10 @@ class Codec:
         self.nidx = (n + CHUNK - 1) // CHUNK
         self.index = torch.empty(max(self.nidx, 1), dtype=torch.int64, device=device)
         self.nbits = torch.zeros(2, dtype=torch.int64, device=device)
+        # device-only fine index (one uint32 per 64 symbols): what lets a wave decode 64 adjacent pieces from one
+        # contiguous piece of the payload (mh_dev_encode_fine / mh_dev_decode_fine); MH_BENCH_NO_FINE=1: without it
+        self.use_fine = order == 1 and not os.environ.get("MH_BENCH_NO_FINE") and not os.environ.get("MH_BENCH_TWO_PASS_ENCODE")
+        self.fine = torch.empty(max((n + 63) // 64, 1), dtype=torch.int32, device=device) if self.use_fine else None
         self.hist_ws_bytes = int(self.lib.mh_dev_histogram_workspace(n))
         self.hist_ws = torch.empty(self.hist_ws_bytes, dtype=torch.uint8, device=device)
         self.enc_ws_bytes = self.lib.mh_dev_encode_workspace(n)
@@ -186,10 +190,11 @@ class Codec:
         pre-shifted by its low 3 bits so that shards concatenate with one OR-merged seam byte), or None."""
         if self.order == 1 and not os.environ.get("MH_BENCH_TWO_PASS_ENCODE"):
             # the histogram of this very buffer is in hist_ws: the encoder prices its regions from it (no length pass)
-            self.check(self.lib.mh_dev_encode_hist(model.handle, data.data_ptr(), self.n, prev0,
+            self.check(self.lib.mh_dev_encode_fine(model.handle, data.data_ptr(), self.n, prev0,
                                                    start_bit.data_ptr() if start_bit is not None else None,
                                                    self.payload.data_ptr(), self.cap,
                                                    self.nbits.data_ptr(), self.index.data_ptr(), CHUNK,
+                                                   self.fine.data_ptr() if self.use_fine else None,
                                                    self.hist_ws.data_ptr(), self.hist_ws_bytes,
                                                    self.enc_ws.data_ptr(), self.enc_ws_bytes, self.stream()), "encode")
             return
@@ -201,9 +206,10 @@ class Codec:
 
     def decode(self, model):
         """The payload length stays on the device (self.nbits[0], written by the encoder)."""
-        self.check(self.lib.mh_dev_decode_dn(model.handle, self.payload.data_ptr(), self.nbits.data_ptr(), self.nbits_hint,
-                                             self.decoded.data_ptr(), self.n, self.index.data_ptr(), CHUNK, self.dec_ws.data_ptr(),
-                                             self.dec_ws_bytes, self.stream()), "decode")
+        self.check(self.lib.mh_dev_decode_fine(model.handle, self.payload.data_ptr(), self.nbits_hint, self.nbits.data_ptr(),
+                                               self.decoded.data_ptr(), self.n, self.index.data_ptr(), CHUNK,
+                                               self.fine.data_ptr() if self.use_fine else None, self.dec_ws.data_ptr(),
+                                               self.dec_ws_bytes, self.stream()), "decode")
 
 
 def cpu_baseline(mhc, table_bytes, sample, gpu_payload_prefix_check):

@@ -123,7 +123,8 @@ int mh_model_get_lut(const mh_model *m, int prev, int w, int *present, int *is_i
 int mh_model_decode_layout(const mh_model *m, int *primary_bits, int *secondary_entries, int *in_lds);
 /* Diagnostic: copies one of the model's device images to the host (tests compare the host-built and the
  * device-built tables bit for bit).  which: 0 enc16, 1 len8, 2 len_slot, 3 code64, 4 decode prim,
- * 5 decode sec, 6 sec_base, 7 walk tree.  *bytes = image size; copied when cap suffices. */
+ * 5 decode sec, 6 sec_base, 7 walk tree, 8 / 9 the tile decoder's first- / second-level tables (LSB-first
+ * indexed, see mh_dev_decode_fine; empty when the model has none).  *bytes = image size; copied when cap suffices. */
 int mh_model_image(const mh_model *m, int which, void *out, size_t cap, size_t *bytes);
 void mh_model_free(mh_model *m);
 
@@ -306,6 +307,35 @@ int mh_dev_decode_dn(const mh_model *m, const uint8_t *d_payload, const uint64_t
                      uint8_t *d_out, uint64_t n_symbols,
                      const uint64_t *d_index, uint32_t chunk_symbols,
                      void *d_ws, size_t ws_bytes, void *stream);
+/*
+ * FINE INDEX — a device-only acceleration structure of the decoder, never part of the stream or of the sidecar
+ * index: one uint32 per MH_FINE_SYMBOLS = 64 input bytes,
+ *        entry = context byte at that byte << 24 | (payload bit offset of its code & 0xFFFFFF);
+ * the chunk index entry in front of it supplies the offset's high bits.  With it one wave decodes 64 adjacent
+ * 64-symbol pieces: its compressed input and its output are each one contiguous run of memory (mh_tile.hip)
+ * instead of 64 scattered cache lines per access.  It costs 1/16 of the input size in HBM, is written by
+ * mh_dev_encode_fine alongside the payload (or by mh_dev_build_index_fine for a stream that came without any
+ * index) and is consumed by mh_dev_decode_fine; it lives and dies in device memory.  Order-0/1 models only
+ * (an order-2 model ignores d_fine); chunk_symbols <= 4096 for the decoder to use it.
+ */
+#define MH_FINE_SYMBOLS 64u
+static inline uint64_t mh_fine_entries(uint64_t n_symbols) { return (n_symbols + MH_FINE_SYMBOLS - 1) / MH_FINE_SYMBOLS; }
+/* mh_dev_encode_hist (d_hist_ws may be NULL: then mh_dev_encode_at) that also fills d_fine[mh_fine_entries(n)]
+ * (d_fine may be NULL).  Payload, index and *d_nbits do not depend on d_fine. */
+int mh_dev_encode_fine(const mh_model *m, const uint8_t *d_data, size_t n, uint8_t prev0,
+                       const uint64_t *d_start_bit,
+                       uint8_t *d_payload, size_t cap, uint64_t *d_nbits,
+                       uint64_t *d_index, uint32_t chunk_symbols, uint32_t *d_fine,
+                       const void *d_hist_ws, size_t hist_ws_bytes,
+                       void *d_ws, size_t ws_bytes, void *stream);
+/* mh_dev_decode / mh_dev_decode_dn (d_nbits != NULL: the payload length is read there, nbits is a hint) with the
+ * fine index of the same stream.  d_fine == NULL, a model without tile tables, chunk_symbols > 4096 or a small
+ * stream: exactly mh_dev_decode.  Same output either way; same workspace size. */
+int mh_dev_decode_fine(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, const uint64_t *d_nbits,
+                       uint8_t *d_out, uint64_t n_symbols,
+                       const uint64_t *d_index, uint32_t chunk_symbols, const uint32_t *d_fine,
+                       void *d_ws, size_t ws_bytes, void *stream);
+
 /* Index building for a stream without one (what the reference writes: src/coding.cpp:35-59 has no
  * index): parallel fixed-point iteration over 512-byte bit segments — each segment is decoded from a
  * guessed state and re-decoded while its predecessor's end state changes; Huffman streams

@@ -45,6 +45,11 @@ struct mh_model {
     uint32_t *d_sec_base = nullptr;
     uint32_t *d_tree = nullptr;
     void *d_block = nullptr;     // the one allocation all of the above point into
+    // tile decoder tables (mh_tile.hip; LSB-first indexed; tile_p == 0: none)
+    int tile_p = 0, tile_h = 0;
+    uint32_t tile_nsec = 0;
+    uint16_t *d_tprim = nullptr, *d_tsec = nullptr;
+    void *d_tile_own = nullptr;  // their allocation when the model owns it
 };
 
 namespace {
@@ -72,6 +77,15 @@ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 uint32_t gcd_u32(uint32_t a, uint32_t b) {
     while (b) { const uint32_t t = a % b; a = b; b = t; }
     return a;
+}
+
+// first-level width of the tile decoder's tables (mh_tile.hip): the LDS left beside 256 << P entries is what the
+// waves stage their input in, so P trades table hits against waves in flight.  MH_TILE_P overrides (5..8; 0: no
+// tile tables).
+int tile_p_choice() {                     // (read at every model build: tests vary it inside one process)
+    const char *e = getenv("MH_TILE_P");
+    const int p = e ? atoi(e) : 7;
+    return p == 0 ? 0 : (p < 5 ? 5 : (p > 8 ? 8 : p));
 }
 
 int chunk_shift_of(uint32_t chunk_symbols) {
@@ -252,6 +266,19 @@ int upload_model(mh_model *m) {
     HIP_TRY(hipMalloc(&m->d_block, total));
     HIP_TRY(hipMemcpy(m->d_block, staging.data(), total, hipMemcpyHostToDevice));
     for (int i = 0; i < 8; ++i) *pieces[i].dst = static_cast<unsigned char *>(m->d_block) + off[i];
+    if (tile_p_choice()) {
+        const mh::Model::TilePacked tp = m->host.pack_tile(tile_p_choice());
+        if (tp.P) {
+            const size_t pb = (tp.prim.size() * 2 + 255) & ~size_t(255), sb = tp.sec.size() * 2 + 64;
+            HIP_TRY(hipMalloc(&m->d_tile_own, pb + sb));
+            HIP_TRY(hipMemset(m->d_tile_own, 0, pb + sb));
+            m->d_tprim = static_cast<uint16_t *>(m->d_tile_own);
+            m->d_tsec = reinterpret_cast<uint16_t *>(static_cast<unsigned char *>(m->d_tile_own) + pb);
+            HIP_TRY(hipMemcpy(m->d_tprim, tp.prim.data(), tp.prim.size() * 2, hipMemcpyHostToDevice));
+            if (!tp.sec.empty()) HIP_TRY(hipMemcpy(m->d_tsec, tp.sec.data(), tp.sec.size() * 2, hipMemcpyHostToDevice));
+            m->tile_p = tp.P; m->tile_h = tp.H; m->tile_nsec = uint32_t(tp.sec.size());
+        }
+    }
     return MH_OK;
 }
 
@@ -386,6 +413,8 @@ BuildLayout build_layout() {
 }
 // second-level tables: at most 32767 uniform tables of 256 entries in the L2 layout (far less in the LDS layout)
 constexpr size_t MODEL_WS_SEC_BYTES = size_t(32768) * 256 * 2 + 64;
+// the tile decoder's tables: a first level of at most 256 << 8 entries, at most 32768 second-level tables of 256
+constexpr size_t MODEL_WS_TILE_BYTES = size_t(65536) * 2 + 256 + size_t(32768) * 256 * 2 + 64 + 512;
 
 // d_ws == nullptr: the model allocates (and owns) its device memory.  Otherwise it lives in the caller's
 // workspace: no allocation, and the stream is synchronised exactly once (16 KiB of table sizes come back
@@ -479,6 +508,39 @@ int dev_model_build(const uint64_t *d_counts, void *d_ws, size_t ws_bytes, hipSt
     pa.P = uint32_t(P); pa.direct = m->dec_direct ? 1u : 0u; pa.H = uint32_t(m->dec_h); pa.hcap = 8u;
     pa.prim = m->d_prim; pa.sec = m->d_sec; pa.tree = m->d_tree;
     HIP_TRY_M(mhk::launch_tree_pack(pa, 256, st));
+    // ---- the tile decoder's tables: the same trees packed once more, LSB-first, with a first level of tile_p bits
+    if (const int tP = tile_p_choice()) {
+        const int tH = std::min(std::max(m->max_len - tP, 1), 8);
+        size_t ntab = size_t(256) << tP;
+        mhk::TreePackArgs pt{};
+        if (tP == 8) {
+            ntab = 0;
+            for (int c = 0; c < 256; ++c) { pt.sec_base_val[c] = uint32_t(ntab << tH); ntab += meta[size_t(c) * mhk::TB_META_STRIDE + 3]; }
+        } else {
+            for (int c = 0; c < 256; ++c) pt.sec_base_val[c] = uint32_t(size_t(c) << (tP + tH));
+        }
+        if (ntab <= 32767 || tP < 8) {
+            const size_t pb = ((size_t(256) << tP) * 2 + 255) & ~size_t(255), sb = (ntab << tH) * 2 + 64;
+            unsigned char *tb;
+            if (d_ws) {
+                const size_t at = (L.fixed + sec_bytes + 255) & ~size_t(255);
+                if (ws_bytes < at + pb + sb) return fail(MH_ERR_CAPACITY);
+                tb = b + at;
+            } else {
+                HIP_TRY_M(hipMalloc(&m->d_tile_own, pb + sb));
+                tb = static_cast<unsigned char *>(m->d_tile_own);
+            }
+            m->d_tprim = reinterpret_cast<uint16_t *>(tb);
+            m->d_tsec = reinterpret_cast<uint16_t *>(tb + pb);
+            HIP_TRY_M(hipMemsetAsync(m->d_tsec, 0, sb, st));
+            pt.node_left = m->d_node_left; pt.node_right = m->d_node_right; pt.node_sym = m->d_node_sym; pt.node_height = d_node_height;
+            pt.ctx_meta = m->d_meta; pt.sec_base = nullptr; pt.sec_base_in = nullptr;
+            pt.P = uint32_t(tP); pt.direct = 1u; pt.H = uint32_t(tH); pt.hcap = 8u;
+            pt.prim = m->d_tprim; pt.sec = m->d_tsec; pt.tree = nullptr; pt.lsb = 1u;
+            HIP_TRY_M(mhk::launch_tree_pack(pt, 256, st));
+            m->tile_p = tP; m->tile_h = tH; m->tile_nsec = uint32_t(ntab << tH);
+        }
+    }
 #undef HIP_TRY_M
     *out = m;
     return MH_OK;
@@ -666,7 +728,7 @@ int model2_write_table(const mh_model *m, std::vector<uint8_t> &out) {
 }
 }  // namespace
 
-size_t mh_dev_model_workspace(int order) { return order == 1 ? build_layout().fixed + MODEL_WS_SEC_BYTES : 0; }
+size_t mh_dev_model_workspace(int order) { return order == 1 ? build_layout().fixed + MODEL_WS_SEC_BYTES + MODEL_WS_TILE_BYTES : 0; }
 
 int mh_dev_model_from_counts_ws(const uint64_t *d_counts, int order, void *d_ws, size_t ws_bytes, void *stream, mh_model **out) {
     if (!d_counts || !out || order != 1 || !d_ws) return MH_ERR_ARG;
@@ -769,6 +831,8 @@ int mh_model_image(const mh_model *m, int which, void *out, size_t cap, size_t *
         case 5: src = m->d_sec; n = size_t(m->nsec) * 2; break;
         case 6: src = m->d_sec_base; n = nc * 4; break;
         case 7: src = m->d_tree; n = nc * mh::TREE_STRIDE * 4; break;
+        case 8: src = m->d_tprim; n = m->tile_p ? (size_t(256) << m->tile_p) * 2 : 0; break;
+        case 9: src = m->d_tsec; n = size_t(m->tile_nsec) * 2; break;
         default: return MH_ERR_ARG;
     }
     *bytes = n;
@@ -783,6 +847,7 @@ void mh_model_free(mh_model *m) {
     if (m->d_block) (void)hipFree(m->d_block);
     if (m->d_build) (void)hipFree(m->d_build);
     if (m->d_sec_own) (void)hipFree(m->d_sec_own);
+    if (m->d_tile_own) (void)hipFree(m->d_tile_own);
     delete m;
 }
 
@@ -828,7 +893,7 @@ int mh_dev_payload_bits(const mh_model *m, const uint64_t *d_counts, uint64_t *d
 // (byte before previous) << 8 | previous byte
 static int dev_encode_ctx(const mh_model *m, const uint8_t *d_data, size_t n, uint32_t ctx0, const uint64_t *d_start_bit,
                           uint8_t *d_payload, size_t cap, uint64_t *d_nbits, uint64_t *d_index, uint32_t chunk_symbols,
-                          void *d_ws, size_t ws_bytes, void *stream) {
+                          void *d_ws, size_t ws_bytes, void *stream, uint32_t *d_fine = nullptr) {
     if (!m || (!d_data && n) || !d_payload || !d_nbits || !d_ws) return MH_ERR_ARG;
     if (!aligned16(d_data) || !aligned16(d_payload) || !aligned16(d_ws)) return MH_ERR_ARG;
     int shift = chunk_shift_of(d_index ? chunk_symbols : MH_CHUNK_DEFAULT);
@@ -844,32 +909,52 @@ static int dev_encode_ctx(const mh_model *m, const uint8_t *d_data, size_t n, ui
     p.nbits = reinterpret_cast<unsigned long long *>(d_nbits);
     p.index = reinterpret_cast<unsigned long long *>(d_index);
     p.start_bit = reinterpret_cast<const unsigned long long *>(d_start_bit);
+    p.fine = m->type == 2 ? nullptr : d_fine;
     HIP_TRY(mhk::launch_encode(p, d_ws, static_cast<hipStream_t>(stream)));
+    return MH_OK;
+}
+
+static int dev_encode_hist(const mh_model *m, const uint8_t *d_data, size_t n, uint8_t prev0, const uint64_t *d_start_bit,
+                           uint8_t *d_payload, size_t cap, uint64_t *d_nbits, uint64_t *d_index, uint32_t chunk_symbols,
+                           const void *d_hist_ws, size_t hist_ws_bytes, void *d_ws, size_t ws_bytes, void *stream, uint32_t *d_fine) {
+    if (!m || (!d_data && n) || !d_payload || !d_nbits || !d_ws) return MH_ERR_ARG;
+    // order-2 models take the regular path; so does a caller without the workspace (codes over 12 bits are escapes
+    // inside the region encoder: src/bitbuffer.cpp:45-73 appends descriptors of any length)
+    if (m->type == 2 || !d_hist_ws || hist_ws_bytes < mhk::hist_workspace_bytes(n))
+        return dev_encode_ctx(m, d_data, n, m->type == 2 ? (uint32_t(prev0) << 8 | prev0) : prev0, d_start_bit, d_payload, cap, d_nbits, d_index,
+                              chunk_symbols, d_ws, ws_bytes, stream, d_fine);
+    if (!aligned16(d_data) || !aligned16(d_payload) || !aligned16(d_ws) || !aligned16(d_hist_ws)) return MH_ERR_ARG;
+    int shift = chunk_shift_of(d_index ? chunk_symbols : MH_CHUNK_DEFAULT);
+    if (shift < 0) return MH_ERR_ARG;
+    if (ws_bytes < mhk::encode_workspace_bytes(n)) return MH_ERR_CAPACITY;
+    if (m->max_len > mh::MAX_CODE_BITS) return MH_ERR_CODE_TOO_LONG;
+    if (!m->d_enc16) return MH_ERR_NO_DEVICE;
+    mhk::EncodeArgs p{};
+    p.order = 1;
+    p.data = d_data; p.n = n; p.prev0 = prev0; p.chunk_shift = uint32_t(shift);
+    p.out = d_payload; p.cap = cap;
+    p.enc16 = m->d_enc16; p.len_slot = m->d_len_slot; p.len8 = m->d_len8; p.code64 = m->d_code64; p.enc64 = nullptr;
+    p.nbits = reinterpret_cast<unsigned long long *>(d_nbits);
+    p.index = reinterpret_cast<unsigned long long *>(d_index);
+    p.start_bit = reinterpret_cast<const unsigned long long *>(d_start_bit);
+    p.fine = d_fine;
+    HIP_TRY(mhk::launch_encode_regions(p, d_hist_ws, hist_ws_bytes, d_ws, static_cast<hipStream_t>(stream)));
     return MH_OK;
 }
 
 int mh_dev_encode_hist(const mh_model *m, const uint8_t *d_data, size_t n, uint8_t prev0, const uint64_t *d_start_bit,
                        uint8_t *d_payload, size_t cap, uint64_t *d_nbits, uint64_t *d_index, uint32_t chunk_symbols,
                        const void *d_hist_ws, size_t hist_ws_bytes, void *d_ws, size_t ws_bytes, void *stream) {
-    if (!m || (!d_data && n) || !d_payload || !d_nbits || !d_ws) return MH_ERR_ARG;
-    // escape codes (> 12 bits) and order-2 models take the regular path; so does a caller without the workspace
-    if (m->type == 2 || m->max_len > mh::ENC16_MAX_LEN || !d_hist_ws || hist_ws_bytes < mhk::hist_workspace_bytes(n))
-        return mh_dev_encode_at(m, d_data, n, prev0, d_start_bit, d_payload, cap, d_nbits, d_index, chunk_symbols, d_ws, ws_bytes, stream);
-    if (!aligned16(d_data) || !aligned16(d_payload) || !aligned16(d_ws) || !aligned16(d_hist_ws)) return MH_ERR_ARG;
-    int shift = chunk_shift_of(d_index ? chunk_symbols : MH_CHUNK_DEFAULT);
-    if (shift < 0) return MH_ERR_ARG;
-    if (ws_bytes < mhk::encode_workspace_bytes(n)) return MH_ERR_CAPACITY;
-    if (!m->d_enc16) return MH_ERR_NO_DEVICE;
-    mhk::EncodeArgs p{};
-    p.order = 1;
-    p.data = d_data; p.n = n; p.prev0 = prev0; p.chunk_shift = uint32_t(shift);
-    p.out = d_payload; p.cap = cap;
-    p.enc16 = m->d_enc16; p.len_slot = m->d_len_slot; p.len8 = m->d_len8; p.code64 = m->d_code64; p.enc64 = m->type == 2 ? m->d_enc64 : nullptr;
-    p.nbits = reinterpret_cast<unsigned long long *>(d_nbits);
-    p.index = reinterpret_cast<unsigned long long *>(d_index);
-    p.start_bit = reinterpret_cast<const unsigned long long *>(d_start_bit);
-    HIP_TRY(mhk::launch_encode_regions(p, d_hist_ws, hist_ws_bytes, d_ws, static_cast<hipStream_t>(stream)));
-    return MH_OK;
+    return dev_encode_hist(m, d_data, n, prev0, d_start_bit, d_payload, cap, d_nbits, d_index, chunk_symbols, d_hist_ws, hist_ws_bytes,
+                           d_ws, ws_bytes, stream, nullptr);
+}
+
+int mh_dev_encode_fine(const mh_model *m, const uint8_t *d_data, size_t n, uint8_t prev0, const uint64_t *d_start_bit,
+                       uint8_t *d_payload, size_t cap, uint64_t *d_nbits, uint64_t *d_index, uint32_t chunk_symbols, uint32_t *d_fine,
+                       const void *d_hist_ws, size_t hist_ws_bytes, void *d_ws, size_t ws_bytes, void *stream) {
+    if (m && m->type == 2) d_fine = nullptr;
+    return dev_encode_hist(m, d_data, n, prev0, d_start_bit, d_payload, cap, d_nbits, d_index, chunk_symbols, d_hist_ws, hist_ws_bytes,
+                           d_ws, ws_bytes, stream, d_fine);
 }
 
 static uint32_t ctx_of_prev0(const mh_model *m, uint8_t prev0) { return m && m->type == 2 ? (uint32_t(prev0) << 8 | prev0) : prev0; }
@@ -896,8 +981,16 @@ size_t mh_dev_decode_workspace(uint64_t, uint64_t n_symbols, uint32_t chunk_symb
 
 size_t mh_dev_build_index_workspace(uint64_t nbits) { return mhk::build_index_workspace_bytes(nbits); }
 
+// MH_DECODE_PATH=tile|chunk forces the decoder choice (tests, A/B runs); otherwise the tile decoder runs whenever
+// a fine index came with the call, the model has tile tables and the stream is large enough to fill the card
+static int decode_path_choice() {        // (read at every call: tests switch inside one process)
+    const char *e = getenv("MH_DECODE_PATH");
+    return !e ? 0 : (e[0] == 't' ? 1 : (e[0] == 'c' ? 2 : 0));
+}
+
 static int dev_decode(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, const uint64_t *d_nbits, uint8_t *d_out,
-                      uint64_t n_symbols, const uint64_t *d_index, uint32_t chunk_symbols, void *d_ws, size_t ws_bytes, void *stream) {
+                      uint64_t n_symbols, const uint64_t *d_index, uint32_t chunk_symbols, void *d_ws, size_t ws_bytes, void *stream,
+                      const uint32_t *d_fine = nullptr) {
     if (!m || !d_ws || ws_bytes < 64) return MH_ERR_ARG;
     if (ws_bytes < mh_dev_decode_workspace(nbits, n_symbols, chunk_symbols)) return MH_ERR_ARG;
     if (n_symbols && (!d_payload || !d_out || !d_index)) return MH_ERR_ARG;
@@ -917,8 +1010,25 @@ static int dev_decode(const mh_model *m, const uint8_t *d_payload, uint64_t nbit
     p.prim = m->d_prim; p.sec = m->d_sec; p.sec_base = m->d_sec_base; p.tree = m->d_tree;
     p.P = uint32_t(m->dec_bits); p.nsec = m->nsec; p.sec_lds = m->dec_lds ? 1u : 0u;
     p.direct = m->dec_direct ? 1u : 0u; p.H = uint32_t(m->dec_h);
+    const int path = decode_path_choice();
+    const bool tile_ok = d_fine && m->tile_p && m->type != 2 && shift <= 12 && path != 2;
+    if (tile_ok && (path == 1 || n_symbols >= (uint64_t(8) << 20))) {
+        mhk::TileParams t{};
+        t.payload = d_payload; t.payload_bytes = p.payload_bytes; t.nbits = nbits; t.d_nbits = p.d_nbits;
+        t.out = d_out; t.n = n_symbols; t.index = p.index; t.nchunks = p.nchunks; t.chunk_shift = p.chunk_shift;
+        t.fine = d_fine;
+        t.prim = m->d_tprim; t.sec = m->d_tsec; t.P = uint32_t(m->tile_p); t.H = uint32_t(m->tile_h); t.nsec = m->tile_nsec;
+        HIP_TRY(mhk::launch_decode_tile(t, p, d_ws, static_cast<hipStream_t>(stream)));
+        return MH_OK;
+    }
     HIP_TRY(mhk::launch_decode(p, d_ws, static_cast<hipStream_t>(stream)));
     return MH_OK;
+}
+
+int mh_dev_decode_fine(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, const uint64_t *d_nbits, uint8_t *d_out,
+                       uint64_t n_symbols, const uint64_t *d_index, uint32_t chunk_symbols, const uint32_t *d_fine,
+                       void *d_ws, size_t ws_bytes, void *stream) {
+    return dev_decode(m, d_payload, nbits, d_nbits, d_out, n_symbols, d_index, chunk_symbols, d_ws, ws_bytes, stream, d_fine);
 }
 
 int mh_dev_decode(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, uint8_t *d_out, uint64_t n_symbols,

@@ -27,6 +27,7 @@ struct EncodeArgs {
     unsigned long long *nbits;    // out: payload bits
     unsigned long long *index;    // out: chunk index or nullptr
     const unsigned long long *start_bit;   // device: global bit position of this payload (low 3 bits used) or nullptr
+    uint32_t *fine;               // out, optional: the device-only fine index (TileParams), one entry per 64 input bytes
 };
 
 struct LenParams {
@@ -62,6 +63,7 @@ struct EmitParams {
     uint64_t nwt;
     unsigned long long *index;
     const int *status;
+    uint32_t *fine;               // optional: fine index (see TileParams)
 };
 
 struct DecParams {
@@ -88,6 +90,38 @@ struct DecParams {
     uint32_t *redo;               // [0] = number of chunks handed to the redo pass, [1..] their numbers (nchunks capacity)
 };
 
+// ---- tile decoder (mh_tile.hip) ----------------------------------------------------------------------------
+// The FINE INDEX is a device-only acceleration structure (never part of the sidecar file): one uint32 per
+// T_SUB = 64 symbols, entry = context byte at the sub-chunk's first symbol << 24 | (payload bit offset of that
+// symbol & 0xFFFFFF).  The full offset is recovered from the chunk index entry in front of it (a chunk holds
+// far fewer than 2^24 bits).  With it a WAVE decodes 64 adjacent sub-chunks: its compressed bytes are one
+// contiguous piece of the payload (staged through LDS with coalesced loads) and so is its output.
+constexpr int T_SUB_SHIFT = 6;
+constexpr uint32_t FINE_POS_MASK = 0x00FFFFFFu;
+struct TileParams {
+    const uint8_t *payload;
+    uint64_t payload_bytes;
+    uint64_t nbits;
+    const unsigned long long *d_nbits;   // when not null the kernels read the payload length from here
+    uint8_t *out;
+    uint64_t n;                          // symbols to produce
+    const unsigned long long *index;     // chunk index (order 1: context << 56 | bit offset)
+    uint64_t nchunks;
+    uint32_t chunk_shift;
+    const uint32_t *fine;                // (n + 63) / 64 entries
+    const uint16_t *prim;                // 256 << P entries, indexed ctx << P | first P stream bits LSB-first
+    const uint16_t *sec;                 // uniform tables of 2^H entries, indexed LSB-first; table id = inner prim entry
+    uint32_t P, H, nsec;
+    int *status;
+    uint32_t *redo;                      // [0] = count, [1..] chunk numbers handed to the redo pass (legacy tables)
+    uint32_t *geom;                      // [0] = largest staged piece of a wave (bytes), written by tile_geom_kernel
+    uint64_t ntiles;                     // full wave pieces (K tiles of 4096 symbols each)
+};
+size_t decode_tile_workspace_extra();    // bytes the tile decoder needs in front of the redo list (status block included)
+hipError_t launch_decode_tile(TileParams p, const DecParams &legacy, void *d_ws, hipStream_t st);
+// the redo pass of launch_decode alone (chunks listed in p.redo; legacy tables)
+hipError_t launch_decode_redo(DecParams p, hipStream_t st);
+
 struct IdxParams {
     int order;
     const uint8_t *payload;
@@ -113,6 +147,7 @@ struct IdxParams {
     uint32_t max_len;             // the model's longest code (bits)
     uint32_t seg_bits;
     uint64_t nseg;
+    uint32_t *fine;               // optional: fine index entries written by the fill passes (see TileParams)
 };
 
 // ---- device tree build (mh_tree.hip)
@@ -135,6 +170,8 @@ struct TreePackArgs {
     const uint32_t *sec_base_in;  // order 2: 65536 offsets in device memory (then sec_base_val is unused)
     uint32_t P, direct, H, hcap;
     uint16_t *prim, *sec; uint32_t *tree;
+    uint32_t lsb;                 // 1: tables indexed by the window's bits LSB-first (first stream bit = bit 0): the
+                                  // tile decoder's layout (mh_tile.hip); 0: MSB-first (first stream bit = top bit)
 };
 hipError_t launch_tree_build(const unsigned long long *d_counts, int nctx, const TreeBuildOut &o, hipStream_t st);
 hipError_t launch_tree_pack(const TreePackArgs &a, int nctx, hipStream_t st);

@@ -543,6 +543,8 @@ __device__ __forceinline__ void emit_substep_slow(const EmitParams &p, const uin
     const uint32_t S = 1u << p.chunk_shift;
     if (p.index && nvalid && ((uint32_t(off) & (S - 1u)) == 0u))
         p.index[off >> p.chunk_shift] = (uint64_t(pb) << (ORDER == 2 ? 48 : 56)) | (abs_bits + exc);
+    if (ORDER != 2 && p.fine && nvalid && (lane & 3u) == 0u)         // every fourth lane starts a 64-symbol sub-chunk
+        p.fine[off >> T_SUB_SHIFT] = (pb << 24) | (uint32_t(abs_bits + exc) & FINE_POS_MASK);
 
     const uint32_t end = cur + sub_bits;     // image bit one past the sub-step (frame of this sub-step)
     const uint32_t nwords = uint32_t(E_STAGE_WORDS - 2);
@@ -657,6 +659,8 @@ __global__ __launch_bounds__(E_THREADS) void enc_emit_kernel(EmitParams p) {
             // chunk index: the lane whose first byte starts a chunk records (context, bit offset)
             if (p.index && nvalid && ((uint32_t(off) & (S - 1u)) == 0u))
                 p.index[off >> p.chunk_shift] = (uint64_t(pb) << 56) | (abs_bits + exc);
+            if (p.fine && nvalid && (lane & 3u) == 0u)             // fine index (mh_kernels.h, TileParams): every fourth lane
+                p.fine[off >> T_SUB_SHIFT] = (pb << 24) | (uint32_t(abs_bits + exc) & FINE_POS_MASK);
             uint32_t o = cur + exc;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -769,9 +773,58 @@ __global__ __launch_bounds__(SCAN_THREADS) void region_scan_kernel(const unsigne
 
 struct RegionParams {
     const unsigned long long *region_start;
+    const unsigned long long *region_bits;   // what region_bits_kernel priced each region at
     uint64_t region_vecs;         // vectors (16 bytes) per region, a multiple of 1024
     uint64_t nvec_up;             // ceil(n / 16)
+    uint64_t cap_words;           // output dwords that may be stored (capacity / 4)
+    int *status;                  // writable: a region that emits something else than it was priced at reports MHK_STATUS_CORRUPT
 };
+constexpr uint32_t R_IMG_CAP_BITS = E_WAVES * E_STAGE_BITS;      // what one round may deposit beside the carried partial word
+
+// One symbol of a lane's vector at a time (the escape path: codes over 12 bits come from the full tables in L2).
+struct Roll1 {
+    uint4 x; uint32_t prev;
+    __device__ __forceinline__ uint32_t next_window() {         // sym << 8 | prev, the raw 16-bit field of the stream
+        const uint32_t sym = x.x & 255u;
+        const uint32_t win = (sym << 8) | prev;
+        prev = sym;
+        x.x = __builtin_amdgcn_alignbyte(x.y, x.x, 1);
+        x.y = __builtin_amdgcn_alignbyte(x.z, x.y, 1);
+        x.z = __builtin_amdgcn_alignbyte(x.w, x.z, 1);
+        x.w >>= 8;
+        return win;
+    }
+};
+__device__ __forceinline__ void code_of1(const uint8_t *len8, const uint64_t *code64, const uint16_t *tab, uint32_t win, bool valid, uint32_t &l, uint64_t &c) {
+    const uint32_t e = valid ? uint32_t(tab[mh::enc_slot(win)]) : 0u;
+    l = e >> 12;
+    c = e & 0xFFFu;
+    if (e >= 0xD000u) {                                          // ENC16_ESCAPE: longer than 12 bits
+        const uint32_t nat = ((win & 255u) << 8) | (win >> 8);   // prev * 256 + sym
+        l = len8[nat];
+        c = code64[nat];
+        if (l > 64u) { l = 0; c = 0; }                           // rejected on the host
+    }
+}
+// bits of the lane's vector / its codes OR-ed into the image from bit `o` on, symbol by symbol
+__device__ __forceinline__ uint32_t region_escape_bits(const uint8_t *len8, const uint64_t *code64, const uint16_t *tab, uint4 x, uint32_t pb, uint32_t nvalid) {
+    Roll1 r{x, pb};
+    uint32_t L = 0;
+#pragma unroll 1
+    for (uint32_t j = 0; j < 16; ++j) { uint32_t l; uint64_t c; code_of1(len8, code64, tab, r.next_window(), j < nvalid, l, c); L += l; }
+    return L;
+}
+__device__ __forceinline__ void region_escape_deposit(const uint8_t *len8, const uint64_t *code64, const uint16_t *tab, uint32_t *img, uint4 x,
+                                                   uint32_t pb, uint32_t nvalid, uint32_t o) {
+    Roll1 r{x, pb};
+#pragma unroll 1
+    for (uint32_t j = 0; j < 16; ++j) {
+        uint32_t l; uint64_t c;
+        code_of1(len8, code64, tab, r.next_window(), j < nvalid, l, c);
+        if (l) deposit<false>(img, c << (64u - l), o, 0, 0);
+        o += l;
+    }
+}
 
 __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, RegionParams rp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -795,6 +848,10 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
     uint64_t gbase = s0 >> 5, abs_round = s0;
     uint32_t cur = uint32_t(s0 & 31u);
     bool seam_first = cur != 0;                  // the region's first dword is shared with its predecessor
+    // The image's partial last word travels from round to round in a REGISTER of the thread that read (and
+    // cleared) its 16-byte group during the flush, and is OR-ed back into word 0 behind the next round's first
+    // barrier: no thread ever reads a word that another thread's clear may touch in the same phase.
+    uint32_t carry = 0;
 
     auto fetch = [&](uint64_t r) -> LaneIn {
         const uint64_t v = v0 + r * E_THREADS + tid;
@@ -806,6 +863,33 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
         slots16(in.x, pb, w);
 #pragma unroll
         for (int j = 0; j < 16; ++j) e[j] = uint32_t(tab[w[j]]);
+    };
+    // the workgroup stores image words [0, nfull) to output dwords gbase + j (coalesced, MSB-first bytes) and
+    // clears them; four words per lane: one 16-byte LDS read, one 16-byte clear, one 16-byte store.  The group
+    // that holds word nfull (the partial tail) is visited too: its reader returns that word.
+    auto flush = [&](uint32_t nfull) -> uint32_t {
+        uint32_t tail = 0;
+        for (uint32_t j = tid * 4u; j <= nfull; j += E_THREADS * 4u) {
+            const uint4 w = *reinterpret_cast<const uint4 *>(img + j);
+            *reinterpret_cast<uint4 *>(img + j) = make_uint4(0, 0, 0, 0);
+            const uint32_t v[4] = {__builtin_bswap32(w.x), __builtin_bswap32(w.y), __builtin_bswap32(w.z), __builtin_bswap32(w.w)};
+            if (j + 4u <= nfull && !(j == 0 && seam_first) && gbase + j + 4u <= rp.cap_words) {
+                struct __attribute__((packed, aligned(4))) Q4 { uint32_t a, b, c, d; };
+                *reinterpret_cast<Q4 *>(out32 + gbase + j) = Q4{v[0], v[1], v[2], v[3]};
+            } else {
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; ++k) {
+                    if (j + k >= nfull || gbase + j + k >= rp.cap_words) break;      // (beyond the capacity: only when the histogram was not this input's)
+                    if (j + k == 0 && seam_first) atomicOr(&out32[gbase], v[k]);
+                    else out32[gbase + j + k] = v[k];
+                }
+            }
+            if (nfull - j < 4u) {
+                const uint32_t k = nfull - j;
+                tail = k == 0 ? w.x : k == 1 ? w.y : k == 2 ? w.z : w.w;
+            }
+        }
+        return tail;
     };
     LaneIn cur_in = fetch(0), next_in = fetch(1), next2_in = fetch(2);
     uint32_t cur_pb = head_byte(cur_in);
@@ -824,9 +908,13 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
         }
         uint32_t L = 0;
         uint64_t g[4]; uint32_t gl[4];
+        uint32_t emax = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const uint32_t e0 = E[4 * q], e1 = E[4 * q + 1], e2 = E[4 * q + 2], e3 = E[4 * q + 3];
+            const uint32_t m01 = e0 > e1 ? e0 : e1, m23 = e2 > e3 ? e2 : e3;
+            emax = emax > m01 ? emax : m01;
+            emax = emax > m23 ? emax : m23;
             const uint32_t l0 = e0 >> 12, l1 = e1 >> 12, l2 = e2 >> 12, l3 = e3 >> 12;
             const uint32_t p01 = ((e0 & 0xFFFu) << l1) | (e1 & 0xFFFu);
             const uint32_t p23 = ((e2 & 0xFFFu) << l3) | (e3 & 0xFFFu);
@@ -834,9 +922,16 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
             gl[q] = l0 + l1 + l2 + l3;
             L += gl[q];
         }
+        // a code of more than 12 bits among the lane's 16 (entry ENC16_ESCAPE): that lane prices and deposits its
+        // symbols one by one from the full tables (src/bitbuffer.cpp:45-73 appends descriptors of any length)
+        const bool esc = emax >= 0xD000u;
+        if (__any(esc)) {                        // wave-uniform
+            if (esc) L = region_escape_bits(p.len8, p.code64, tab, cur_in.x, cur_pb, nvalid);
+        }
         const uint32_t inc = wave_inclusive_sum(L);
         if (lane == 63) sb[wave] = inc;          // the piece's bit count
         __syncthreads();
+        if (carry) { atomicOr(&img[0], carry); carry = 0; }      // the previous round's partial word (every clear is behind the barrier)
         // bits of the round in front of this wave / in the whole round: every row of 16 lanes scans the 16 counts
         // (one LDS read, four DPP adds, two readlanes instead of sixteen scalar reads and selects: this sits
         // between the barrier and the deposits, where the whole workgroup waits for it)
@@ -852,40 +947,44 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
         const uint64_t off = (v0 + r * E_THREADS + tid) * E_VEC;
         if (p.index && nvalid && ((uint32_t(off) & (S - 1u)) == 0u))
             p.index[off >> p.chunk_shift] = (uint64_t(cur_pb) << 56) | (abs_round + exc);
-        uint32_t o = cur + exc;
+        if (p.fine && nvalid && (lane & 3u) == 0u)               // fine index (mh_kernels.h, TileParams): every fourth lane
+            p.fine[off >> T_SUB_SHIFT] = (cur_pb << 24) | (uint32_t(abs_round + exc) & FINE_POS_MASK);
+        if (cur + tot <= R_IMG_CAP_BITS) {       // workgroup-uniform: the round fits the image (always, without escapes)
+            uint32_t o = cur + exc;
+            if (!esc) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (gl[q]) deposit<false>(img, g[q] << (64u - gl[q]), o, 0, 0);
-            o += gl[q];
-        }
-        __syncthreads();
-        // the workgroup flushes the image: full words out (coalesced), the partial last word becomes word 0
-        // (four words per lane: one 16-byte LDS read, one 16-byte clear, one 16-byte store)
-        const uint32_t nfull = (cur + tot) >> 5;
-        const uint32_t carry = tid == 0 ? img[nfull] : 0u;       // read before anyone clears it
-        for (uint32_t j = tid * 4u; j < nfull; j += E_THREADS * 4u) {
-            const uint4 w = *reinterpret_cast<const uint4 *>(img + j);
-            *reinterpret_cast<uint4 *>(img + j) = make_uint4(0, 0, 0, 0);
-            const uint32_t v[4] = {__builtin_bswap32(w.x), __builtin_bswap32(w.y), __builtin_bswap32(w.z), __builtin_bswap32(w.w)};
-            if (j + 4u <= nfull && !(j == 0 && seam_first)) {
-                struct __attribute__((packed, aligned(4))) Q4 { uint32_t a, b, c, d; };
-                *reinterpret_cast<Q4 *>(out32 + gbase + j) = Q4{v[0], v[1], v[2], v[3]};
-            } else {
-#pragma unroll
-                for (uint32_t k = 0; k < 4u; ++k) {
-                    if (j + k >= nfull) break;
-                    if (j + k == 0 && seam_first) atomicOr(&out32[gbase], v[k]);
-                    else out32[gbase + j + k] = v[k];
+                for (int q = 0; q < 4; ++q) {
+                    if (gl[q]) deposit<false>(img, g[q] << (64u - gl[q]), o, 0, 0);
+                    o += gl[q];
                 }
+            } else {
+                region_escape_deposit(p.len8, p.code64, tab, img, cur_in.x, cur_pb, nvalid, o);
+            }
+            __syncthreads();
+            const uint32_t nfull = (cur + tot) >> 5;
+            carry = flush(nfull);
+            // no barrier here: the next round touches the image only behind ITS first barrier (the exchange of the
+            // bit counts), which every wave reaches after its share of this flush
+            seam_first = seam_first && nfull == 0;
+            gbase += nfull;
+            cur = (cur + tot) & 31u;
+        } else {
+            // more bits than the image holds (only a model with many codes far over 12 bits can do that): one
+            // wave's piece at a time — at most 1024 x 64 bits — each deposited symbol by symbol and flushed
+            for (uint32_t m = 0; m < uint32_t(E_WAVES); ++m) {
+                const uint32_t upto = uint32_t(__builtin_amdgcn_readlane(int(cs), int(m)));
+                const uint32_t before = m ? uint32_t(__builtin_amdgcn_readlane(int(cs), int(m) - 1)) : 0u;
+                if (wave == m) region_escape_deposit(p.len8, p.code64, tab, img, cur_in.x, cur_pb, nvalid, cur + (exc - pre));
+                __syncthreads();
+                const uint32_t nfull = (cur + (upto - before)) >> 5;
+                const uint32_t t = flush(nfull);
+                seam_first = seam_first && nfull == 0;
+                gbase += nfull;
+                cur = (cur + (upto - before)) & 31u;
+                __syncthreads();                 // the flush's clears are done before anything is OR-ed in again
+                if (t) atomicOr(&img[0], t);
             }
         }
-        // the partial word moves to the front (when nfull is a multiple of 4 no 16-byte clear covered it)
-        if (tid == 0 && nfull > 0) { img[nfull] = 0; img[0] = carry; }
-        // no barrier here: the next round touches the image only behind ITS first barrier (the exchange of the
-        // bit counts), which every wave reaches after its share of this flush
-        seam_first = seam_first && nfull == 0;
-        gbase += nfull;
-        cur = (cur + tot) & 31u;
         abs_round += tot;
         cur_in = next_in; cur_pb = next_pb;
         next_in = next2_in;
@@ -894,7 +993,13 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
         for (int j = 0; j < 16; ++j) E[j] = En[j];
     }
     // the region's last partial dword: shared with the next region (or the stream's end), zeroed by the scan
-    if (cur != 0 && tid == 0) atomicOr(&out32[gbase], __builtin_bswap32(img[0]));
+    if (cur != 0 && gbase < rp.cap_words) {
+        if (carry) atomicOr(&out32[gbase], __builtin_bswap32(carry));
+        else if (tid == 0 && img[0]) atomicOr(&out32[gbase], __builtin_bswap32(img[0]));   // (left by the piece-by-piece path)
+    }
+    // The region was priced from the histogram workspace; if the buffer was refilled between the histogram and
+    // this call the counts are another input's and the regions overlap or leave gaps: say so.
+    if (tid == 0 && abs_round != s0 + rp.region_bits[blockIdx.x]) atomicExch(rp.status, MHK_STATUS_CORRUPT);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2123,7 +2228,7 @@ __global__ __launch_bounds__(256) void decode2_kernel(DecParams p) {
 constexpr int MAX_DEVICES = 64;
 struct DeviceState {
     int cu_count = 0;
-    bool hist_ready = false, hist2_ready = false, encode_ready = false, region_ready = false, decode_ready = false, index_ready = false;
+    bool hist_ready = false, hist2_ready = false, encode_ready = false, region_ready = false, decode_ready = false, redo_ready = false, index_ready = false;
 };
 static DeviceState g_dev[MAX_DEVICES];
 static std::mutex g_dev_mu;
@@ -2326,7 +2431,8 @@ hipError_t launch_encode(const EncodeArgs &a, void *d_ws, hipStream_t st) {
     ScanParams sp{wt_start, blk_sum, L.nwt, L.nblk, a.out, a.cap & ~uint64_t(3), a.nbits, status};
     hipLaunchKernelGGL(scan_apply_kernel, dim3(unsigned(L.nblk)), dim3(SCAN_THREADS), 0, st, sp);
 
-    EmitParams ep{a.data, a.n, a.prev0, a.chunk_shift, a.out, a.enc16, a.len8, a.code64, a.enc64, wt_start, L.nwt, a.index, status};
+    EmitParams ep{a.data, a.n, a.prev0, a.chunk_shift, a.out, a.enc16, a.len8, a.code64, a.enc64, wt_start, L.nwt, a.index, status,
+                  a.order == 2 ? nullptr : a.fine};
     if (a.order == 2) {                                      // no table in LDS: two workgroups per CU
         hipLaunchKernelGGL(enc2_emit_kernel, dim3(grid), dim3(E_THREADS), E_WAVES * E_STAGE_WORDS * 4, st, ep);
         return hipGetLastError();
@@ -2362,8 +2468,8 @@ hipError_t launch_encode_regions(const EncodeArgs &a, const void *d_hist_ws, siz
                        region_bits, status);
     hipLaunchKernelGGL(region_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, region_bits, uint32_t(g.grid), region_start, a.start_bit,
                        a.out, a.cap & ~uint64_t(3), a.nbits, status);
-    EmitParams ep{a.data, a.n, a.prev0, a.chunk_shift, a.out, a.enc16, a.len8, a.code64, nullptr, nullptr, 0, a.index, status};
-    RegionParams rp{region_start, g.region_vecs, g.nvec_up};
+    EmitParams ep{a.data, a.n, a.prev0, a.chunk_shift, a.out, a.enc16, a.len8, a.code64, nullptr, nullptr, 0, a.index, status, a.fine};
+    RegionParams rp{region_start, region_bits, g.region_vecs, g.nvec_up, (a.cap & ~uint64_t(3)) >> 2, status};
     hipLaunchKernelGGL(enc_region_kernel, dim3(g.grid), dim3(E_THREADS), REGION_LDS_BYTES, st, ep, rp);
     return hipGetLastError();
 }
@@ -2377,6 +2483,30 @@ __global__ __launch_bounds__(256) void enc64_pack_kernel(const uint8_t *len8, co
 hipError_t launch_enc64_pack(const uint8_t *len8, const uint64_t *code64, uint64_t *enc64, uint64_t n, hipStream_t st) {
     hipLaunchKernelGGL(enc64_pack_kernel, dim3(unsigned(cu_count()) * 8u), dim3(256), 0, st, len8,
                        reinterpret_cast<const unsigned long long *>(code64), reinterpret_cast<unsigned long long *>(enc64), n);
+    return hipGetLastError();
+}
+
+// The redo pass: one lane per chunk listed in p.redo (count in [0]), runtime table widths, with the tree walk for
+// codes longer than both table levels.  Normally the list is empty and the launch returns at once.
+hipError_t launch_decode_redo(DecParams p, hipStream_t st) {
+    auto r_lds = decode_kernel<true, 2, false, 1, 8, 1, 0, 0, true>;
+    auto r_l2 = decode_kernel<false, 2, false, 1, 8, 1, 0, 0, true>;
+    auto r_l2d = decode_kernel<false, 2, true, 1, 8, 1, 0, 0, true>;
+    hipError_t e = once_per_device(&DeviceState::redo_ready, [&] {
+        const void *all[] = {(const void *)r_lds, (const void *)r_l2, (const void *)r_l2d};
+        for (const void *f : all) {
+            hipError_t r = allow_lds(f, DEC_LDS_MAX);
+            if (r != hipSuccess) return r;
+        }
+        return hipSuccess;
+    });
+    if (e != hipSuccess) return e;
+    if (!p.sec_lds && p.P != 8) return hipErrorInvalidValue;
+    const size_t lds = 1024 + (size_t(256) << p.P) * 2 + (p.sec_lds ? ((size_t(p.nsec) * 2 + 15) & ~size_t(15)) : 0);
+    if (lds > size_t(DEC_LDS_MAX)) return hipErrorInvalidValue;
+    const uint64_t rwant = (p.nchunks + DEC_THREADS - 1) / DEC_THREADS;
+    const int rgrid = int(rwant > uint64_t(cu_count()) ? uint64_t(cu_count()) : rwant);
+    hipLaunchKernelGGL(p.sec_lds ? r_lds : p.direct ? r_l2d : r_l2, dim3(rgrid < 1 ? 1 : rgrid), dim3(DEC_THREADS), lds, st, p);
     return hipGetLastError();
 }
 
@@ -2428,15 +2558,10 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
 #define L2D(SPRV, HCV) decode_kernel<false, SPRV, true, MH_L2D_K, MH_L2D_GW, MH_L2D_OUTB, 8, HCV, false, MH_L2D_NT, MH_L2D_DEPTH>
     void (*k_l2d[9])(DecParams) = {L2D(2, 0), L2D(2, 0), L2D(2, 2), L2D(2, 3), L2D(2, 4), L2D(2, 0), L2D(2, 0), L2D(2, 0), L2D(2, 8)};
 #undef L2D
-    // redo pass (one lane per handed-over chunk, runtime table widths)
-    auto r_lds = decode_kernel<true, 2, false, 1, 8, 1, 0, 0, true>;
-    auto r_l2 = decode_kernel<false, 2, false, 1, 8, 1, 0, 0, true>;
-    auto r_l2d = decode_kernel<false, 2, true, 1, 8, 1, 0, 0, true>;
     e = once_per_device(&DeviceState::decode_ready, [&] {
         const void *all[] = {(const void *)k_lds2_light[0], (const void *)k_lds2_light[1],
                              (const void *)k_lds4, (const void *)k_lds4_light, (const void *)k_l2, (const void *)k_l2d[0], (const void *)k_l2d[2],
-                             (const void *)k_l2d[3], (const void *)k_l2d[4], (const void *)k_l2d[8],
-                             (const void *)r_lds, (const void *)r_l2, (const void *)r_l2d};
+                             (const void *)k_l2d[3], (const void *)k_l2d[4], (const void *)k_l2d[8]};
         for (const void *f : all) {
             hipError_t r = allow_lds(f, DEC_LDS_MAX);
             if (r != hipSuccess) return r;
@@ -2466,10 +2591,7 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     // chunks with a code longer than both table levels: normally none, and the pass returns at once
-    const uint64_t rwant = (p.nchunks + DEC_THREADS - 1) / DEC_THREADS;
-    const int rgrid = int(rwant > uint64_t(cu_count()) ? uint64_t(cu_count()) : rwant);
-    hipLaunchKernelGGL(p.sec_lds ? r_lds : p.direct ? r_l2d : r_l2, dim3(rgrid), dim3(DEC_THREADS), lds, st, p);
-    return hipGetLastError();
+    return launch_decode_redo(p, st);
 }
 
 // workspace: [0,64) status | changed u32[IDX_MAX_PASSES] | end_state u64[nseg] | used u64[nseg] |

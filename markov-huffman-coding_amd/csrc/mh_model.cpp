@@ -458,4 +458,50 @@ Model::Packed Model::pack() const {
     return pk;
 }
 
+static uint32_t bit_reverse(uint32_t v, int width) {
+    uint32_t r = 0;
+    for (int i = 0; i < width; ++i) r |= ((v >> i) & 1u) << (width - 1 - i);
+    return r;
+}
+
+Model::TilePacked Model::pack_tile(int P) const {
+    TilePacked t;
+    if (P < 5 || P > 8) return t;
+    const int max_len = max_code_len();
+    const int H = std::min(std::max(max_len - P, 1), 8);
+    const int nctx = type ? 256 : 1;
+    // the MSB-first images of every context (pack_decode with uniform tables: an inner entry is the table's rank
+    // within its context in path order), then the LSB-first permutation
+    std::vector<std::vector<uint16_t>> prim_of(nctx), sec_of(nctx);
+    parallel_for(nctx, [&](int c) {
+        prim_of[c].assign(size_t(1) << P, DEC16_NULL);
+        uint32_t tree[TREE_STRIDE];
+        ctx[c].pack_decode(P, 8, H, prim_of[c].data(), sec_of[c], 0, tree);
+    });
+    std::vector<size_t> first_id(256, 0);
+    size_t ntab = size_t(256) << P;
+    if (P == 8) {
+        ntab = 0;
+        for (int c = 0; c < 256; ++c) { first_id[c] = ntab; ntab += sec_of[type ? c : 0].size() >> H; }
+        if (ntab > 32767) return t;
+    } else {
+        for (int c = 0; c < 256; ++c) first_id[c] = size_t(c) << P;
+    }
+    t.P = P; t.H = H;
+    t.prim.assign(size_t(256) << P, DEC16_NULL);
+    t.sec.assign(ntab << H, 0);
+    parallel_for(256, [&](int c) {
+        const std::vector<uint16_t> &pm = prim_of[type ? c : 0], &sm = sec_of[type ? c : 0];
+        size_t rank = 0;
+        for (uint32_t v = 0; v < (1u << P); ++v) {               // tables are laid out by increasing LSB-first window value
+            const uint16_t e = pm[bit_reverse(v, P)];
+            if (e & DEC16_LEAF) { t.prim[(size_t(c) << P) | v] = e; continue; }
+            const size_t id = first_id[c] + rank++;
+            t.prim[(size_t(c) << P) | v] = uint16_t(id);
+            for (uint32_t x = 0; x < (1u << H); ++x) t.sec[(id << H) + x] = sm[(size_t(e) << H) + bit_reverse(x, H)];
+        }
+    });
+    return t;
+}
+
 }  // namespace mh

@@ -182,6 +182,14 @@ public:
         bool any_escape = false;
     };
     Packed pack() const;
+
+    // Tables of the tile decoder (mh_tile.hip): first level of P bits (5..8) per context, uniform second-level
+    // tables of 2^H entries (H = min(max(max_len - P, 1), 8)), BOTH indexed by the window's bits LSB-first (first
+    // stream bit = bit 0).  An inner first-level entry is the global table id; context c's tables start at id
+    // c << P (P <= 7; sparse: most ids stay unused) or at the running count of depth-8 inner nodes (P = 8; then
+    // empty when there are more than 32767 such nodes).  Same images as tree_pack_kernel with lsb = 1.
+    struct TilePacked { int P = 0, H = 0; std::vector<uint16_t> prim, sec; };
+    TilePacked pack_tile(int P) const;
 };
 
 }  // namespace mh

@@ -1,0 +1,322 @@
+// mh_tile.hip — the wave-contiguous ("tile") decoder of the order-1 hot path.
+//
+// decode_kernel (mh_kernels.hip) gives every lane its own 1024-symbol chunk: a lane's compressed bytes are
+// ~0.7 KiB from its neighbour's, so every 32-byte input granule and every 64-byte output burst is a cache line
+// of its own — 64 lines per wave instruction, 2.3x the algorithmic HBM traffic, the vector-memory pipe 63 % busy.
+// Here a WAVE decodes 64 ADJACENT sub-chunks of 64 symbols (one per lane; K such tiles side by side): with the
+// device-only fine index (mh_kernels.h, TileParams: context byte + bit offset per 64 symbols, written by the
+// encoders and by the index builder) the wave's input is ONE contiguous piece of the payload — about 3 KiB per
+// tile for Zipf(1.1) — and its output one contiguous 4 KiB per tile:
+//   * the piece is loaded with coalesced 16-byte loads, bit-reversed inside its bytes (so that the first stream
+//     bit of a dword is bit 0) and parked in a wave-private LDS region: every payload byte crosses the memory
+//     pipe once, in whole lines;
+//   * a lane's bit window is two LDS dwords and one v_alignbit — no register FIFO, no refill branches, ~12
+//     registers of state per stream instead of ~60, so sixteen waves per CU run instead of eight;
+//   * tables are indexed LSB-first (tree_pack_kernel, lsb = 1): first level (P bits, P <= 8) in LDS, uniform
+//     second-level tables (2^H entries) gathered from L2 by every lane through a bounds-checked buffer load
+//     (a leaf entry used as a table id lands past the end of the table: answered with 0, no cache access);
+//   * 64 symbols per stream end in four 16-byte stores per lane; adjacent lanes complete whole lines.
+// The LDS not taken by the first-level table is divided into the waves' regions; tile_geom_kernel finds the
+// largest piece any wave will stage, and the workgroup sizes its regions (and the number of waves it keeps) from
+// that: nothing is assumed about the compression ratio, locally or globally.
+// Chunks the tiles do not cover (the stream's ragged end, pieces larger than the whole LDS, codes longer than
+// P + H bits) go to the redo pass of the chunk decoder (one lane per chunk, legacy tables, tree walk).
+// Reference semantics: i_coding_provider::decompress, src/coding.cpp:118-157; bit order src/bitbuffer.cpp:12.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdlib>
+#include <mutex>
+
+#include "mh_kernels.h"
+#include "mh_model.hpp"
+
+namespace mhk {
+
+using mh::DEC16_LEAF;
+
+constexpr int T_SUB = 1 << T_SUB_SHIFT;          // symbols per sub-chunk = per fine-index entry
+constexpr int T_TILE = 64 * T_SUB;               // symbols per tile: one sub-chunk per lane
+constexpr int T_THREADS = 1024;
+constexpr int T_WAVES = T_THREADS / 64;
+constexpr int T_LDS_BYTES = 163840;
+constexpr uint64_t T_POS_MASK = 0x00FFFFFFFFFFFFFFull;
+
+// bit offset of sub-chunk j's first symbol: the chunk index entry in front of it supplies the high bits
+__device__ __forceinline__ uint64_t sub_pos(const TileParams &p, uint64_t j, uint32_t f) {
+    const uint64_t base = p.index[(j << T_SUB_SHIFT) >> p.chunk_shift] & T_POS_MASK;
+    return base + ((f - uint32_t(base)) & FINE_POS_MASK);
+}
+
+// first payload byte a wave stages for a piece that starts at bit `start` (16-byte aligned), and the byte count
+__device__ __forceinline__ uint64_t stage_first(uint64_t start) { return (start >> 3) & ~uint64_t(15); }
+
+// ---- geometry: the largest piece any wave stages ----------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void tile_geom_kernel(TileParams p, uint32_t cap_bytes) {
+    if (p.d_nbits) p.nbits = *p.d_nbits;
+    const uint64_t nsub = (p.n + T_SUB - 1) >> T_SUB_SHIFT;
+    uint32_t mx = 0;
+    for (uint64_t t = uint64_t(blockIdx.x) * 256 + threadIdx.x; t < p.ntiles; t += uint64_t(gridDim.x) * 256) {
+        const uint64_t j0 = t * (64u * K), j1 = j0 + 64u * K;
+        const uint64_t start = sub_pos(p, j0, p.fine[j0]);
+        const uint64_t end = j1 < nsub ? sub_pos(p, j1, p.fine[j1]) : p.nbits;
+        if (end < start || end > p.nbits) continue;               // the decoder reports it
+        const uint64_t bytes = ((end + 7) >> 3) - stage_first(start);
+        if (bytes <= cap_bytes && uint32_t(bytes) > mx) mx = uint32_t(bytes);
+    }
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
+    if ((threadIdx.x & 63u) == 0 && mx) atomicMax(&p.geom[0], mx);
+}
+
+// LDS through absolute byte addresses: the kernel's address arithmetic happens on plain integers (a pointer
+// derived from `smem` costs an add of the segment's base, which the compiler does not fold, on every access)
+typedef __attribute__((address_space(3))) const uint32_t lds_u32;
+template <typename T>
+__device__ __forceinline__ __attribute__((address_space(3))) const T *lds_ptr(uint32_t byte_addr) {
+    return reinterpret_cast<__attribute__((address_space(3))) const T *>(byte_addr);
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const void *generic) {
+    return uint32_t(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) const void *)(generic)));
+}
+
+// inserts the low byte of `e` as byte j of `d`
+__device__ __forceinline__ uint32_t tile_put_byte(uint32_t d, uint32_t e, int j) {
+    const uint32_t sel = j == 0 ? 0x03020104u : j == 1 ? 0x03020400u : j == 2 ? 0x03040100u : 0x04020100u;
+    return __builtin_amdgcn_perm(e, d, sel);
+}
+
+// K tiles per wave, PC = first-level width (compile time), HC = second-level height (0: read p.H)
+template <int K, int PC, int HC>
+__global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr uint32_t P = PC;
+    constexpr uint32_t PRIM_BYTES = (256u << P) * 2u;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (p.d_nbits) {
+        p.nbits = *p.d_nbits;
+        p.payload_bytes = (p.nbits + 7) >> 3;
+    }
+    uint16_t *lut = reinterpret_cast<uint16_t *>(smem);
+    for (uint32_t i = tid; i < PRIM_BYTES / 16u; i += T_THREADS)
+        reinterpret_cast<uint4 *>(lut)[i] = reinterpret_cast<const uint4 *>(p.prim)[i];
+    __syncthreads();
+    // ---- the waves' LDS regions: as many waves as regions of the largest piece fit (the rest leave)
+    const uint32_t free_bytes = uint32_t(T_LDS_BYTES) - PRIM_BYTES;
+    const uint32_t maxb = p.geom[0];
+    uint32_t region = (maxb + 15u + 16u) & ~15u;                  // + the dword behind the last one a window read may touch
+    uint32_t nw = free_bytes / region;
+    if (nw == 0) { nw = 1; region = free_bytes & ~15u; }
+    if (nw > uint32_t(T_WAVES)) nw = T_WAVES;
+    const uint32_t H = HC ? uint32_t(HC) : p.H;
+    const uint32_t S = 1u << p.chunk_shift;
+    const uint64_t nsub = (p.n + T_SUB - 1) >> T_SUB_SHIFT;
+    constexpr uint32_t TSYM = uint32_t(K) * T_TILE;               // symbols per wave piece
+    // ---- what the tiles do not cover: the chunks behind the last full piece (block 0, wave 0)
+    if (blockIdx.x == 0 && wave == 0) {
+        const uint64_t c_first = (p.ntiles * TSYM) >> p.chunk_shift;
+        for (uint64_t c = c_first + lane; c < p.nchunks; c += 64) p.redo[1u + atomicAdd(p.redo, 1u)] = uint32_t(c);
+    }
+    if (wave >= nw) return;                                       // no barrier below this line
+    unsigned char *reg = smem + PRIM_BYTES + wave * region;
+    if (lds_addr_of(smem) != 0u) {                                // the first-level table is addressed from LDS address 0
+        if (tid == 0) atomicExch(p.status, MHK_STATUS_CORRUPT);
+        return;
+    }
+    const uint32_t reg_bit0 = lds_addr_of(reg) * 8u;              // LDS bit address of the region's first bit
+    const __amdgpu_buffer_rsrc_t sec_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.sec), 0, int((p.nsec + 8u) * 2u), 0x00020000);
+    const uint32_t chunks_per_tile = T_TILE >> p.chunk_shift;     // >= 1: chunk_shift <= 12 (launch_decode_tile)
+
+    for (uint64_t t = uint64_t(blockIdx.x) * nw + wave; t < p.ntiles; t += uint64_t(gridDim.x) * nw) {
+        // ---- positions: lane l, stream k decodes sub-chunk j = (t * K + k) * 64 + l
+        uint64_t pos[K];
+        uint32_t cf[K];                                           // low byte: the context (previous symbol)
+        const uint64_t j0 = t * (64u * K);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint64_t j = j0 + uint64_t(k) * 64u + lane;
+            const uint32_t f = p.fine[j];
+            pos[k] = sub_pos(p, j, f);
+            cf[k] = f >> 24;
+        }
+        const uint64_t jn = j0 + 64u * K;
+        uint64_t end = p.nbits;
+        if (jn < nsub) end = sub_pos(p, jn, p.fine[jn]);          // same address in every lane
+        const uint64_t start = __shfl(pos[0], 0);
+        const uint64_t b0 = stage_first(start);
+        const uint64_t nbytes = ((end + 7) >> 3) - b0;
+        // every sub-chunk starts inside the piece, in order (a damaged index fails here, not in the loop)
+        bool sane = end >= start && end <= p.nbits;
+#pragma unroll
+        for (int k = 0; k < K; ++k) sane = sane && pos[k] >= start && pos[k] <= end;
+        if (!__all(sane)) {
+            if (lane == 0) atomicExch(p.status, MHK_STATUS_CORRUPT);
+            continue;
+        }
+        if (nbytes + 16u > region) {                              // larger than anything the LDS can hold: chunk decoder
+            const uint64_t c0 = (t * TSYM) >> p.chunk_shift;
+            for (uint32_t c = lane; c < chunks_per_tile * K; c += 64) p.redo[1u + atomicAdd(p.redo, 1u)] = uint32_t(c0 + c);
+            continue;
+        }
+        // ---- stage the piece: coalesced 16-byte loads, bits reversed inside every byte, so that stream bit i of
+        // the piece sits at bit i & 31 of LDS dword i >> 5
+        {
+            const uint4 *src = reinterpret_cast<const uint4 *>(p.payload + b0);
+            const uint32_t nvec = uint32_t((nbytes + 15) >> 4);
+            for (uint32_t i = lane; i < nvec; i += 64u) {
+                uint4 v = src[i];
+                v.x = __builtin_bswap32(__builtin_bitreverse32(v.x));
+                v.y = __builtin_bswap32(__builtin_bitreverse32(v.y));
+                v.z = __builtin_bswap32(__builtin_bitreverse32(v.z));
+                v.w = __builtin_bswap32(__builtin_bitreverse32(v.w));
+                *reinterpret_cast<uint4 *>(reg + i * 16u) = v;
+            }
+            // the dword behind the piece (a window may read it) holds zero bits (src/bitbuffer.cpp:116-127)
+            if (lane == 0) *reinterpret_cast<uint4 *>(reg + nvec * 16u) = make_uint4(0, 0, 0, 0);
+        }
+        // LDS operations of one wave execute in order: the reads below see the writes above
+        uint32_t q[K], q0[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) { q[k] = reg_bit0 + uint32_t(pos[k] - b0 * 8u); q0[k] = q[k]; }
+        uint32_t leafacc = DEC16_LEAF;
+        uint4 Q[K][4];
+        // One symbol of every stream per step, in four phases that the scheduler may not mix (it otherwise finishes
+        // one stream's window before it asks for the next one's: two LDS round trips in a row instead of one):
+        //   A  window dwords on their way (one ds_read2_b32 per stream)
+        //   B  window = alignbit, first-level lookups on their way
+        //   C  second-level gathers on their way (every lane; a leaf indexes past the end: 0, no cache access)
+        //   D  the resolving entry, position, context, output byte
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                             // 16 symbols -> one uint4 per stream
+            uint32_t w4[K][4];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                uint32_t w0[K], w1[K], win[K], e[K], e2[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const lds_u32 *wp = lds_ptr<uint32_t>((q[k] >> 3) & ~3u);
+                    w0[k] = wp[0];
+                    w1[k] = wp[1];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    win[k] = __builtin_amdgcn_alignbit(w1[k], w0[k], q[k]);           // 32 stream bits from bit q on, first in bit 0
+                    // byte address of the entry (the table starts at LDS address 0, checked at entry): context << (P + 1) | bits << 1
+                    const uint32_t csh = P == 7 ? __builtin_amdgcn_perm(0u, cf[k], 0x0C0C000Cu)       // byte 0 -> byte 1
+                                                : (cf[k] & 255u) << (P + 1);
+                    e[k] = *lds_ptr<uint16_t>(((win[k] << 1) & ((2u << P) - 2u)) | csh);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const uint32_t idx2 = (e[k] << (H + 1)) | ((win[k] >> (P - 1)) & ((2u << H) - 2u));   // byte offset of the entry
+                    e2[k] = uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(sec_rsrc, int(idx2), 0, 0)));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    uint32_t ef;
+                    asm("v_max_u32 %0, %1, %2" : "=v"(ef) : "v"(e[k]), "v"(e2[k]));    // (opaque: keeps the value a plain 32-bit one)
+                    leafacc &= ef;
+                    q[k] += __builtin_amdgcn_ubfe(ef, 8, 5);
+                    cf[k] = ef;
+                    w4[k][j >> 2] = (j & 3) == 0 ? (ef & 255u) : tile_put_byte(w4[k][j >> 2], ef, j & 3);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) Q[k][u] = make_uint4(w4[k][0], w4[k][1], w4[k][2], w4[k][3]);
+        }
+        // ---- output: 64 bytes per stream, adjacent lanes adjacent
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            uint4 *o16 = reinterpret_cast<uint4 *>(p.out + ((j0 + uint64_t(k) * 64u + lane) << T_SUB_SHIFT));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) o16[u] = Q[k][u];
+        }
+        // ---- every sub-chunk must end exactly where the next one starts (null entries, a wrong table or a damaged
+        // stream all miss it); a code that neither table level resolves sends the tile's chunks to the redo pass
+        const uint32_t qend = reg_bit0 + uint32_t(end - b0 * 8u);
+        bool bad = false;
+        uint32_t unresolved = (leafacc & DEC16_LEAF) ? 0u : 1u;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            uint32_t nxt = __shfl_down(q0[k], 1);
+            const uint32_t first_of_next = k + 1 < K ? __shfl(q0[k + 1 < K ? k + 1 : k], 0) : qend;
+            if (lane == 63) nxt = first_of_next;
+            bad = bad || q[k] != nxt;
+        }
+        if (__any(unresolved)) {                                  // rare: all chunks of this piece again, with the walk
+            const uint64_t c0 = (t * TSYM) >> p.chunk_shift;
+            for (uint32_t c = lane; c < chunks_per_tile * K; c += 64) p.redo[1u + atomicAdd(p.redo, 1u)] = uint32_t(c0 + c);
+        } else if (__any(bad)) {
+            if (lane == 0) atomicExch(p.status, MHK_STATUS_CORRUPT);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+static std::mutex g_tile_mu;
+static bool g_tile_ready[4][64];
+
+size_t decode_tile_workspace_extra() { return 64; }
+
+
+template <int K>
+static hipError_t launch_tile_k(TileParams p, const DecParams &legacy, void *d_ws, hipStream_t st) {
+    void (*kern[9])(TileParams) = {nullptr, nullptr, nullptr, nullptr, nullptr, decode_tile_kernel<K, 5, 0>, decode_tile_kernel<K, 6, 0>,
+                                   decode_tile_kernel<K, 7, 0>, decode_tile_kernel<K, 8, 0>};
+    if (p.P < 5 || p.P > 8) return hipErrorInvalidValue;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    {
+        std::lock_guard<std::mutex> lock(g_tile_mu);
+        if (dev >= 0 && dev < 64 && !g_tile_ready[K][dev]) {
+            for (int P = 5; P <= 8; ++P) {
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern[P]), hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
+                if (e != hipSuccess) return e;
+            }
+            g_tile_ready[K][dev] = true;
+        }
+    }
+    hipDeviceProp_t prop;
+    static int cus = 0;
+    if (cus == 0) cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    p.ntiles = p.n / (uint64_t(K) * T_TILE);
+    // workspace: [0,64) status | [64, 64 + 16) redo count ... as launch_decode lays it out; the geometry word lives in
+    // the status block (bytes 32..35)
+    p.status = reinterpret_cast<int *>(d_ws);
+    p.geom = reinterpret_cast<uint32_t *>(static_cast<char *>(d_ws) + 32);
+    p.redo = reinterpret_cast<uint32_t *>(static_cast<char *>(d_ws) + 64);
+    e = hipMemsetAsync(d_ws, 0, 64 + 16, st);
+    if (e != hipSuccess) return e;
+    if (p.ntiles) {
+        const uint32_t cap = uint32_t(T_LDS_BYTES) - ((256u << p.P) * 2u) - 32u;
+        const uint64_t gwant = (p.ntiles + 255) / 256;
+        hipLaunchKernelGGL((tile_geom_kernel<K>), dim3(unsigned(gwant > 1024 ? 1024 : gwant)), dim3(256), 0, st, p, cap);
+    }
+    // one workgroup per CU (the first-level table takes most of the LDS); with few pieces, fewer workgroups
+    const uint64_t want = (p.ntiles + T_WAVES - 1) / T_WAVES;
+    const unsigned grid = unsigned(want < 1 ? 1 : (want > uint64_t(cus) ? uint64_t(cus) : want));
+    hipLaunchKernelGGL(kern[p.P], dim3(grid), dim3(T_THREADS), T_LDS_BYTES, st, p);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    DecParams r = legacy;
+    r.status = p.status;
+    r.redo = p.redo;
+    return launch_decode_redo(r, st);
+}
+
+hipError_t launch_decode_tile(TileParams p, const DecParams &legacy, void *d_ws, hipStream_t st) {
+    if (p.chunk_shift > 12 || p.chunk_shift < T_SUB_SHIFT) return hipErrorInvalidValue;
+    // tiles per wave: 2 by default; MH_TILE_K (1..3) for A/B runs
+    const char *e = getenv("MH_TILE_K");
+    const int k = e ? atoi(e) : 2;
+    if (k == 1) return launch_tile_k<1>(p, legacy, d_ws, st);
+    if (k == 3) return launch_tile_k<3>(p, legacy, d_ws, st);
+    return launch_tile_k<2>(p, legacy, d_ws, st);
+}
+
+}  // namespace mhk

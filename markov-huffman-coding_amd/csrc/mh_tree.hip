@@ -394,10 +394,10 @@ __global__ __launch_bounds__(256) void tree_pack_kernel(TreePackArgs a) {
     __syncthreads();
     const uint32_t P = a.P, nprim = 1u << P;
     const uint32_t my_base = a.sec_base_in ? a.sec_base_in[c] : a.sec_base_val[c];
-    if (tid == 0 && !a.sec_base_in) a.sec_base[c] = my_base;
+    if (tid == 0 && !a.sec_base_in && a.sec_base) a.sec_base[c] = my_base;
     if (root == 0xFFFFFFFFu) {                       // empty context: null tables
         if (tid < nprim) a.prim[(c << P) | tid] = DEC16_NULL;
-        a.tree[c * TREE_STRIDE + tid] = 0;
+        if (a.tree) a.tree[c * TREE_STRIDE + tid] = 0;
         return;
     }
     if (tid == 0) {                                   // inner-node ids for the walk: root = 0, the rest in node order
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void tree_pack_kernel(TreePackArgs a) {
     uint32_t node = root, depth = 0, tabsize = 0, h = 0;
     if (tid < nprim) {
         while (depth < P && left[node] != NONE) {
-            const uint32_t bit = (tid >> (P - 1 - depth)) & 1u;
+            const uint32_t bit = a.lsb ? (tid >> depth) & 1u : (tid >> (P - 1 - depth)) & 1u;
             node = bit ? right[node] : left[node];
             ++depth;
         }
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256) void tree_pack_kernel(TreePackArgs a) {
         for (uint32_t x = 0; x < tabsize; ++x) {
             uint32_t n2 = node, d2 = 0;
             while (d2 < h && left[n2] != NONE) {
-                const uint32_t bit = (x >> (h - 1 - d2)) & 1u;
+                const uint32_t bit = a.lsb ? (x >> d2) & 1u : (x >> (h - 1 - d2)) & 1u;
                 n2 = bit ? right[n2] : left[n2];
                 ++d2;
             }
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256) void tree_pack_kernel(TreePackArgs a) {
         }
     }
     __syncthreads();
-    a.tree[c * TREE_STRIDE + tid] = tr[tid];
+    if (a.tree) a.tree[c * TREE_STRIDE + tid] = tr[tid];      // (a second packing of the same trees leaves the walk tree alone)
 }
 
 hipError_t launch_tree_build(const unsigned long long *d_counts, int nctx, const TreeBuildOut &o, hipStream_t st) {
