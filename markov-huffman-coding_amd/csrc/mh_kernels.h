@@ -116,6 +116,7 @@ struct TileParams {
     uint32_t *redo;                      // [0] = count, [1..] chunk numbers handed to the redo pass (legacy tables)
     uint32_t *geom;                      // [0] = largest staged piece of a wave (bytes), written by tile_geom_kernel
     uint64_t ntiles;                     // full wave pieces (K tiles of 4096 symbols each)
+    uint32_t probe;                      // timing probes (MH_TILE_PROBE): results are wrong and nothing is reported
 };
 size_t decode_tile_workspace_extra();    // bytes the tile decoder needs in front of the redo list (status block included)
 hipError_t launch_decode_tile(TileParams p, const DecParams &legacy, void *d_ws, hipStream_t st);

@@ -72,9 +72,14 @@ __global__ __launch_bounds__(256) void tile_geom_kernel(TileParams p, uint32_t c
 // LDS through absolute byte addresses: the kernel's address arithmetic happens on plain integers (a pointer
 // derived from `smem` costs an add of the segment's base, which the compiler does not fold, on every access)
 typedef __attribute__((address_space(3))) const uint32_t lds_u32;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <typename T>
 __device__ __forceinline__ __attribute__((address_space(3))) const T *lds_ptr(uint32_t byte_addr) {
     return reinterpret_cast<__attribute__((address_space(3))) const T *>(byte_addr);
+}
+template <typename T>
+__device__ __forceinline__ __attribute__((address_space(3))) T *lds_wptr(uint32_t byte_addr) {
+    return reinterpret_cast<__attribute__((address_space(3))) T *>(byte_addr);
 }
 __device__ __forceinline__ uint32_t lds_addr_of(const void *generic) {
     return uint32_t(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) const void *)(generic)));
@@ -87,7 +92,10 @@ __device__ __forceinline__ uint32_t tile_put_byte(uint32_t d, uint32_t e, int j)
 }
 
 // K tiles per wave, PC = first-level width (compile time), HC = second-level height (0: read p.H)
-template <int K, int PC, int HC>
+// OUT: how a stream's 64 bytes leave (A/B, MH_TILE_OUT): 0 = a 16-byte store per 16 symbols (adjacent lanes 64 bytes apart),
+// 1 = four such stores back to back at the end of the tile, 2 = through the wave's LDS region, transposed, so that every
+// store instruction writes one contiguous KiB
+template <int K, int PC, int HC, int OUT>
 __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr uint32_t P = PC;
@@ -105,6 +113,7 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
     const uint32_t free_bytes = uint32_t(T_LDS_BYTES) - PRIM_BYTES;
     const uint32_t maxb = p.geom[0];
     uint32_t region = (maxb + 15u + 16u) & ~15u;                  // + the dword behind the last one a window read may touch
+    if (OUT == 2 && region < 1024u) region = 1024u;               // the output transposition needs one KiB
     uint32_t nw = free_bytes / region;
     if (nw == 0) { nw = 1; region = free_bytes & ~15u; }
     if (nw > uint32_t(T_WAVES)) nw = T_WAVES;
@@ -125,7 +134,7 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
     }
     const uint32_t reg_bit0 = lds_addr_of(reg) * 8u;              // LDS bit address of the region's first bit
     const __amdgpu_buffer_rsrc_t sec_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.sec), 0, int((p.nsec + 8u) * 2u), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.sec), 0, p.nsec ? int((p.nsec + 8u) * 2u) : 0, 0x00020000);
     const uint32_t chunks_per_tile = T_TILE >> p.chunk_shift;     // >= 1: chunk_shift <= 12 (launch_decode_tile)
 
     for (uint64_t t = uint64_t(blockIdx.x) * nw + wave; t < p.ntiles; t += uint64_t(gridDim.x) * nw) {
@@ -180,15 +189,18 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
 #pragma unroll
         for (int k = 0; k < K; ++k) { q[k] = reg_bit0 + uint32_t(pos[k] - b0 * 8u); q0[k] = q[k]; }
         uint32_t leafacc = DEC16_LEAF;
-        uint4 Q[K][4];
+        uint4 *o16[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) o16[k] = reinterpret_cast<uint4 *>(p.out + ((j0 + uint64_t(k) * 64u + lane) << T_SUB_SHIFT));
+        uint4 Q[OUT ? K : 1][4];                                  // OUT 1, 2: the stream's 64 bytes; the pieces rotate through
         // One symbol of every stream per step, in four phases that the scheduler may not mix (it otherwise finishes
         // one stream's window before it asks for the next one's: two LDS round trips in a row instead of one):
         //   A  window dwords on their way (one ds_read2_b32 per stream)
         //   B  window = alignbit, first-level lookups on their way
         //   C  second-level gathers on their way (every lane; a leaf indexes past the end: 0, no cache access)
         //   D  the resolving entry, position, context, output byte
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {                             // 16 symbols -> one uint4 per stream
+#pragma unroll 1
+        for (int u = 0; u < 4; ++u) {                             // 16 symbols -> one 16-byte store per stream
             uint32_t w4[K][4];
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
@@ -226,14 +238,43 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
                 }
             }
 #pragma unroll
-            for (int k = 0; k < K; ++k) Q[k][u] = make_uint4(w4[k][0], w4[k][1], w4[k][2], w4[k][3]);
+            for (int k = 0; k < K; ++k) {
+                const uint4 v = make_uint4(w4[k][0], w4[k][1], w4[k][2], w4[k][3]);
+                if (OUT == 0) o16[k][u] = v;
+                else { Q[k][0] = Q[k][1]; Q[k][1] = Q[k][2]; Q[k][2] = Q[k][3]; Q[k][3] = v; }
+            }
         }
-        // ---- output: 64 bytes per stream, adjacent lanes adjacent
+        if (OUT == 1) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            uint4 *o16 = reinterpret_cast<uint4 *>(p.out + ((j0 + uint64_t(k) * 64u + lane) << T_SUB_SHIFT));
+            for (int k = 0; k < K; ++k)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) o16[u] = Q[k][u];
+                for (int u = 0; u < 4; ++u) o16[k][u] = Q[k][u];
+        }
+        if (OUT == 2) {
+            // The input piece is used up: its LDS region now turns the tile's 64 x 64 bytes around, one KiB (16 lanes'
+            // pieces) at a time, so that every store instruction writes 64 x 16 contiguous bytes.  A lane's piece u goes
+            // to slot u ^ (lane >> 1 & 3) of its 64 bytes: the eight lanes one ds_write_b128 group serves then hit eight
+            // different bank quads.
+            const uint32_t rb = reg_bit0 >> 3;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if ((lane >> 4) == uint32_t(g)) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            *lds_wptr<u32x4>(rb + (lane & 15u) * 64u + ((uint32_t(u) ^ ((lane >> 1) & 3u)) << 4)) =
+                                u32x4{Q[k][u].x, Q[k][u].y, Q[k][u].z, Q[k][u].w};
+                    }
+                    __builtin_amdgcn_wave_barrier();                    // (compiler fence: other lanes' writes, same wave, in order)
+                    asm volatile("" ::: "memory");
+                    const uint32_t l = lane >> 2, u = lane & 3u;       // reader: piece u of lane l (within the group)
+                    const u32x4 v = *lds_ptr<u32x4>(rb + l * 64u + ((u ^ ((l >> 1) & 3u)) << 4));
+                    reinterpret_cast<uint4 *>(p.out + ((j0 + uint64_t(k) * 64u + uint32_t(g) * 16u) << T_SUB_SHIFT))[lane] = make_uint4(v.x, v.y, v.z, v.w);
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("" ::: "memory");
+                }
+            }
         }
         // ---- every sub-chunk must end exactly where the next one starts (null entries, a wrong table or a damaged
         // stream all miss it); a code that neither table level resolves sends the tile's chunks to the redo pass
@@ -247,6 +288,7 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
             if (lane == 63) nxt = first_of_next;
             bad = bad || q[k] != nxt;
         }
+        if (p.probe) continue;
         if (__any(unresolved)) {                                  // rare: all chunks of this piece again, with the walk
             const uint64_t c0 = (t * TSYM) >> p.chunk_shift;
             for (uint32_t c = lane; c < chunks_per_tile * K; c += 64) p.redo[1u + atomicAdd(p.redo, 1u)] = uint32_t(c0 + c);
@@ -258,27 +300,27 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
 
 // ------------------------------------------------------------------------------------------------
 static std::mutex g_tile_mu;
-static bool g_tile_ready[4][64];
+static bool g_tile_ready[3][5][64];
 
 size_t decode_tile_workspace_extra() { return 64; }
 
 
-template <int K>
+template <int K, int OUT>
 static hipError_t launch_tile_k(TileParams p, const DecParams &legacy, void *d_ws, hipStream_t st) {
-    void (*kern[9])(TileParams) = {nullptr, nullptr, nullptr, nullptr, nullptr, decode_tile_kernel<K, 5, 0>, decode_tile_kernel<K, 6, 0>,
-                                   decode_tile_kernel<K, 7, 0>, decode_tile_kernel<K, 8, 0>};
+    void (*kern[9])(TileParams) = {nullptr, nullptr, nullptr, nullptr, nullptr, decode_tile_kernel<K, 5, 0, OUT>, decode_tile_kernel<K, 6, 0, OUT>,
+                                   decode_tile_kernel<K, 7, 0, OUT>, decode_tile_kernel<K, 8, 0, OUT>};
     if (p.P < 5 || p.P > 8) return hipErrorInvalidValue;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     {
         std::lock_guard<std::mutex> lock(g_tile_mu);
-        if (dev >= 0 && dev < 64 && !g_tile_ready[K][dev]) {
+        if (dev >= 0 && dev < 64 && !g_tile_ready[OUT][K][dev]) {
             for (int P = 5; P <= 8; ++P) {
                 e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern[P]), hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
                 if (e != hipSuccess) return e;
             }
-            g_tile_ready[K][dev] = true;
+            g_tile_ready[OUT][K][dev] = true;
         }
     }
     hipDeviceProp_t prop;
@@ -311,12 +353,17 @@ static hipError_t launch_tile_k(TileParams p, const DecParams &legacy, void *d_w
 
 hipError_t launch_decode_tile(TileParams p, const DecParams &legacy, void *d_ws, hipStream_t st) {
     if (p.chunk_shift > 12 || p.chunk_shift < T_SUB_SHIFT) return hipErrorInvalidValue;
-    // tiles per wave: 2 by default; MH_TILE_K (1..3) for A/B runs
+    // timing probe (MH_TILE_PROBE=1): the second-level table has zero records, so every gather is answered by the
+    // bounds check — the instruction stream and the waits stay, the trips to L2 go (results are wrong)
+    if (const char *pr = getenv("MH_TILE_PROBE")) { p.probe = uint32_t(atoi(pr)); if (p.probe & 1) p.nsec = 0; }
+    // tiles per wave: 2 by default; MH_TILE_K (1..4) for A/B runs
     const char *e = getenv("MH_TILE_K");
     const int k = e ? atoi(e) : 2;
-    if (k == 1) return launch_tile_k<1>(p, legacy, d_ws, st);
-    if (k == 3) return launch_tile_k<3>(p, legacy, d_ws, st);
-    return launch_tile_k<2>(p, legacy, d_ws, st);
+    const char *eo = getenv("MH_TILE_OUT");
+    const int o = eo ? atoi(eo) : 2;
+    if (o == 0) return k == 1 ? launch_tile_k<1, 0>(p, legacy, d_ws, st) : k == 4 ? launch_tile_k<4, 0>(p, legacy, d_ws, st) : launch_tile_k<2, 0>(p, legacy, d_ws, st);
+    if (o == 1) return k == 1 ? launch_tile_k<1, 1>(p, legacy, d_ws, st) : k == 3 ? launch_tile_k<3, 1>(p, legacy, d_ws, st) : launch_tile_k<2, 1>(p, legacy, d_ws, st);
+    return k == 1 ? launch_tile_k<1, 2>(p, legacy, d_ws, st) : k == 3 ? launch_tile_k<3, 2>(p, legacy, d_ws, st) : launch_tile_k<2, 2>(p, legacy, d_ws, st);
 }
 
 }  // namespace mhk
