@@ -85,6 +85,15 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void *generic) {
     return uint32_t(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) const void *)(generic)));
 }
 
+// diagnostic build only (MH_TILE_STAMP): shader-clock stamp, all of the wave's LDS / scalar loads drained first
+__device__ __forceinline__ unsigned long long tile_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+
 // inserts the low byte of `e` as byte j of `d`
 __device__ __forceinline__ uint32_t tile_put_byte(uint32_t d, uint32_t e, int j) {
     const uint32_t sel = j == 0 ? 0x03020104u : j == 1 ? 0x03020400u : j == 2 ? 0x03040100u : 0x04020100u;
@@ -95,7 +104,7 @@ __device__ __forceinline__ uint32_t tile_put_byte(uint32_t d, uint32_t e, int j)
 // OUT: how a stream's 64 bytes leave (A/B, MH_TILE_OUT): 0 = a 16-byte store per 16 symbols (adjacent lanes 64 bytes apart),
 // 1 = four such stores back to back at the end of the tile, 2 = through the wave's LDS region, transposed, so that every
 // store instruction writes one contiguous KiB
-template <int K, int PC, int HC, int OUT>
+template <int K, int PC, int HC, int OUT, int WIN, int STAMP = 0>
 __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr uint32_t P = PC;
@@ -137,7 +146,10 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.sec), 0, p.nsec ? int((p.nsec + 8u) * 2u) : 0, 0x00020000);
     const uint32_t chunks_per_tile = T_TILE >> p.chunk_shift;     // >= 1: chunk_shift <= 12 (launch_decode_tile)
 
+    unsigned long long seg[4] = {0, 0, 0, 0};
     for (uint64_t t = uint64_t(blockIdx.x) * nw + wave; t < p.ntiles; t += uint64_t(gridDim.x) * nw) {
+        unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+        if (STAMP) t0 = tile_stamp();
         // ---- positions: lane l, stream k decodes sub-chunk j = (t * K + k) * 64 + l
         uint64_t pos[K];
         uint32_t cf[K];                                           // low byte: the context (previous symbol)
@@ -168,6 +180,7 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
             for (uint32_t c = lane; c < chunks_per_tile * K; c += 64) p.redo[1u + atomicAdd(p.redo, 1u)] = uint32_t(c0 + c);
             continue;
         }
+        if (STAMP) t1 = tile_stamp();
         // ---- stage the piece: coalesced 16-byte loads, bits reversed inside every byte, so that stream bit i of
         // the piece sits at bit i & 31 of LDS dword i >> 5
         {
@@ -184,6 +197,7 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
             // the dword behind the piece (a window may read it) holds zero bits (src/bitbuffer.cpp:116-127)
             if (lane == 0) *reinterpret_cast<uint4 *>(reg + nvec * 16u) = make_uint4(0, 0, 0, 0);
         }
+        if (STAMP) t2 = tile_stamp();
         // LDS operations of one wave execute in order: the reads below see the writes above
         uint32_t q[K], q0[K];
 #pragma unroll
@@ -193,10 +207,29 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
 #pragma unroll
         for (int k = 0; k < K; ++k) o16[k] = reinterpret_cast<uint4 *>(p.out + ((j0 + uint64_t(k) * 64u + lane) << T_SUB_SHIFT));
         uint4 Q[OUT ? K : 1][4];                                  // OUT 1, 2: the stream's 64 bytes; the pieces rotate through
-        // One symbol of every stream per step, in four phases that the scheduler may not mix (it otherwise finishes
+        // WIN 1: the bit window lives in registers — lo/hi hold the next cnt stream bits (first in bit 0 of lo), `ahead`
+        // the LDS dword behind them, loaded one refill early; every second symbol a lane with fewer than 32 bits
+        // left takes `ahead` in (two table-resolved codes are at most 2 (P + H) <= 32 bits).  One masked ds_read_b32
+        // per ~5.5 symbols instead of a ds_read2_b32 per symbol: the LDS array was busy 60 % of the kernel's time,
+        // 60 % of that bank conflicts (profiles/r03), most of it window traffic.
+        uint32_t lo[K], hi[K], cnt[K], ahead[K], wnext[K];
+        if (WIN) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const uint32_t wa = (q[k] >> 3) & ~3u, sh = q[k] & 31u;
+                const lds_u32 *wp = lds_ptr<uint32_t>(wa);
+                const uint32_t d0 = wp[0], d1 = wp[1];
+                ahead[k] = wp[2];
+                wnext[k] = wa + 12u;
+                lo[k] = __builtin_amdgcn_alignbit(d1, d0, sh);
+                hi[k] = d1 >> sh;
+                cnt[k] = 64u - sh;
+            }
+        }
+        // One symbol of every stream per step, in phases that the scheduler may not mix (it otherwise finishes
         // one stream's window before it asks for the next one's: two LDS round trips in a row instead of one):
-        //   A  window dwords on their way (one ds_read2_b32 per stream)
-        //   B  window = alignbit, first-level lookups on their way
+        //   A  (WIN 0) window dwords on their way (one ds_read2_b32 per stream)
+        //   B  window, first-level lookups on their way
         //   C  second-level gathers on their way (every lane; a leaf indexes past the end: 0, no cache access)
         //   D  the resolving entry, position, context, output byte
 #pragma unroll 1
@@ -205,16 +238,32 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 uint32_t w0[K], w1[K], win[K], e[K], e2[K];
+                if (WIN) {
+                    if ((j & 1) == 0) {
 #pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const lds_u32 *wp = lds_ptr<uint32_t>((q[k] >> 3) & ~3u);
-                    w0[k] = wp[0];
-                    w1[k] = wp[1];
+                        for (int k = 0; k < K; ++k) {
+                            if (cnt[k] < 32u) {
+                                const uint64_t t = uint64_t(ahead[k]) << cnt[k];
+                                lo[k] |= uint32_t(t);
+                                hi[k] = uint32_t(t >> 32);            // (fewer than 32 bits left: hi was empty)
+                                cnt[k] += 32u;
+                                ahead[k] = *lds_ptr<uint32_t>(wnext[k]);
+                                wnext[k] += 4u;
+                            }
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const lds_u32 *wp = lds_ptr<uint32_t>((q[k] >> 3) & ~3u);
+                        w0[k] = wp[0];
+                        w1[k] = wp[1];
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
-                    win[k] = __builtin_amdgcn_alignbit(w1[k], w0[k], q[k]);           // 32 stream bits from bit q on, first in bit 0
+                    win[k] = WIN ? lo[k] : __builtin_amdgcn_alignbit(w1[k], w0[k], q[k]);   // 32 stream bits from bit q on, first in bit 0
                     // byte address of the entry (the table starts at LDS address 0, checked at entry): context << (P + 1) | bits << 1
                     const uint32_t csh = P == 7 ? __builtin_amdgcn_perm(0u, cf[k], 0x0C0C000Cu)       // byte 0 -> byte 1
                                                 : (cf[k] & 255u) << (P + 1);
@@ -232,7 +281,14 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
                     uint32_t ef;
                     asm("v_max_u32 %0, %1, %2" : "=v"(ef) : "v"(e[k]), "v"(e2[k]));    // (opaque: keeps the value a plain 32-bit one)
                     leafacc &= ef;
-                    q[k] += __builtin_amdgcn_ubfe(ef, 8, 5);
+                    const uint32_t len = __builtin_amdgcn_ubfe(ef, 8, 5);
+                    if (WIN) {
+                        lo[k] = __builtin_amdgcn_alignbit(hi[k], lo[k], len);
+                        hi[k] >>= len;
+                        cnt[k] -= len;
+                    } else {
+                        q[k] += len;
+                    }
                     cf[k] = ef;
                     w4[k][j >> 2] = (j & 3) == 0 ? (ef & 255u) : tile_put_byte(w4[k][j >> 2], ef, j & 3);
                 }
@@ -244,6 +300,7 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
                 else { Q[k][0] = Q[k][1]; Q[k][1] = Q[k][2]; Q[k][2] = Q[k][3]; Q[k][3] = v; }
             }
         }
+        if (STAMP) t3 = tile_stamp();
         if (OUT == 1) {
 #pragma unroll
             for (int k = 0; k < K; ++k)
@@ -278,6 +335,10 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
         }
         // ---- every sub-chunk must end exactly where the next one starts (null entries, a wrong table or a damaged
         // stream all miss it); a code that neither table level resolves sends the tile's chunks to the redo pass
+        if (WIN) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) q[k] = (wnext[k] - 4u) * 8u - cnt[k];       // `ahead` is the dword at wnext - 4: not in the window yet
+        }
         const uint32_t qend = reg_bit0 + uint32_t(end - b0 * 8u);
         bool bad = false;
         uint32_t unresolved = (leafacc & DEC16_LEAF) ? 0u : 1u;
@@ -288,6 +349,10 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
             if (lane == 63) nxt = first_of_next;
             bad = bad || q[k] != nxt;
         }
+        if (STAMP) {
+            const unsigned long long t4 = tile_stamp();
+            seg[0] += t1 - t0; seg[1] += t2 - t1; seg[2] += t3 - t2; seg[3] += t4 - t3;
+        }
         if (p.probe) continue;
         if (__any(unresolved)) {                                  // rare: all chunks of this piece again, with the walk
             const uint64_t c0 = (t * TSYM) >> p.chunk_shift;
@@ -296,41 +361,32 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
             if (lane == 0) atomicExch(p.status, MHK_STATUS_CORRUPT);
         }
     }
+    if (STAMP && lane == 0) {                                     // cycles per segment, summed over the waves (diagnostic build)
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(p.status) + 1;   // bytes 8..39 of the status block
+        for (int i = 0; i < 4; ++i) atomicAdd(&dst[i], seg[i]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
-static std::mutex g_tile_mu;
-static bool g_tile_ready[3][5][64];
 
 size_t decode_tile_workspace_extra() { return 64; }
 
 
-template <int K, int OUT>
-static hipError_t launch_tile_k(TileParams p, const DecParams &legacy, void *d_ws, hipStream_t st) {
-    void (*kern[9])(TileParams) = {nullptr, nullptr, nullptr, nullptr, nullptr, decode_tile_kernel<K, 5, 0, OUT>, decode_tile_kernel<K, 6, 0, OUT>,
-                                   decode_tile_kernel<K, 7, 0, OUT>, decode_tile_kernel<K, 8, 0, OUT>};
-    if (p.P < 5 || p.P > 8) return hipErrorInvalidValue;
+template <int K>
+static hipError_t launch_tile_with(void (*kern)(TileParams), TileParams p, const DecParams &legacy, void *d_ws, hipStream_t st) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    {
-        std::lock_guard<std::mutex> lock(g_tile_mu);
-        if (dev >= 0 && dev < 64 && !g_tile_ready[OUT][K][dev]) {
-            for (int P = 5; P <= 8; ++P) {
-                e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern[P]), hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
-                if (e != hipSuccess) return e;
-            }
-            g_tile_ready[OUT][K][dev] = true;
-        }
-    }
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
+    if (e != hipSuccess) return e;
     hipDeviceProp_t prop;
     static int cus = 0;
     if (cus == 0) cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     p.ntiles = p.n / (uint64_t(K) * T_TILE);
     // workspace: [0,64) status | [64, 64 + 16) redo count ... as launch_decode lays it out; the geometry word lives in
-    // the status block (bytes 32..35)
+    // the status block (bytes 4..7; bytes 8..39 take the diagnostic build's cycle sums)
     p.status = reinterpret_cast<int *>(d_ws);
-    p.geom = reinterpret_cast<uint32_t *>(static_cast<char *>(d_ws) + 32);
+    p.geom = reinterpret_cast<uint32_t *>(static_cast<char *>(d_ws) + 4);
     p.redo = reinterpret_cast<uint32_t *>(static_cast<char *>(d_ws) + 64);
     e = hipMemsetAsync(d_ws, 0, 64 + 16, st);
     if (e != hipSuccess) return e;
@@ -342,13 +398,21 @@ static hipError_t launch_tile_k(TileParams p, const DecParams &legacy, void *d_w
     // one workgroup per CU (the first-level table takes most of the LDS); with few pieces, fewer workgroups
     const uint64_t want = (p.ntiles + T_WAVES - 1) / T_WAVES;
     const unsigned grid = unsigned(want < 1 ? 1 : (want > uint64_t(cus) ? uint64_t(cus) : want));
-    hipLaunchKernelGGL(kern[p.P], dim3(grid), dim3(T_THREADS), T_LDS_BYTES, st, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(T_THREADS), T_LDS_BYTES, st, p);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     DecParams r = legacy;
     r.status = p.status;
     r.redo = p.redo;
     return launch_decode_redo(r, st);
+}
+
+template <int K, int OUT, int WIN = 1>
+static hipError_t launch_tile_k(TileParams p, const DecParams &legacy, void *d_ws, hipStream_t st) {
+    void (*kern[9])(TileParams) = {nullptr, nullptr, nullptr, nullptr, nullptr, decode_tile_kernel<K, 5, 0, OUT, WIN>, decode_tile_kernel<K, 6, 0, OUT, WIN>,
+                                   decode_tile_kernel<K, 7, 0, OUT, WIN>, decode_tile_kernel<K, 8, 0, OUT, WIN>};
+    if (p.P < 5 || p.P > 8) return hipErrorInvalidValue;
+    return launch_tile_with<K>(kern[p.P], p, legacy, d_ws, st);
 }
 
 hipError_t launch_decode_tile(TileParams p, const DecParams &legacy, void *d_ws, hipStream_t st) {
@@ -363,6 +427,15 @@ hipError_t launch_decode_tile(TileParams p, const DecParams &legacy, void *d_ws,
     const int o = eo ? atoi(eo) : 2;
     if (o == 0) return k == 1 ? launch_tile_k<1, 0>(p, legacy, d_ws, st) : k == 4 ? launch_tile_k<4, 0>(p, legacy, d_ws, st) : launch_tile_k<2, 0>(p, legacy, d_ws, st);
     if (o == 1) return k == 1 ? launch_tile_k<1, 1>(p, legacy, d_ws, st) : k == 3 ? launch_tile_k<3, 1>(p, legacy, d_ws, st) : launch_tile_k<2, 1>(p, legacy, d_ws, st);
+    if (const char *es = getenv("MH_TILE_STAMP")) {
+        if (atoi(es)) {
+            void (*ks)(TileParams) = decode_tile_kernel<2, 7, 0, 2, 0, 1>;
+            if (p.P != 7) return hipErrorInvalidValue;
+            return launch_tile_with<2>(ks, p, legacy, d_ws, st);
+        }
+    }
+    const char *ew = getenv("MH_TILE_WIN");
+    if (ew && atoi(ew) == 0) return k == 1 ? launch_tile_k<1, 2, 0>(p, legacy, d_ws, st) : launch_tile_k<2, 2, 0>(p, legacy, d_ws, st);
     return k == 1 ? launch_tile_k<1, 2>(p, legacy, d_ws, st) : k == 3 ? launch_tile_k<3, 2>(p, legacy, d_ws, st) : launch_tile_k<2, 2>(p, legacy, d_ws, st);
 }
 
