@@ -938,6 +938,7 @@ static int dev_encode_hist(const mh_model *m, const uint8_t *d_data, size_t n, u
     p.index = reinterpret_cast<unsigned long long *>(d_index);
     p.start_bit = reinterpret_cast<const unsigned long long *>(d_start_bit);
     p.fine = d_fine;
+    p.max_len = m->max_len;
     HIP_TRY(mhk::launch_encode_regions(p, d_hist_ws, hist_ws_bytes, d_ws, static_cast<hipStream_t>(stream)));
     return MH_OK;
 }

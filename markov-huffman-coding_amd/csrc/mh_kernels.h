@@ -28,6 +28,7 @@ struct EncodeArgs {
     unsigned long long *index;    // out: chunk index or nullptr
     const unsigned long long *start_bit;   // device: global bit position of this payload (low 3 bits used) or nullptr
     uint32_t *fine;               // out, optional: the device-only fine index (TileParams), one entry per 64 input bytes
+    int max_len;                  // the model's longest code (the region encoder launches its escape variant only above 12)
 };
 
 struct LenParams {

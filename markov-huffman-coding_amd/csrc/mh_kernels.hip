@@ -17,6 +17,7 @@
 
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 
 #include "mh_kernels.h"
 #include "mh_model.hpp"
@@ -701,7 +702,7 @@ __global__ __launch_bounds__(E_THREADS) void enc_emit_kernel(EmitParams p) {
 // HBM: traffic is the algorithmic (1 + r) n.  Two workgroup barriers per round are the price.
 // Only for models without escape codes (max length <= 12); others take the three-kernel path.
 constexpr int R_IMG_WORDS = E_WAVES * (E_STAGE_BITS / 32) + 16;          // 16 pieces of <= 12288 bits + carry + slack
-constexpr int REGION_LDS_BYTES = 131072 + R_IMG_WORDS * 4 + 64;
+constexpr int REGION_LDS_BYTES = 131072 + R_IMG_WORDS * 4 + 128;           // + the waves' piece counts, two rounds' worth
 constexpr uint64_t HIST_WS_MAGIC = 0x4D48525247303031ull;                 // "MHRRG001"
 
 struct HistHeader { unsigned long long magic, n, data, region_vecs; uint32_t grid, prev0, cross_cap, pad; };
@@ -711,29 +712,38 @@ __global__ void hist_header_kernel(HistHeader *hdr, HistHeader v) { *hdr = v; }
 // one workgroup per region: bits = sum over pairs of (slab field + 16384 x crossings) x code length
 __global__ __launch_bounds__(1024) void region_bits_kernel(const HistHeader *hdr, HistHeader expect, const uint32_t *slab,
                                                            const uint32_t *cross_all, const uint8_t *len8,
-                                                           unsigned long long *region_bits, int *status) {
+                                                           unsigned long long *region_bits, uint32_t *region_esc, int *status) {
     __shared__ unsigned long long part[16];
+    __shared__ uint32_t any_esc;
+    if (threadIdx.x == 0) any_esc = 0;
+    __syncthreads();
     const uint32_t w = blockIdx.x, tid = threadIdx.x;
     if (hdr->magic != HIST_WS_MAGIC || hdr->n != expect.n || hdr->data != expect.data || hdr->region_vecs != expect.region_vecs ||
         hdr->grid != expect.grid || hdr->prev0 != expect.prev0 || hdr->cross_cap != expect.cross_cap) {
-        if (tid == 0) { atomicExch(status, MHK_STATUS_CORRUPT); region_bits[w] = 0; }   // not the histogram of this input
+        if (tid == 0) { atomicExch(status, MHK_STATUS_CORRUPT); region_bits[w] = 0; region_esc[w] = 0; }   // not the histogram of this input
         return;
     }
     unsigned long long acc = 0;
+    bool esc = false;                            // a pair of this region has a code the 12-bit table does not hold
     const uint32_t *sl = slab + size_t(w) * 32768u;
     for (uint32_t i = tid; i < 32768u; i += 1024u) {
         const uint32_t v = sl[i];
         const uint32_t s0 = i, s1 = i | 0x8000u;
-        acc += (unsigned long long)(v & 0xFFFFu) * len8[hist_slot_prev(s0) * 256u + (s0 >> 8)];
-        acc += (unsigned long long)(v >> 16) * len8[hist_slot_prev(s1) * 256u + (s1 >> 8)];
+        const uint32_t l0 = len8[hist_slot_prev(s0) * 256u + (s0 >> 8)], l1 = len8[hist_slot_prev(s1) * 256u + (s1 >> 8)];
+        acc += (unsigned long long)(v & 0xFFFFu) * l0;
+        acc += (unsigned long long)(v >> 16) * l1;
+        esc |= ((v & 0xFFFFu) && l0 > uint32_t(mh::ENC16_MAX_LEN)) || ((v >> 16) && l1 > uint32_t(mh::ENC16_MAX_LEN));
     }
     const uint32_t *cross = cross_all + size_t(w) * (expect.cross_cap + 1u);
     const uint32_t nc = cross[0];
     if (nc > expect.cross_cap && tid == 0) atomicExch(status, MHK_STATUS_CAPACITY);
     for (uint32_t i = tid; i < (nc < expect.cross_cap ? nc : expect.cross_cap); i += 1024u) {
         const uint32_t sl2 = cross[1u + i];
-        acc += 16384ull * len8[hist_slot_prev(sl2) * 256u + (sl2 >> 8)];
+        const uint32_t l2 = len8[hist_slot_prev(sl2) * 256u + (sl2 >> 8)];
+        acc += 16384ull * l2;
+        esc |= l2 > uint32_t(mh::ENC16_MAX_LEN);
     }
+    if (esc) atomicOr(&any_esc, 1u);
     for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
     if ((tid & 63u) == 0) part[tid >> 6] = acc;
     __syncthreads();
@@ -741,6 +751,7 @@ __global__ __launch_bounds__(1024) void region_bits_kernel(const HistHeader *hdr
         unsigned long long t = 0;
         for (int i = 0; i < 16; ++i) t += part[i];
         region_bits[w] = t;
+        region_esc[w] = any_esc;
     }
 }
 
@@ -774,6 +785,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void region_scan_kernel(const unsigne
 struct RegionParams {
     const unsigned long long *region_start;
     const unsigned long long *region_bits;   // what region_bits_kernel priced each region at
+    const uint32_t *region_esc;   // per region: != 0 when its histogram has pairs whose codes exceed 12 bits
     uint64_t region_vecs;         // vectors (16 bytes) per region, a multiple of 1024
     uint64_t nvec_up;             // ceil(n / 16)
     uint64_t cap_words;           // output dwords that may be stored (capacity / 4)
@@ -826,8 +838,20 @@ __device__ __forceinline__ void region_escape_deposit(const uint8_t *len8, const
     }
 }
 
+// ESCK: the kernel is launched twice; a workgroup takes its region in the launch that matches the region's escape flag
+// (one function with both round bodies spilled registers; a workgroup of the other kind leaves at once)
+#ifdef MH_ENC_STAMP
+// diagnostic build only (make exp EXPFLAGS=-DMH_ENC_STAMP): shader-clock stamps around the round's phases
+#define ENC_STAMP(i) do { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+        stamp_acc[i] += t_ - stamp_last; stamp_last = t_; } while (0)
+#else
+#define ENC_STAMP(i) do { } while (0)
+#endif
+template <bool ESCK>
 __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, RegionParams rp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if ((rp.region_esc[blockIdx.x] != 0) != ESCK) return;
     uint16_t *tab = reinterpret_cast<uint16_t *>(smem);
     uint32_t *img = reinterpret_cast<uint32_t *>(smem + 131072);
     uint32_t *sb = img + R_IMG_WORDS;
@@ -891,90 +915,121 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
         }
         return tail;
     };
-    LaneIn cur_in = fetch(0), next_in = fetch(1), next2_in = fetch(2);
-    uint32_t cur_pb = head_byte(cur_in);
-    uint32_t E[16];
-    lookup16(cur_in, cur_pb, E);
-#pragma unroll 1
-    for (uint64_t r = 0; r < rounds; ++r) {
-        const LaneIn in3 = fetch(r + 3);
-        const uint32_t next_pb = head_byte(next_in);
-        uint32_t En[16];
-        lookup16(next_in, next_pb, En);
-        const uint32_t nvalid = cur_in.nvalid;
-        if (nvalid != E_VEC) {                   // the stream's ragged last vector, or lanes past the region's end
+#ifdef MH_ENC_STAMP
+    unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0}, stamp_last = 0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last) :: "memory");
+#endif
+    // ---- the round pipeline ------------------------------------------------------------------------------------
+    // Stamps of the two-phase version (profiles/r03/enc_stamps_*.txt): a round spent 1800 cycles packing (vector
+    // ALU, LDS idle), 900 at the first barrier, 1700 behind its deposits (the LDS working through ~160 atomic
+    // wave-instructions, vector ALU idle), 600 at the second barrier and 850 flushing.  Deposits return nothing, so a
+    // wave can issue them and go on: round r + 1 is therefore PACKED between round r's deposits and the barrier
+    // that ends them — the vector ALU packs while the LDS ORs.
+    //   top of round r:   P = round r packed (groups, lengths, inclusive scan), its bit count in sb[r & 1];
+    //                     E1 = codeword entries of round r + 1; D1, D2, D3 = input of rounds r + 1 .. r + 3
+    //   barrier 1         counts of round r visible, image free (every wave has flushed round r - 1)
+    //   exchange, index entries, deposits of round r (issued, not awaited)
+    //   fetch r + 4, lookups of round r + 2, pack + scan of round r + 1, its count to sb[(r + 1) & 1]
+    //   barrier 2         deposits of round r done
+    //   flush round r
+    struct Packed { uint64_t g[4]; uint32_t gl[4]; uint32_t L, inc; bool esc; };
+    auto pack = [&](const uint32_t (&E)[16], const LaneIn &in, uint32_t pb, auto full_c, auto esc_c) __attribute__((always_inline)) -> Packed {
+        constexpr bool FULL = decltype(full_c)::value, ESC = decltype(esc_c)::value;
+        Packed P;
+        uint32_t e[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) E[j] = uint32_t(j) < nvalid ? E[j] : 0u;
-        }
-        uint32_t L = 0;
-        uint64_t g[4]; uint32_t gl[4];
+        for (int j = 0; j < 16; ++j) e[j] = (FULL || uint32_t(j) < in.nvalid) ? E[j] : 0u;   // the stream's ragged last vector, lanes past the region's end
+        P.L = 0;
         uint32_t emax = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const uint32_t e0 = E[4 * q], e1 = E[4 * q + 1], e2 = E[4 * q + 2], e3 = E[4 * q + 3];
-            const uint32_t m01 = e0 > e1 ? e0 : e1, m23 = e2 > e3 ? e2 : e3;
-            emax = emax > m01 ? emax : m01;
-            emax = emax > m23 ? emax : m23;
+            const uint32_t e0 = e[4 * q], e1 = e[4 * q + 1], e2 = e[4 * q + 2], e3 = e[4 * q + 3];
+            if (ESC) {
+                const uint32_t m01 = e0 > e1 ? e0 : e1, m23 = e2 > e3 ? e2 : e3;
+                emax = emax > m01 ? emax : m01;
+                emax = emax > m23 ? emax : m23;
+            }
             const uint32_t l0 = e0 >> 12, l1 = e1 >> 12, l2 = e2 >> 12, l3 = e3 >> 12;
             const uint32_t p01 = ((e0 & 0xFFFu) << l1) | (e1 & 0xFFFu);
             const uint32_t p23 = ((e2 & 0xFFFu) << l3) | (e3 & 0xFFFu);
-            g[q] = (uint64_t(p01) << (l2 + l3)) | p23;
-            gl[q] = l0 + l1 + l2 + l3;
-            L += gl[q];
+            P.g[q] = (uint64_t(p01) << (l2 + l3)) | p23;
+            P.gl[q] = l0 + l1 + l2 + l3;
+            P.L += P.gl[q];
         }
         // a code of more than 12 bits among the lane's 16 (entry ENC16_ESCAPE): that lane prices and deposits its
         // symbols one by one from the full tables (src/bitbuffer.cpp:45-73 appends descriptors of any length)
-        const bool esc = emax >= 0xD000u;
-        if (__any(esc)) {                        // wave-uniform
-            if (esc) L = region_escape_bits(p.len8, p.code64, tab, cur_in.x, cur_pb, nvalid);
+        P.esc = ESC && emax >= 0xD000u;
+        if (ESC && __any(P.esc)) {               // wave-uniform
+            if (P.esc) P.L = region_escape_bits(p.len8, p.code64, tab, in.x, pb, FULL ? uint32_t(E_VEC) : in.nvalid);
         }
-        const uint32_t inc = wave_inclusive_sum(L);
-        if (lane == 63) sb[wave] = inc;          // the piece's bit count
+        P.inc = wave_inclusive_sum(P.L);
+        return P;
+    };
+    auto fetch_full = [&](uint64_t r) -> LaneIn {                // round r is whole: no bounds checks
+        LaneIn in;
+        const uint64_t v = v0 + r * E_THREADS + tid;
+        in.x = reinterpret_cast<const uint4 *>(p.data)[v];
+        in.nvalid = E_VEC;
+        in.head = p.prev0;
+        if (lane == 0 && v) in.head = uint32_t(p.data[v * E_VEC - 1]);
+        return in;
+    };
+    using ESC_T = std::integral_constant<bool, ESCK>;
+    LaneIn D0 = fetch(0), D1 = fetch(1), D2 = fetch(2), D3 = fetch(3);
+    uint32_t pb0 = head_byte(D0), pb1 = head_byte(D1);
+    uint32_t E1[16];
+    Packed P;                                    // loop-carried: round r packed
+    {
+        uint32_t E0[16];
+        lookup16(D0, pb0, E0);
+        lookup16(D1, pb1, E1);
+        P = pack(E0, D0, pb0, std::false_type{}, ESC_T{});
+    }
+    if (lane == 63) sb[wave] = P.inc;            // round 0's piece count
+    uint4 x0 = D0.x;                             // round r's input (the escape path re-reads it) and valid bytes
+    uint32_t nvalid0 = D0.nvalid;
+    static_assert(E_WAVES == 16, "the scan below is one DPP row");
+    auto round = [&](uint64_t r, auto full_c) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_c)::value, ESC = ESCK;
+        uint32_t *sbr = sb + (r & 1u) * 16u, *sbn = sb + ((r + 1u) & 1u) * 16u;
+        ENC_STAMP(0);                            // flush of the previous round (+ loop overhead)
         __syncthreads();
+        ENC_STAMP(1);                            // barrier 1
         if (carry) { atomicOr(&img[0], carry); carry = 0; }      // the previous round's partial word (every clear is behind the barrier)
         // bits of the round in front of this wave / in the whole round: every row of 16 lanes scans the 16 counts
-        // (one LDS read, four DPP adds, two readlanes instead of sixteen scalar reads and selects: this sits
-        // between the barrier and the deposits, where the whole workgroup waits for it)
-        static_assert(E_WAVES == 16, "the scan below is one DPP row");
-        uint32_t cs = sb[lane & 15u];
+        uint32_t cs = sbr[lane & 15u];
         cs += uint32_t(__builtin_amdgcn_update_dpp(0, int(cs), 0x111, 0xF, 0xF, true));      // row_shr:1
         cs += uint32_t(__builtin_amdgcn_update_dpp(0, int(cs), 0x112, 0xF, 0xF, true));      // row_shr:2
         cs += uint32_t(__builtin_amdgcn_update_dpp(0, int(cs), 0x114, 0xF, 0xF, true));      // row_shr:4
         cs += uint32_t(__builtin_amdgcn_update_dpp(0, int(cs), 0x118, 0xF, 0xF, true));      // row_shr:8
         const uint32_t tot = uint32_t(__builtin_amdgcn_readlane(int(cs), 15));
         const uint32_t pre = wave ? uint32_t(__builtin_amdgcn_readlane(int(cs), int(wave) - 1)) : 0u;
-        const uint32_t exc = pre + inc - L;      // bits of the round in front of this lane
+        const uint32_t exc = pre + P.inc - P.L;  // bits of the round in front of this lane
         const uint64_t off = (v0 + r * E_THREADS + tid) * E_VEC;
+        const uint32_t nvalid = FULL ? uint32_t(E_VEC) : nvalid0;
         if (p.index && nvalid && ((uint32_t(off) & (S - 1u)) == 0u))
-            p.index[off >> p.chunk_shift] = (uint64_t(cur_pb) << 56) | (abs_round + exc);
+            p.index[off >> p.chunk_shift] = (uint64_t(pb0) << 56) | (abs_round + exc);
         if (p.fine && nvalid && (lane & 3u) == 0u)               // fine index (mh_kernels.h, TileParams): every fourth lane
-            p.fine[off >> T_SUB_SHIFT] = (cur_pb << 24) | (uint32_t(abs_round + exc) & FINE_POS_MASK);
-        if (cur + tot <= R_IMG_CAP_BITS) {       // workgroup-uniform: the round fits the image (always, without escapes)
+            p.fine[off >> T_SUB_SHIFT] = (pb0 << 24) | (uint32_t(abs_round + exc) & FINE_POS_MASK);
+        const bool fits = !ESC || cur + tot <= R_IMG_CAP_BITS;   // workgroup-uniform: the round fits the image (always, without escapes)
+        if (fits) {
             uint32_t o = cur + exc;
-            if (!esc) {
+            if (!ESC || !P.esc) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    if (gl[q]) deposit<false>(img, g[q] << (64u - gl[q]), o, 0, 0);
-                    o += gl[q];
+                    if (P.gl[q]) deposit<false>(img, P.g[q] << (64u - P.gl[q]), o, 0, 0);
+                    o += P.gl[q];
                 }
             } else {
-                region_escape_deposit(p.len8, p.code64, tab, img, cur_in.x, cur_pb, nvalid, o);
+                region_escape_deposit(p.len8, p.code64, tab, img, x0, pb0, nvalid, o);
             }
-            __syncthreads();
-            const uint32_t nfull = (cur + tot) >> 5;
-            carry = flush(nfull);
-            // no barrier here: the next round touches the image only behind ITS first barrier (the exchange of the
-            // bit counts), which every wave reaches after its share of this flush
-            seam_first = seam_first && nfull == 0;
-            gbase += nfull;
-            cur = (cur + tot) & 31u;
         } else {
             // more bits than the image holds (only a model with many codes far over 12 bits can do that): one
             // wave's piece at a time — at most 1024 x 64 bits — each deposited symbol by symbol and flushed
             for (uint32_t m = 0; m < uint32_t(E_WAVES); ++m) {
                 const uint32_t upto = uint32_t(__builtin_amdgcn_readlane(int(cs), int(m)));
                 const uint32_t before = m ? uint32_t(__builtin_amdgcn_readlane(int(cs), int(m) - 1)) : 0u;
-                if (wave == m) region_escape_deposit(p.len8, p.code64, tab, img, cur_in.x, cur_pb, nvalid, cur + (exc - pre));
+                if (wave == m) region_escape_deposit(p.len8, p.code64, tab, img, x0, pb0, nvalid, cur + (exc - pre));
                 __syncthreads();
                 const uint32_t nfull = (cur + (upto - before)) >> 5;
                 const uint32_t t = flush(nfull);
@@ -985,13 +1040,44 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
                 if (t) atomicOr(&img[0], t);
             }
         }
+        ENC_STAMP(2);                            // exchange + deposits issued
+        // ---- while the LDS works the deposits off: the next rounds
+        const LaneIn D4 = FULL ? fetch_full(r + 4) : fetch(r + 4);
+        const uint32_t pb2 = head_byte(D2);
+        uint32_t E2[16];
+        lookup16(D2, pb2, E2);
+        const Packed Pn = pack(E1, D1, pb1, full_c, ESC_T{});
+        if (lane == 63) sbn[wave] = Pn.inc;      // round r + 1's piece count (the other half of sb: round r's is still being read)
+        ENC_STAMP(3);                            // lookups issued + pack + scan of the next round
+        if (fits) {
+            __syncthreads();
+            ENC_STAMP(4);                        // barrier 2
+            const uint32_t nfull = (cur + tot) >> 5;
+            carry = flush(nfull);
+            // no barrier here: the next round touches the image only behind ITS first barrier, which every wave
+            // reaches after its share of this flush
+            seam_first = seam_first && nfull == 0;
+            gbase += nfull;
+            cur = (cur + tot) & 31u;
+        }
         abs_round += tot;
-        cur_in = next_in; cur_pb = next_pb;
-        next_in = next2_in;
-        next2_in = in3;
+        P = Pn;
+        x0 = D1.x; nvalid0 = D1.nvalid; pb0 = pb1;
+        D1 = D2; pb1 = pb2;
+        D2 = D3;
+        D3 = D4;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) E[j] = En[j];
-    }
+        for (int j = 0; j < 16; ++j) E1[j] = E2[j];
+    };
+    // leading rounds whose 16 KiB, and those of the four rounds behind them, are whole: the steady state
+    const uint64_t whole = (p.n >> 4) < v1 ? (p.n >> 4) : v1;       // vectors with all 16 bytes inside the stream
+    const uint64_t rounds_full = whole > v0 ? (whole - v0) / E_THREADS : 0;
+    const uint64_t r_fast = rounds_full > 4 ? rounds_full - 4 : 0;
+    uint64_t r = 0;
+#pragma unroll 1
+    for (; r < r_fast; ++r) round(r, std::true_type{});
+#pragma unroll 1
+    for (; r < rounds; ++r) round(r, std::false_type{});
     // the region's last partial dword: shared with the next region (or the stream's end), zeroed by the scan
     if (cur != 0 && gbase < rp.cap_words) {
         if (carry) atomicOr(&out32[gbase], __builtin_bswap32(carry));
@@ -1000,6 +1086,10 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
     // The region was priced from the histogram workspace; if the buffer was refilled between the histogram and
     // this call the counts are another input's and the regions overlap or leave gaps: say so.
     if (tid == 0 && abs_round != s0 + rp.region_bits[blockIdx.x]) atomicExch(rp.status, MHK_STATUS_CORRUPT);
+#ifdef MH_ENC_STAMP
+    if (lane == 0)                               // cycle sums per phase, over all waves: bytes 8..47 of the status block
+        for (int i = 0; i < 5; ++i) atomicAdd(reinterpret_cast<unsigned long long *>(rp.status) + 1 + i, stamp_acc[i]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2360,7 +2450,7 @@ static EncWs enc_ws_layout(uint64_t n) {
     w.off_start = up(w.off_bits + size_t(w.nwt) * 4);
     w.off_blk = up(w.off_start + size_t(w.nwt) * 8);
     w.total = up(w.off_blk + size_t(w.nblk + 1) * 8);
-    if (w.total < 64 + 2 * 1024 * 8) w.total = 64 + 2 * 1024 * 8;      // the region path keeps <= 1024 lengths and starts here
+    if (w.total < 64 + 2 * 1024 * 8 + 1024 * 4) w.total = 64 + 2 * 1024 * 8 + 1024 * 4;   // the region path keeps <= 1024 lengths, starts and escape flags here
     return w;
 }
 size_t encode_workspace_bytes(uint64_t n) { return enc_ws_layout(n).total; }
@@ -2457,20 +2547,26 @@ hipError_t launch_encode_regions(const EncodeArgs &a, const void *d_hist_ws, siz
     }
     const RegionGeom g = region_geom(a.n);
     if (!d_hist_ws || hist_ws_bytes < g.total || g.grid > 1024) return hipErrorInvalidValue;
-    e = once_per_device(&DeviceState::region_ready, [] { return allow_lds(reinterpret_cast<const void *>(enc_region_kernel), REGION_LDS_BYTES); });
+    e = once_per_device(&DeviceState::region_ready, [] {
+        hipError_t r = allow_lds(reinterpret_cast<const void *>(enc_region_kernel<false>), REGION_LDS_BYTES);
+        return r != hipSuccess ? r : allow_lds(reinterpret_cast<const void *>(enc_region_kernel<true>), REGION_LDS_BYTES);
+    });
     if (e != hipSuccess) return e;
     const unsigned char *hws = static_cast<const unsigned char *>(d_hist_ws);
     unsigned long long *region_bits = reinterpret_cast<unsigned long long *>(ws + 64);
     unsigned long long *region_start = region_bits + 1024;
+    uint32_t *region_esc = reinterpret_cast<uint32_t *>(region_start + 1024);
     const HistHeader expect{HIST_WS_MAGIC, a.n, reinterpret_cast<unsigned long long>(a.data), g.region_vecs, uint32_t(g.grid), a.prev0, g.cross_cap, 0};
     hipLaunchKernelGGL(region_bits_kernel, dim3(g.grid), dim3(1024), 0, st, reinterpret_cast<const HistHeader *>(hws), expect,
                        reinterpret_cast<const uint32_t *>(hws + g.off_slab), reinterpret_cast<const uint32_t *>(hws + g.off_cross), a.len8,
-                       region_bits, status);
+                       region_bits, region_esc, status);
     hipLaunchKernelGGL(region_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, region_bits, uint32_t(g.grid), region_start, a.start_bit,
                        a.out, a.cap & ~uint64_t(3), a.nbits, status);
     EmitParams ep{a.data, a.n, a.prev0, a.chunk_shift, a.out, a.enc16, a.len8, a.code64, nullptr, nullptr, 0, a.index, status, a.fine};
-    RegionParams rp{region_start, region_bits, g.region_vecs, g.nvec_up, (a.cap & ~uint64_t(3)) >> 2, status};
-    hipLaunchKernelGGL(enc_region_kernel, dim3(g.grid), dim3(E_THREADS), REGION_LDS_BYTES, st, ep, rp);
+    RegionParams rp{region_start, region_bits, region_esc, g.region_vecs, g.nvec_up, (a.cap & ~uint64_t(3)) >> 2, status};
+    hipLaunchKernelGGL(enc_region_kernel<false>, dim3(g.grid), dim3(E_THREADS), REGION_LDS_BYTES, st, ep, rp);
+    if (a.max_len > mh::ENC16_MAX_LEN)           // the model has codes over 12 bits: the regions that contain any
+        hipLaunchKernelGGL(enc_region_kernel<true>, dim3(g.grid), dim3(E_THREADS), REGION_LDS_BYTES, st, ep, rp);
     return hipGetLastError();
 }
 
