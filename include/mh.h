@@ -58,6 +58,9 @@ enum {
 
 const char *mh_strerror(int status);
 int mh_last_hip_error(void);
+/* Diagnostic: how the calling thread's last mh_decode / mh_decode_to WITHOUT an index rebuilt it (codes of
+ * mh_dev_index_path below). */
+int mh_last_index_path(void);
 /* Number of usable devices; 0 when there is none (never an error). */
 int mh_device_count(void);
 /* Device used by the calling thread's subsequent mh_* / mh_dev_* calls (hipSetDevice). */
@@ -233,12 +236,16 @@ int mh_model_payload_bits(const mh_model *m, const uint64_t *counts, uint64_t *n
  * mh_dev_encode_hist needs: every workgroup counts one contiguous region of the input and leaves that
  * region's own pair counts behind. */
 size_t mh_dev_histogram_workspace(size_t n);
-/* d_counts (65536 or 256 x uint64) is overwritten. */
+/* d_counts (65536 or 256 x uint64) is overwritten.  With a workspace (>= 256 bytes) the order-1 call also checks
+ * on the device that the counts add up to n (src/main.cpp:176-178: the reference's counts sum to the file size; a
+ * spilled LDS counter field or a lost fix-up cannot hide): mh_dev_status(d_ws) then reports MH_ERR_CORRUPT. */
 int mh_dev_histogram_o1(const uint8_t *d_data, size_t n, uint8_t prev0, uint64_t *d_counts,
                         void *d_ws, size_t ws_bytes, void *stream);
 int mh_dev_histogram_o0(const uint8_t *d_data, size_t n, uint64_t *d_counts,
                         void *d_ws, size_t ws_bytes, void *stream);
 
+/* (large enough for the encoder to take a region-mode histogram of the input by itself when the call comes without
+ * one: mh_dev_encode, mh_dev_encode_at and mh_encode then run the same fast encoder as mh_dev_encode_hist) */
 size_t mh_dev_encode_workspace(size_t n);
 /* d_nbits: one uint64 (payload bits).  d_index: mh_index_entries(n, chunk_symbols) entries or NULL.
  * Errors found on the device (capacity overrun) go to the int32 at the start of d_ws: mh_dev_status(). */
@@ -252,9 +259,12 @@ int mh_dev_encode(const mh_model *m, const uint8_t *d_data, size_t n, uint8_t pr
  * filled for (d_data, n, prev0), untouched since.  The encoder then prices each of the histogram's regions from
  * its pair counts and the code lengths and needs no pass of its own over the input to find where everything
  * goes: the input is read once.  Same payload, index and *d_nbits as mh_dev_encode_at.  Falls back to
- * mh_dev_encode_at by itself for models with codes over 12 bits, order-2 models, or a workspace that is too
- * small; a workspace that holds some other buffer's histogram is reported as MH_ERR_CORRUPT by
- * mh_dev_status(d_ws) and nothing is written. */
+ * mh_dev_encode_at by itself for order-2 models or a workspace that is too small (codes over 12 bits are handled
+ * inside: src/bitbuffer.cpp:45-73 appends descriptors of any length).  A workspace that holds some other buffer's
+ * histogram is reported as MH_ERR_CORRUPT by mh_dev_status(d_ws) and nothing is written.  d_data itself must be
+ * unchanged too: if the buffer was refilled between the two calls, the header still matches, the regions are priced
+ * from the old contents, and what is written (never beyond `cap`) is not a valid stream — every region compares
+ * the bits it emitted with its price and mh_dev_status(d_ws) reports MH_ERR_CORRUPT. */
 int mh_dev_encode_hist(const mh_model *m, const uint8_t *d_data, size_t n, uint8_t prev0,
                        const uint64_t *d_start_bit,
                        uint8_t *d_payload, size_t cap, uint64_t *d_nbits,
@@ -346,6 +356,20 @@ size_t mh_dev_build_index_workspace(uint64_t nbits);
 int mh_dev_build_index(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, uint8_t prev0,
                        uint64_t *d_index, uint64_t index_cap, uint32_t chunk_symbols,
                        uint64_t *d_n_symbols, void *d_ws, size_t ws_bytes, void *stream);
+/* mh_dev_build_index that also fills the fine index (see above) of the stream: d_fine[fine_cap], one entry per 64
+ * symbols (nbits / 64 + 2 entries always suffice: a code has at least one bit). */
+int mh_dev_build_index_fine(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, uint8_t prev0,
+                            uint64_t *d_index, uint64_t index_cap, uint32_t chunk_symbols,
+                            uint32_t *d_fine, uint64_t fine_cap,
+                            uint64_t *d_n_symbols, void *d_ws, size_t ws_bytes, void *stream);
+/* Diagnostic: how the last mh_dev_build_index on this workspace arrived at the index — 1 the segment iteration
+ * converged, 2 per-group context maps (fixed-length codes), 3 per-group state maps (mixed lengths), 4 the one-lane
+ * walk, 0 nothing ran.  Synchronises `stream`. */
+int mh_dev_index_path(const void *d_ws, void *stream);
+/* Diagnostic: which encoder the last mh_dev_encode* call on this workspace ran — 1 the region encoder (priced from a
+ * histogram of the input, one read), 3 the same with its escape variant launched too (model with codes over 12
+ * bits), 2 the length pass + emit pair (order-2 models, inputs under 4 MiB without a histogram).  Synchronises. */
+int mh_dev_encode_path(const void *d_ws, void *stream);
 /* Synchronises `stream` and returns the device-side status word of a workspace (MH_OK, MH_ERR_CORRUPT,
  * MH_ERR_TIMEOUT, MH_ERR_CAPACITY). */
 int mh_dev_status(const void *d_ws, void *stream);

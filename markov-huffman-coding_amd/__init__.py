@@ -27,7 +27,7 @@ INDEX2_BIT_MASK = 0x0000FFFFFFFFFFFF      # order-2 models: two context bytes in
 
 # every symbol include/mh.h declares (checked by tests/test_abi.py)
 EXPORTS = [
-    "mh_strerror", "mh_last_hip_error", "mh_device_count", "mh_set_device",
+    "mh_strerror", "mh_last_hip_error", "mh_last_index_path", "mh_device_count", "mh_set_device",
     "mh_dev_malloc", "mh_dev_free", "mh_dev_upload", "mh_dev_download",
     "mh_model_from_counts", "mh_dev_model_from_counts", "mh_dev_model_workspace", "mh_dev_model_from_counts_ws",
     "mh_model_from_table_bits", "mh_model_write_table",
@@ -38,7 +38,7 @@ EXPORTS = [
     "mh_dev_histogram_workspace", "mh_dev_histogram_o1", "mh_dev_histogram_o0",
     "mh_decode_to", "mh_model_payload_bits", "mh_dev_encode_workspace", "mh_dev_encode", "mh_dev_payload_bits", "mh_dev_encode_at", "mh_dev_encode_ctx", "mh_dev_encode_hist", "mh_dev_decode_workspace", "mh_dev_decode", "mh_dev_decode_dn",
     "mh_dev_build_index_workspace", "mh_dev_build_index", "mh_dev_status",
-    "mh_dev_encode_fine", "mh_dev_decode_fine",
+    "mh_dev_encode_fine", "mh_dev_decode_fine", "mh_dev_build_index_fine", "mh_dev_index_path", "mh_dev_encode_path",
 ]
 
 
@@ -115,6 +115,9 @@ def lib():
         l.mh_dev_status.argtypes = [vp, vp]
         l.mh_dev_encode_fine.argtypes = [vp, vp, sz, u8, vp, vp, sz, vp, vp, u32, vp, vp, sz, vp, sz, vp]
         l.mh_dev_decode_fine.argtypes = [vp, vp, u64, vp, vp, u64, vp, u32, vp, vp, sz, vp]
+        l.mh_dev_build_index_fine.argtypes = [vp, vp, u64, u8, vp, u64, u32, vp, u64, vp, vp, sz, vp]
+        l.mh_dev_index_path.argtypes = [vp, vp]
+        l.mh_dev_encode_path.argtypes = [vp, vp]
         _lib = l
     return _lib
 

@@ -55,6 +55,7 @@ struct mh_model {
 namespace {
 
 thread_local int g_last_hip = 0;
+thread_local int g_last_index_path = 0;   // how the calling thread's last index-free mh_decode* built its index (mh_last_index_path)
 
 int hip_fail(hipError_t e) {
     g_last_hip = int(e);
@@ -202,12 +203,21 @@ private:
     size_t seq_ = 0;
     int threads_ = 1;
 };
-PinnedRing g_ring;
+// one ring per device: its events belong to the device that was current when they were created (an event recorded
+// on another device's stream is refused), and a process may drive several cards (mh_set_device)
+constexpr int MAX_RING_DEVICES = 16;
+PinnedRing g_rings[MAX_RING_DEVICES];
+int ring_slot_for_device(int dev) { return dev >= 0 && dev < MAX_RING_DEVICES ? dev : 0; }
+PinnedRing &ring_for_current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    return g_rings[ring_slot_for_device(dev)];
+}
 
 // small transfers keep the plain call (the ring pays from a few MiB on)
 hipError_t stage_h2d(void *d_dst, const void *h_src, size_t n, hipStream_t st) {
     if (n < (size_t(4) << 20)) return hipMemcpyAsync(d_dst, h_src, n, hipMemcpyHostToDevice, st);   // pageable: returns after staging
-    return g_ring.upload(d_dst, h_src, n, st);
+    return ring_for_current_device().upload(d_dst, h_src, n, st);
 }
 // Device -> caller memory.  Measured on the GPU box (tools/cli_rate.py, 4 GiB): going through the ring costs
 // MORE than the runtime's own pageable path when the destination is a freshly grown file mapping — the
@@ -217,7 +227,7 @@ hipError_t stage_h2d(void *d_dst, const void *h_src, size_t n, hipStream_t st) {
 // the ring for destinations that are already resident.
 hipError_t stage_d2h(void *h_dst, const void *d_src, size_t n, hipStream_t st) {
     static const bool use_ring = getenv("MH_D2H_RING") && atoi(getenv("MH_D2H_RING")) != 0;
-    if (use_ring && n >= (size_t(4) << 20)) return g_ring.download(h_dst, d_src, n, st);
+    if (use_ring && n >= (size_t(4) << 20)) return ring_for_current_device().download(h_dst, d_src, n, st);
     hipError_t e = hipMemcpyAsync(h_dst, d_src, n, hipMemcpyDeviceToHost, st);
     return e != hipSuccess ? e : hipStreamSynchronize(st);
 }
@@ -338,6 +348,7 @@ const char *mh_strerror(int status) {
 }
 
 int mh_last_hip_error(void) { return g_last_hip; }
+int mh_last_index_path(void) { return g_last_index_path; }
 
 int mh_device_count(void) {
     int n = 0;
@@ -400,6 +411,9 @@ static int model_from_device_counts_via_host(const uint64_t *d_counts, int order
 
 // Fixed-size part of a device-built model: every image + the node arrays, each piece 256-byte aligned.
 namespace {
+// internal: dev_model_build met a model whose second-level tables need the general (non-uniform) L2 layout, which only
+// the host packer lays out (more than 32767 depth-8 inner nodes); never returned through the C ABI
+constexpr int BUILD_NEEDS_HOST = -1000;
 struct BuildLayout { size_t off[12], fixed; };
 BuildLayout build_layout() {
     const size_t nn = size_t(256) * mhk::TB_NODE_STRIDE;
@@ -476,7 +490,7 @@ int dev_model_build(const uint64_t *d_counts, void *d_ws, size_t ws_bytes, hipSt
         if (worst[q] <= size_t(mh::DEC_SEC_MAX_PER_CTX) && (size_t(256) << q) + tot[q] <= size_t(mh::DEC_LDS_ENTRIES)) P = q;
     m->dec_lds = P != 0;
     if (!m->dec_lds) {
-        if (ntab8 > 32767) return fail(MH_ERR_ARG - 100);       // general L2 layout: rare; the caller lets the host do it
+        if (ntab8 > 32767) return fail(BUILD_NEEDS_HOST);         // general L2 layout: rare; the caller lets the host do it
         P = 8;
         m->dec_direct = true;
         m->dec_h = std::min(std::max(m->max_len - 8, 1), 8);
@@ -733,7 +747,10 @@ size_t mh_dev_model_workspace(int order) { return order == 1 ? build_layout().fi
 int mh_dev_model_from_counts_ws(const uint64_t *d_counts, int order, void *d_ws, size_t ws_bytes, void *stream, mh_model **out) {
     if (!d_counts || !out || order != 1 || !d_ws) return MH_ERR_ARG;
     if (!have_device()) return MH_ERR_NO_DEVICE;
-    return dev_model_build(d_counts, d_ws, ws_bytes, static_cast<hipStream_t>(stream), out);
+    const int rc = dev_model_build(d_counts, d_ws, ws_bytes, static_cast<hipStream_t>(stream), out);
+    // the rare model the device packer does not lay out: built on the host instead (that model owns its memory)
+    if (rc == BUILD_NEEDS_HOST) return model_from_device_counts_via_host(d_counts, order, static_cast<hipStream_t>(stream), out);
+    return rc;
 }
 
 int mh_dev_model_from_counts(const uint64_t *d_counts, int order, void *stream, mh_model **out) {
@@ -743,7 +760,7 @@ int mh_dev_model_from_counts(const uint64_t *d_counts, int order, void *stream, 
     if (order == 2) return dev_model_build2(d_counts, st, out);
     if (order == 0) return model_from_device_counts_via_host(d_counts, order, st, out);   // one tree: not worth a kernel
     int rc = dev_model_build(d_counts, nullptr, 0, st, out);
-    if (rc == MH_ERR_ARG - 100) return model_from_device_counts_via_host(d_counts, order, st, out);
+    if (rc == BUILD_NEEDS_HOST) return model_from_device_counts_via_host(d_counts, order, st, out);
     return rc;
 }
 
@@ -874,7 +891,16 @@ int mh_dev_histogram_o2(const uint8_t *d_data, size_t n, uint16_t ctx0, uint64_t
     return MH_OK;
 }
 
-size_t mh_dev_encode_workspace(size_t n) { return mhk::encode_workspace_bytes(n); }
+// The encode workspace also has room for a region-mode histogram of the input (workspace + 65536 counts): an
+// order-0/1 encode that comes without one (mh_dev_encode, mh_dev_encode_at, mh_encode: the reference's `-e table`
+// flow, src/main.cpp:137-161 + 208-212) takes it first and then runs the region encoder — 5.8 + 10 ms per 16 GiB
+// against 4.1 + 13.7 ms for the length pass + emit pair, and the same bytes out.
+static size_t enc_ws_core(size_t n) { return (mhk::encode_workspace_bytes(n) + 255) & ~size_t(255); }
+static size_t enc_ws_hist(size_t n) { return (mhk::hist_workspace_bytes(n) + 255) & ~size_t(255); }
+constexpr size_t ENC_OWN_HIST_MIN = size_t(4) << 20;   // below this the length pass costs nothing worth a histogram
+size_t mh_dev_encode_workspace(size_t n) {
+    return enc_ws_core(n) + (n >= ENC_OWN_HIST_MIN && have_device() ? enc_ws_hist(n) + 65536 * 8 : 0);
+}
 
 int mh_dev_encode(const mh_model *m, const uint8_t *d_data, size_t n, uint8_t prev0, uint8_t *d_payload, size_t cap,
                   uint64_t *d_nbits, uint64_t *d_index, uint32_t chunk_symbols, void *d_ws, size_t ws_bytes, void *stream) {
@@ -889,11 +915,15 @@ int mh_dev_payload_bits(const mh_model *m, const uint64_t *d_counts, uint64_t *d
     return MH_OK;
 }
 
+static int dev_encode_hist(const mh_model *m, const uint8_t *d_data, size_t n, uint8_t prev0, const uint64_t *d_start_bit,
+                           uint8_t *d_payload, size_t cap, uint64_t *d_nbits, uint64_t *d_index, uint32_t chunk_symbols,
+                           const void *d_hist_ws, size_t hist_ws_bytes, void *d_ws, size_t ws_bytes, void *stream, uint32_t *d_fine);
+
 // ctx0: the context before the first byte — the previous byte (orders 0/1) or, for an order-2 model,
 // (byte before previous) << 8 | previous byte
 static int dev_encode_ctx(const mh_model *m, const uint8_t *d_data, size_t n, uint32_t ctx0, const uint64_t *d_start_bit,
                           uint8_t *d_payload, size_t cap, uint64_t *d_nbits, uint64_t *d_index, uint32_t chunk_symbols,
-                          void *d_ws, size_t ws_bytes, void *stream, uint32_t *d_fine = nullptr) {
+                          void *d_ws, size_t ws_bytes, void *stream, uint32_t *d_fine) {
     if (!m || (!d_data && n) || !d_payload || !d_nbits || !d_ws) return MH_ERR_ARG;
     if (!aligned16(d_data) || !aligned16(d_payload) || !aligned16(d_ws)) return MH_ERR_ARG;
     int shift = chunk_shift_of(d_index ? chunk_symbols : MH_CHUNK_DEFAULT);
@@ -901,6 +931,16 @@ static int dev_encode_ctx(const mh_model *m, const uint8_t *d_data, size_t n, ui
     if (ws_bytes < mhk::encode_workspace_bytes(n)) return MH_ERR_CAPACITY;
     if (m->max_len > mh::MAX_CODE_BITS) return MH_ERR_CODE_TOO_LONG;
     if (!m->d_len8) return MH_ERR_NO_DEVICE;
+    if (m->type != 2 && n >= ENC_OWN_HIST_MIN && ws_bytes >= enc_ws_core(n) + enc_ws_hist(n) + 65536 * 8 && !getenv("MH_ENCODE_LENGTH_PASS")) {
+        // no histogram came with the call: take one of this very buffer (region mode) and let the region encoder price
+        // its regions from it — one more read of the input, but no length pass and the faster emit
+        unsigned char *w = static_cast<unsigned char *>(d_ws);
+        void *hws = w + enc_ws_core(n);
+        uint64_t *cnt = reinterpret_cast<uint64_t *>(w + enc_ws_core(n) + enc_ws_hist(n));
+        HIP_TRY(mhk::launch_hist_o1(d_data, n, ctx0, reinterpret_cast<unsigned long long *>(cnt), hws, enc_ws_hist(n), static_cast<hipStream_t>(stream)));
+        return dev_encode_hist(m, d_data, n, uint8_t(ctx0), d_start_bit, d_payload, cap, d_nbits, d_index, chunk_symbols, hws, enc_ws_hist(n),
+                               d_ws, enc_ws_core(n), stream, d_fine);
+    }
     mhk::EncodeArgs p{};
     p.order = m->type == 2 ? 2 : 1;
     p.data = d_data; p.n = n; p.prev0 = ctx0; p.chunk_shift = uint32_t(shift);
@@ -964,14 +1004,14 @@ int mh_dev_encode_ctx(const mh_model *m, const uint8_t *d_data, size_t n, uint32
                       uint8_t *d_payload, size_t cap, uint64_t *d_nbits, uint64_t *d_index, uint32_t chunk_symbols,
                       void *d_ws, size_t ws_bytes, void *stream) {
     if (m && ctx0 > (m->type == 2 ? 0xFFFFu : 0xFFu)) return MH_ERR_ARG;
-    return dev_encode_ctx(m, d_data, n, ctx0, d_start_bit, d_payload, cap, d_nbits, d_index, chunk_symbols, d_ws, ws_bytes, stream);
+    return dev_encode_ctx(m, d_data, n, ctx0, d_start_bit, d_payload, cap, d_nbits, d_index, chunk_symbols, d_ws, ws_bytes, stream, nullptr);
 }
 
 int mh_dev_encode_at(const mh_model *m, const uint8_t *d_data, size_t n, uint8_t prev0, const uint64_t *d_start_bit,
                      uint8_t *d_payload, size_t cap, uint64_t *d_nbits, uint64_t *d_index, uint32_t chunk_symbols,
                      void *d_ws, size_t ws_bytes, void *stream) {
     return dev_encode_ctx(m, d_data, n, ctx_of_prev0(m, prev0), d_start_bit, d_payload, cap, d_nbits, d_index, chunk_symbols, d_ws,
-                          ws_bytes, stream);
+                          ws_bytes, stream, nullptr);
 }
 
 size_t mh_dev_decode_workspace(uint64_t, uint64_t n_symbols, uint32_t chunk_symbols) {
@@ -1043,8 +1083,9 @@ int mh_dev_decode_dn(const mh_model *m, const uint8_t *d_payload, const uint64_t
     return dev_decode(m, d_payload, nbits_hint, d_nbits, d_out, n_symbols, d_index, chunk_symbols, d_ws, ws_bytes, stream);
 }
 
-int mh_dev_build_index(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, uint8_t prev0, uint64_t *d_index,
-                       uint64_t index_cap, uint32_t chunk_symbols, uint64_t *d_n_symbols, void *d_ws, size_t ws_bytes, void *stream) {
+static int dev_build_index(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, uint8_t prev0, uint64_t *d_index,
+                           uint64_t index_cap, uint32_t chunk_symbols, uint64_t *d_n_symbols, void *d_ws, size_t ws_bytes, void *stream,
+                           uint32_t *d_fine, uint64_t fine_cap) {
     if (!m || !d_index || !d_n_symbols || !d_ws || (!d_payload && nbits)) return MH_ERR_ARG;
     if (ws_bytes < mhk::build_index_workspace_bytes(nbits)) return MH_ERR_CAPACITY;
     int shift = chunk_shift_of(chunk_symbols);
@@ -1062,8 +1103,32 @@ int mh_dev_build_index(const mh_model *m, const uint8_t *d_payload, uint64_t nbi
     p.direct = m->dec_direct ? 1u : 0u; p.H = uint32_t(m->dec_h);
     p.len_gcd = m->len_gcd;
     p.max_len = uint32_t(m->max_len > 0 ? m->max_len : 1);
+    p.fine = m->type == 2 ? nullptr : d_fine;
+    p.fine_cap = fine_cap;
     HIP_TRY(mhk::launch_build_index(p, d_ws, static_cast<hipStream_t>(stream)));
     return MH_OK;
+}
+
+int mh_dev_build_index(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, uint8_t prev0, uint64_t *d_index,
+                       uint64_t index_cap, uint32_t chunk_symbols, uint64_t *d_n_symbols, void *d_ws, size_t ws_bytes, void *stream) {
+    return dev_build_index(m, d_payload, nbits, prev0, d_index, index_cap, chunk_symbols, d_n_symbols, d_ws, ws_bytes, stream, nullptr, 0);
+}
+
+int mh_dev_build_index_fine(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, uint8_t prev0, uint64_t *d_index,
+                            uint64_t index_cap, uint32_t chunk_symbols, uint32_t *d_fine, uint64_t fine_cap, uint64_t *d_n_symbols,
+                            void *d_ws, size_t ws_bytes, void *stream) {
+    return dev_build_index(m, d_payload, nbits, prev0, d_index, index_cap, chunk_symbols, d_n_symbols, d_ws, ws_bytes, stream, d_fine, fine_cap);
+}
+
+int mh_dev_index_path(const void *d_ws, void *stream);
+int mh_dev_encode_path(const void *d_ws, void *stream) { return mh_dev_index_path(d_ws, stream); }   // same word of the status block
+
+int mh_dev_index_path(const void *d_ws, void *stream) {
+    if (!d_ws) return MH_ERR_ARG;
+    uint32_t v = 0;
+    HIP_TRY(hipMemcpyAsync(&v, static_cast<const unsigned char *>(d_ws) + 8, sizeof v, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return int(v);
 }
 
 int mh_dev_status(const void *d_ws, void *stream) {
@@ -1249,7 +1314,7 @@ int mh_encode(const mh_model *m, const uint8_t *data, size_t n, uint8_t prev0, u
         const uint32_t c0 = m->type == 2 ? (off ? uint32_t(data[off - 2]) << 8 | data[off - 1] : ctx_of_prev0(m, prev0))
                                          : (off ? data[off - 1] : prev0);      // segments are >= 8 KiB, so off >= 2 when not 0
         int rc = dev_encode_ctx(m, d_seg, len, c0, d_start.as<uint64_t>(), d_out.as<uint8_t>(), dcap,
-                                d_nbits.as<uint64_t>(), index ? d_index.as<uint64_t>() : nullptr, chunk_symbols, d_ws.p, wsb, st);
+                                d_nbits.as<uint64_t>(), index ? d_index.as<uint64_t>() : nullptr, chunk_symbols, d_ws.p, wsb, st, nullptr);
         if (rc != MH_OK) return rc;
         rc = mh_dev_status(d_ws.p, st);
         if (rc != MH_OK) return rc;
@@ -1349,15 +1414,21 @@ int mh_decode_to(const mh_model *m, const uint8_t *payload, uint64_t nbits, uint
     const uint64_t idx_cap = nbits / chunk_symbols + 2;
     HIP_TRY(d_index.alloc(size_t(idx_cap) * 8));
     HIP_TRY(d_nsym.alloc(8));
+    // the fill pass of the index builder also writes the fine index (one uint32 per 64 symbols): the stream then
+    // decodes with the tile decoder although it came without any index
+    DevBuf d_fine;
+    const uint64_t fine_cap = m->type == 2 ? 0 : nbits / MH_FINE_SYMBOLS + 2;
+    if (fine_cap) HIP_TRY(d_fine.alloc(size_t(fine_cap) * 4));
     {
         DevBuf d_iws;
         const size_t iws = mh_dev_build_index_workspace(nbits);
         HIP_TRY(d_iws.alloc(iws));
-        int rc = mh_dev_build_index(m, d_payload.as<uint8_t>(), nbits, prev0, d_index.as<uint64_t>(), idx_cap, chunk_symbols,
-                                    d_nsym.as<uint64_t>(), d_iws.p, iws, st);
+        int rc = mh_dev_build_index_fine(m, d_payload.as<uint8_t>(), nbits, prev0, d_index.as<uint64_t>(), idx_cap, chunk_symbols,
+                                         fine_cap ? d_fine.as<uint32_t>() : nullptr, fine_cap, d_nsym.as<uint64_t>(), d_iws.p, iws, st);
         if (rc != MH_OK) return rc;
         rc = mh_dev_status(d_iws.p, st);
         if (rc != MH_OK) return rc;
+        g_last_index_path = mh_dev_index_path(d_iws.p, st);
     }
     HIP_TRY(hipMemcpy(&n_symbols, d_nsym.p, 8, hipMemcpyDeviceToHost));
     *nbytes = size_t(n_symbols);
@@ -1378,8 +1449,8 @@ int mh_decode_to(const mh_model *m, const uint8_t *payload, uint64_t nbits, uint
             HIP_TRY(hipMemcpy(&end_bits, d_index.as<uint64_t>() + c0 + ne, 8, hipMemcpyDeviceToHost));
             end_bits &= m->type == 2 ? MH_INDEX2_BIT_MASK : MH_INDEX_BIT_MASK;
         }
-        int rc = mh_dev_decode(m, d_payload.as<uint8_t>(), end_bits, d_out.as<uint8_t>(), len, d_index.as<uint64_t>() + c0,
-                               chunk_symbols, d_ws.p, dws, st);
+        int rc = mh_dev_decode_fine(m, d_payload.as<uint8_t>(), end_bits, nullptr, d_out.as<uint8_t>(), len, d_index.as<uint64_t>() + c0,
+                                    chunk_symbols, fine_cap ? d_fine.as<uint32_t>() + off / MH_FINE_SYMBOLS : nullptr, d_ws.p, dws, st);
         if (rc != MH_OK) return rc;
         rc = mh_dev_status(d_ws.p, st);
         if (rc != MH_OK) return rc;

@@ -150,7 +150,12 @@ struct IdxParams {
     uint32_t seg_bits;
     uint64_t nseg;
     uint32_t *fine;               // optional: fine index entries written by the fill passes (see TileParams)
+    uint64_t fine_cap;            // entries available at `fine`
 };
+// which encoder a launch_encode* call used (its workspace's status block, bytes 8..11)
+enum { ENC_PATH_NONE = 0, ENC_PATH_REGIONS = 1, ENC_PATH_LENGTH_PASS = 2, ENC_PATH_REGIONS_ESCAPES = 3 };
+// how launch_build_index arrived at the index (status block bytes 8..11)
+enum { IDX_PATH_NONE = 0, IDX_PATH_SEGMENTS = 1, IDX_PATH_GROUP_MAPS = 2, IDX_PATH_STATE_MAPS = 3, IDX_PATH_WALK = 4 };
 
 // ---- device tree build (mh_tree.hip)
 constexpr int TB_NODE_STRIDE = 520;   // >= 513 nodes per context

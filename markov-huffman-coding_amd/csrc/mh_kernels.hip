@@ -64,6 +64,8 @@ __device__ __forceinline__ void slots16(const uint4 &x4, uint32_t pb, uint32_t (
     }
 }
 
+__global__ void set_word_kernel(uint32_t *p, uint32_t v) { *p = v; }
+
 // ------------------------------------------------------------------------------------------------
 // histogram, order 1
 // ------------------------------------------------------------------------------------------------
@@ -95,21 +97,27 @@ __device__ __forceinline__ uint32_t hist_slot_prev(uint32_t slot) { return (slot
 // cross (region mode): the workgroup's list of crossings, [0] = count, then the slots — with the slab it gives
 // the workgroup's own exact pair counts (field + 16384 per listed crossing), which is what lets the encoder
 // price its region without a length pass (enc_region_kernel)
+// GUARD = counter bits of a 16-bit field: 14 (two guard bits, the product) or 15 (one guard bit: round 1's
+// version, which loses counts on runs of one pair — kept ONLY as MH_DEBUG_HIST_GUARD1=1, so that a test can watch
+// the conservation check of hist_reduce_kernel catch a spill)
+template <int GUARD>
 __device__ __forceinline__ void hist_fixup(uint32_t *h, unsigned long long *counts, uint32_t slot, uint32_t *cross, uint32_t cross_cap) {
-    atomicSub(&h[slot & 0x7FFFu], (slot >> 15) ? 0x40000000u : 0x4000u);
-    atomicAdd(&counts[hist_slot_prev(slot) * 256u + (slot >> 8)], 16384ull);
+    atomicSub(&h[slot & 0x7FFFu], (slot >> 15) ? (0x10000u << GUARD) : (1u << GUARD));
+    atomicAdd(&counts[hist_slot_prev(slot) * 256u + (slot >> 8)], (unsigned long long)(1u << GUARD));
     if (cross) {
         const uint32_t i = atomicAdd(&cross[0], 1u);
         if (i < cross_cap) cross[1u + i] = slot;
     }
 }
 
+template <int GUARD>
 __device__ __forceinline__ void hist_add(uint32_t *h, unsigned long long *counts, uint32_t prev, uint32_t sym, uint32_t *cross,
                                          uint32_t cross_cap) {
+    constexpr uint32_t CROSS = ((0x10000u - (1u << GUARD)) & 0xFFFFu) * 0x10001u;   // 0xC000C000 for 14 bits
     const uint32_t slot = hist_slot(prev, sym);
     const uint32_t inc = (slot >> 15) ? 0x10000u : 1u;
     const uint32_t old = atomicAdd(&h[slot & 0x7FFFu], inc);
-    if (((old + inc) ^ old) & 0xC000C000u) hist_fixup(h, counts, slot, cross, cross_cap);
+    if (((old + inc) ^ old) & CROSS) hist_fixup<GUARD>(h, counts, slot, cross, cross_cap);
 }
 
 // slab: when not null, every workgroup stores its 32768 LDS words there (plain coalesced stores) and
@@ -118,9 +126,11 @@ __device__ __forceinline__ void hist_add(uint32_t *h, unsigned long long *counts
 // region_vecs != 0 (region mode, needs the slab): workgroup w counts the CONTIGUOUS vectors
 // [w * region_vecs, (w + 1) * region_vecs) instead of a grid-strided share, and lists its crossings in
 // cross_all + w * (cross_cap + 1).
+template <int GUARD>
 __global__ __launch_bounds__(HIST_THREADS) void hist_o1_kernel(const uint8_t *__restrict__ data, uint64_t n,
                                                               uint32_t prev0, unsigned long long *counts, uint32_t *slab,
                                                               uint64_t region_vecs, uint32_t *cross_all, uint32_t cross_cap) {
+    constexpr uint32_t CROSS = ((0x10000u - (1u << GUARD)) & 0xFFFFu) * 0x10001u;   // 0xC000C000 for 14 bits
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *h = reinterpret_cast<uint32_t *>(smem);
     for (int i = threadIdx.x; i < 32768 / 4; i += HIST_THREADS) reinterpret_cast<uint4 *>(h)[i] = make_uint4(0, 0, 0, 0);
@@ -175,10 +185,10 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_o1_kernel(const uint8_t *__
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) newly |= (old[i] + inc[i]) ^ old[i];
-        if (newly & 0xC000C000u) {                               // some add of this lane crossed a multiple of 0x4000
+        if (newly & CROSS) {                                     // some add of this lane crossed a multiple of 0x4000
 #pragma unroll
             for (int i = 0; i < 16; ++i)
-                if (((old[i] + inc[i]) ^ old[i]) & 0xC000C000u) hist_fixup(h, counts, slot[i], cross, cross_cap);
+                if (((old[i] + inc[i]) ^ old[i]) & CROSS) hist_fixup<GUARD>(h, counts, slot[i], cross, cross_cap);
         }
     }
     // ragged tail (< 16 bytes): one lane of block 0 — in region mode of the workgroup whose region holds that vector
@@ -188,7 +198,7 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_o1_kernel(const uint8_t *__
         uint32_t prev = i ? uint32_t(data[i - 1]) : prev0;
         for (; i < n; ++i) {
             uint32_t c = data[i];
-            hist_add(h, counts, prev, c, cross, cross_cap);
+            hist_add<GUARD>(h, counts, prev, c, cross, cross_cap);
             prev = c;
         }
     }
@@ -212,7 +222,13 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_o1_kernel(const uint8_t *__
 
 // Sums the workgroups' slabs into the 64-bit counters (which already hold the 16384-credits of counter
 // overflows): thread w owns word w = two counters, reads are coalesced across the block.
-__global__ __launch_bounds__(256) void hist_reduce_kernel(const uint32_t *__restrict__ slab, uint32_t nslab, unsigned long long *counts) {
+// check (the workspace's first 64 bytes: [0] status, [2..3] running total, [4] ticket): the grand total of the counts
+// must be the number of bytes counted (the reference's counts sum to the file size, src/main.cpp:176-178); a 16-bit
+// field that spilled into its neighbour, a lost fix-up or a damaged slab all break that, and the last block to finish
+// says so in the status word (mh_dev_status -> MH_ERR_CORRUPT).
+__global__ __launch_bounds__(256) void hist_reduce_kernel(const uint32_t *__restrict__ slab, uint32_t nslab, unsigned long long *counts,
+                                                          unsigned int *check, unsigned long long n) {
+    __shared__ unsigned long long part[4];
     const uint32_t w = blockIdx.x * 256u + threadIdx.x;          // < 32768
     unsigned long long lo = 0, hi = 0;
     for (uint32_t s = 0; s < nslab; ++s) {
@@ -221,8 +237,24 @@ __global__ __launch_bounds__(256) void hist_reduce_kernel(const uint32_t *__rest
         hi += v >> 16;
     }
     const uint32_t s1 = w | 0x8000u;
-    counts[hist_slot_prev(w) * 256u + (w >> 8)] += lo;
-    counts[hist_slot_prev(s1) * 256u + (s1 >> 8)] += hi;
+    const unsigned long long c0 = counts[hist_slot_prev(w) * 256u + (w >> 8)] + lo;
+    const unsigned long long c1 = counts[hist_slot_prev(s1) * 256u + (s1 >> 8)] + hi;
+    counts[hist_slot_prev(w) * 256u + (w >> 8)] = c0;
+    counts[hist_slot_prev(s1) * 256u + (s1 >> 8)] = c1;
+    if (!check) return;
+    unsigned long long t = c0 + c1;
+    for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d);
+    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long *total = reinterpret_cast<unsigned long long *>(check + 2);
+        atomicAdd(total, part[0] + part[1] + part[2] + part[3]);
+        __threadfence();
+        if (atomicAdd(check + 4, 1u) == gridDim.x - 1u) {       // the last block: every block's share is in
+            const unsigned long long all = atomicAdd(total, 0ull);
+            if (all != n) atomicExch(reinterpret_cast<int *>(check), MHK_STATUS_CORRUPT);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1726,6 +1758,13 @@ __device__ __forceinline__ uint64_t st_make(const IdxParams &p, uint32_t ctx, ui
 __device__ __forceinline__ uint64_t st_pos(const IdxParams &p, uint64_t s) { return s & ((1ull << st_shift(p)) - 1ull); }
 __device__ __forceinline__ uint32_t st_ctx(const IdxParams &p, uint64_t s) { return uint32_t(s >> st_shift(p)); }
 
+// the fine index entry (mh_kernels.h, TileParams) of symbol number g, when g starts a 64-symbol sub-chunk: the fill
+// passes know every symbol's context and position, so a stream that came without any index gets the tile decoder too
+__device__ __forceinline__ void idx_fine_entry(const IdxParams &p, uint64_t g, uint32_t prev, uint64_t pos) {
+    if (p.fine && p.order != 2 && (g & ((1u << T_SUB_SHIFT) - 1u)) == 0 && (g >> T_SUB_SHIFT) < p.fine_cap)
+        p.fine[g >> T_SUB_SHIFT] = (prev << 24) | (uint32_t(pos) & FINE_POS_MASK);
+}
+
 // Decodes from `start` until the bit position reaches seg_end.  Returns the end state; *count = symbols
 // whose code starts before seg_end.  ON_SYMBOL(k, prev_before, pos_before) is called per symbol.
 // A null table entry stops the walk (*bad): speculative starts may run into one legitimately.
@@ -1804,6 +1843,7 @@ __global__ __launch_bounds__(256) void index_fill_kernel(IdxParams p) {
             const uint64_t ci = g >> p.chunk_shift;
             if (ci < p.index_cap) p.index[ci] = st_make(p, prev, pos); else overflow = true;
         }
+        idx_fine_entry(p, g, prev, pos);
     });
     if (overflow) atomicExch(p.status, MHK_STATUS_CAPACITY);
     // with true start states a null entry, a mismatch with the converged end state, or a stream that does
@@ -1887,6 +1927,7 @@ __global__ __launch_bounds__(64) void index_group_fill_kernel(IdxParams p, IdxFi
             const uint64_t ci = k >> p.chunk_shift;
             if (ci < p.index_cap) p.index[ci] = st_pack(prev, pos); else overflow = true;
         }
+        idx_fine_entry(p, k, prev, pos);
         uint32_t used = 0;
         prev = decode_one(p.prim, p.sec_base, tabs, src, bc, prev, used, bad);
         pos += used;
@@ -1971,6 +2012,7 @@ __global__ __launch_bounds__(64) void index_state_fill_kernel(IdxParams p, IdxSt
             const uint64_t cidx = k >> p.chunk_shift;
             if (cidx < p.index_cap) p.index[cidx] = st_pack(prev, pos); else overflow = true;
         }
+        idx_fine_entry(p, k, prev, pos);
         uint32_t used = 0;
         prev = decode_one(p.prim, p.sec_base, tabs, src, bc, prev, used, bad);
         pos += used;
@@ -2010,6 +2052,7 @@ __global__ __launch_bounds__(64) void build_index_kernel(IdxParams p) {
             if (ci >= p.index_cap) { atomicExch(p.status, MHK_STATUS_CAPACITY); break; }
             p.index[ci] = (uint64_t(prev) << (ORDER == 2 ? 48 : 56)) | bi;
         }
+        idx_fine_entry(p, nsym, prev, bi);
         uint32_t used = 0;
         const uint32_t sym = decode_one(prim, p.sec_base, tabs, src, bc, prev, used, bad);
         if (bad) break;
@@ -2383,25 +2426,35 @@ hipError_t launch_hist_o1(const uint8_t *d_data, uint64_t n, uint32_t prev0, uns
     const bool ws_ok = d_ws && (reinterpret_cast<uintptr_t>(d_ws) & 15u) == 0;
     const RegionGeom g = region_geom(n);
     const bool regions = ws_ok && ws_bytes >= g.total;
-    if (regions) {      // the header says whose histogram the workspace holds (the region encoder checks it)
-        HistHeader h{HIST_WS_MAGIC, n, reinterpret_cast<unsigned long long>(d_data), g.region_vecs, uint32_t(g.grid), prev0, g.cross_cap, 0};
-        hipLaunchKernelGGL(hist_header_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<HistHeader *>(ws), h);
-    } else if (ws_ok && ws_bytes >= 256) {
-        e = hipMemsetAsync(ws, 0, 64, st);                      // no longer the histogram of anything
+    const char *dbg = getenv("MH_DEBUG_HIST_GUARD1");
+    const bool guard1 = dbg && atoi(dbg) != 0;                   // debug: one guard bit (loses counts on long runs of one pair)
+    // workspace: [0,64) status block (status word, the conservation check's total and ticket) | [64,256) header
+    if (ws_ok && ws_bytes >= 256) {
+        e = hipMemsetAsync(ws, 0, 128, st);                     // status OK; no longer the histogram of anything
         if (e != hipSuccess) return e;
+    }
+    unsigned int *check = (ws_ok && ws_bytes >= 256) ? reinterpret_cast<unsigned int *>(ws) : nullptr;
+    if (regions && !guard1) {   // the header says whose histogram the workspace holds (the region encoder checks it)
+        HistHeader h{HIST_WS_MAGIC, n, reinterpret_cast<unsigned long long>(d_data), g.region_vecs, uint32_t(g.grid), prev0, g.cross_cap, 0};
+        hipLaunchKernelGGL(hist_header_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<HistHeader *>(ws + 64), h);
     }
     if (n == 0) {
         if (regions) { e = hipMemsetAsync(ws + g.off_cross, 0, size_t(g.grid) * (g.cross_cap + 1u) * 4u, st); if (e != hipSuccess) return e;
                        e = hipMemsetAsync(ws + g.off_slab, 0, size_t(g.grid) * 32768u * 4u, st); }
         return e;
     }
-    e = once_per_device(&DeviceState::hist_ready, [] { return allow_lds(reinterpret_cast<const void *>(hist_o1_kernel), HIST_LDS_BYTES); });
+    e = once_per_device(&DeviceState::hist_ready, [] {
+        hipError_t r = allow_lds(reinterpret_cast<const void *>(hist_o1_kernel<14>), HIST_LDS_BYTES);
+        return r != hipSuccess ? r : allow_lds(reinterpret_cast<const void *>(hist_o1_kernel<15>), HIST_LDS_BYTES);
+    });
     if (e != hipSuccess) return e;
+    auto kern = guard1 ? hist_o1_kernel<15> : hist_o1_kernel<14>;
     if (regions) {
         uint32_t *slab = reinterpret_cast<uint32_t *>(ws + g.off_slab);
-        hipLaunchKernelGGL(hist_o1_kernel, dim3(g.grid), dim3(HIST_THREADS), HIST_LDS_BYTES, st, d_data, n, prev0, d_counts, slab,
+        hipLaunchKernelGGL(kern, dim3(g.grid), dim3(HIST_THREADS), HIST_LDS_BYTES, st, d_data, n, prev0, d_counts, slab,
                            g.region_vecs, reinterpret_cast<uint32_t *>(ws + g.off_cross), g.cross_cap);
-        hipLaunchKernelGGL(hist_reduce_kernel, dim3(32768 / 256), dim3(256), 0, st, slab, uint32_t(g.grid), d_counts);
+        hipLaunchKernelGGL(hist_reduce_kernel, dim3(32768 / 256), dim3(256), 0, st, slab, uint32_t(g.grid), d_counts, check,
+                           (unsigned long long)(n));
         return hipGetLastError();
     }
     uint64_t nvec = n >> 4;
@@ -2409,9 +2462,10 @@ hipError_t launch_hist_o1(const uint8_t *d_data, uint64_t n, uint32_t prev0, uns
     int grid = int(want < 1 ? 1 : (want > uint64_t(cu_count()) ? uint64_t(cu_count()) : want));
     // with a (smaller) workspace the workgroups' counters go out as plain stores and are summed by a second kernel
     uint32_t *slab = (ws_ok && ws_bytes >= 256 + size_t(grid) * 32768u * 4u) ? reinterpret_cast<uint32_t *>(ws + 256) : nullptr;
-    hipLaunchKernelGGL(hist_o1_kernel, dim3(grid), dim3(HIST_THREADS), HIST_LDS_BYTES, st, d_data, n, prev0, d_counts, slab,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(HIST_THREADS), HIST_LDS_BYTES, st, d_data, n, prev0, d_counts, slab,
                        uint64_t(0), static_cast<uint32_t *>(nullptr), 0u);
-    if (slab) hipLaunchKernelGGL(hist_reduce_kernel, dim3(32768 / 256), dim3(256), 0, st, slab, uint32_t(grid), d_counts);
+    if (slab) hipLaunchKernelGGL(hist_reduce_kernel, dim3(32768 / 256), dim3(256), 0, st, slab, uint32_t(grid), d_counts, check,
+                                 (unsigned long long)(n));
     return hipGetLastError();
 }
 
@@ -2501,6 +2555,8 @@ hipError_t launch_encode(const EncodeArgs &a, void *d_ws, hipStream_t st) {
         return r != hipSuccess ? r : allow_lds(reinterpret_cast<const void *>(enc_emit_kernel), EMIT_LDS_BYTES);
     });
     if (e != hipSuccess) return e;
+    // which encoder ran (status block bytes 8..11, mh_dev_encode_path): ENC_PATH_LENGTH_PASS
+    hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<uint32_t *>(ws + 8), uint32_t(ENC_PATH_LENGTH_PASS));
     uint32_t *wt_bits = reinterpret_cast<uint32_t *>(ws + L.off_bits);
     unsigned long long *wt_start = reinterpret_cast<unsigned long long *>(ws + L.off_start);
     unsigned long long *blk_sum = reinterpret_cast<unsigned long long *>(ws + L.off_blk);
@@ -2557,13 +2613,15 @@ hipError_t launch_encode_regions(const EncodeArgs &a, const void *d_hist_ws, siz
     unsigned long long *region_start = region_bits + 1024;
     uint32_t *region_esc = reinterpret_cast<uint32_t *>(region_start + 1024);
     const HistHeader expect{HIST_WS_MAGIC, a.n, reinterpret_cast<unsigned long long>(a.data), g.region_vecs, uint32_t(g.grid), a.prev0, g.cross_cap, 0};
-    hipLaunchKernelGGL(region_bits_kernel, dim3(g.grid), dim3(1024), 0, st, reinterpret_cast<const HistHeader *>(hws), expect,
+    hipLaunchKernelGGL(region_bits_kernel, dim3(g.grid), dim3(1024), 0, st, reinterpret_cast<const HistHeader *>(hws + 64), expect,
                        reinterpret_cast<const uint32_t *>(hws + g.off_slab), reinterpret_cast<const uint32_t *>(hws + g.off_cross), a.len8,
                        region_bits, region_esc, status);
     hipLaunchKernelGGL(region_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, region_bits, uint32_t(g.grid), region_start, a.start_bit,
                        a.out, a.cap & ~uint64_t(3), a.nbits, status);
     EmitParams ep{a.data, a.n, a.prev0, a.chunk_shift, a.out, a.enc16, a.len8, a.code64, nullptr, nullptr, 0, a.index, status, a.fine};
     RegionParams rp{region_start, region_bits, region_esc, g.region_vecs, g.nvec_up, (a.cap & ~uint64_t(3)) >> 2, status};
+    hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<uint32_t *>(ws + 8),
+                       uint32_t(a.max_len > mh::ENC16_MAX_LEN ? ENC_PATH_REGIONS_ESCAPES : ENC_PATH_REGIONS));
     hipLaunchKernelGGL(enc_region_kernel<false>, dim3(g.grid), dim3(E_THREADS), REGION_LDS_BYTES, st, ep, rp);
     if (a.max_len > mh::ENC16_MAX_LEN)           // the model has codes over 12 bits: the regions that contain any
         hipLaunchKernelGGL(enc_region_kernel<true>, dim3(g.grid), dim3(E_THREADS), REGION_LDS_BYTES, st, ep, rp);
@@ -2717,6 +2775,12 @@ static IdxWs idx_ws_layout(uint64_t nbits) {
 }
 size_t build_index_workspace_bytes(uint64_t nbits) { return idx_ws_layout(nbits).total; }
 
+// which way the index was built (status block of the workspace, bytes 8..11; mh_dev_index_path): tests tell the
+// fallbacks apart by this, not by the clock
+static void note_index_path(unsigned char *ws, uint32_t path, hipStream_t st) {
+    hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<uint32_t *>(ws + 8), path);
+}
+
 // Synchronises `st` between batches of passes (the pass count depends on the data).
 hipError_t launch_build_index(IdxParams p, void *d_ws, hipStream_t st) {
     unsigned char *ws = static_cast<unsigned char *>(d_ws);
@@ -2789,6 +2853,7 @@ hipError_t launch_build_index(IdxParams p, void *d_ws, hipStream_t st) {
         }
     }
     if (!converged && (L.nseg < 256 || p.order == 2)) {          // a workspace too small to hold the maps (a small stream); order 2
+        note_index_path(ws, IDX_PATH_WALK, st);
         if (p.order == 2) hipLaunchKernelGGL(build_index_kernel<2>, dim3(1), dim3(64), 0, st, p);
         else hipLaunchKernelGGL(build_index_kernel<1>, dim3(1), dim3(64), (size_t(256) << p.P) * 2, st, p);
         return hipGetLastError();
@@ -2837,6 +2902,7 @@ hipError_t launch_build_index(IdxParams p, void *d_ws, hipStream_t st) {
             if (e != hipSuccess) return e;
             IdxFixed f{d_live, nlive, l0, gfix, shift, nsym, ngroups, reinterpret_cast<uint8_t *>(p.seg_end_state), reinterpret_cast<uint8_t *>(p.seg_used)};
             const uint64_t nthreads = ngroups * nlive;
+            note_index_path(ws, IDX_PATH_GROUP_MAPS, st);
             hipLaunchKernelGGL(index_group_map_kernel, dim3(unsigned((nthreads + 255) / 256)), dim3(256), 0, st, p, f);
             hipLaunchKernelGGL(index_group_chain_kernel, dim3(1), dim3(64), 0, st, p, f);
             hipLaunchKernelGGL(index_group_fill_kernel, dim3(unsigned((ngroups + 63) / 64)), dim3(64), 0, st, p, f);
@@ -2864,6 +2930,7 @@ hipError_t launch_build_index(IdxParams p, void *d_ws, hipStream_t st) {
                 IdxState f{aux, aux + 256, nlive, maxlen, shift, ngroups, reinterpret_cast<unsigned long long *>(ws + L.off_end),
                            reinterpret_cast<uint16_t *>(aux + gstart_off), reinterpret_cast<unsigned long long *>(aux + gbase_off)};
                 const uint64_t nthreads = ngroups * nlive * maxlen;
+                note_index_path(ws, IDX_PATH_STATE_MAPS, st);
                 hipLaunchKernelGGL(index_state_map_kernel, dim3(unsigned((nthreads + 255) / 256)), dim3(256), 0, st, p, f);
                 hipLaunchKernelGGL(index_state_chain_kernel, dim3(1), dim3(64), 0, st, p, f);
                 hipLaunchKernelGGL(index_state_fill_kernel, dim3(unsigned((ngroups + 63) / 64)), dim3(64), 0, st, p, f);
@@ -2871,10 +2938,12 @@ hipError_t launch_build_index(IdxParams p, void *d_ws, hipStream_t st) {
             }
         }
         // the slow, certain way: one lane walks the payload
+        note_index_path(ws, IDX_PATH_WALK, st);
         if (p.order == 2) hipLaunchKernelGGL(build_index_kernel<2>, dim3(1), dim3(64), 0, st, p);
         else hipLaunchKernelGGL(build_index_kernel<1>, dim3(1), dim3(64), (size_t(256) << p.P) * 2, st, p);
         return hipGetLastError();
     }
+    note_index_path(ws, IDX_PATH_SEGMENTS, st);
     unsigned long long *blk_sum = reinterpret_cast<unsigned long long *>(ws + L.off_blk);
     hipLaunchKernelGGL(scan_local_kernel, dim3(unsigned(nblk)), dim3(SCAN_THREADS), 0, st, p.seg_count, p.nseg, p.seg_sym_start, blk_sum);
     hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, blk_sum, nblk, static_cast<const unsigned long long *>(nullptr));

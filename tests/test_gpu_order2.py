@@ -143,7 +143,8 @@ def test_order2_large_text_round_trip_parity_unpinned(mhc, oracle):
     t0 = time.perf_counter()
     assert m.decompress(blob) == data
     dt = time.perf_counter() - t0
-    assert dt < 4.0, "order-2 decode without an index took %.1f s: the one-lane walk?" % dt
+    assert mhc.lib().mh_last_index_path() == 1, "not the segment iteration"       # 4 would be the one-lane walk
+    assert dt < 15.0, "order-2 decode without an index took %.1f s" % dt
 
 
 def test_order2_codes_longer_than_the_packed_entry_parity_unpinned(mhc, oracle):
