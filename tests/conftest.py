@@ -5,6 +5,11 @@ import sys
 
 import pytest
 
+try:                      # torch (bench.py, the sharded tests) brings its own HIP runtime: when libmhc.so is loaded first the
+    import torch  # noqa: F401   # process ends up with two runtimes and torch then sees no GPU, so torch is always imported first
+except Exception:         # (the codec itself does not need torch)
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

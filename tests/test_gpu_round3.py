@@ -41,23 +41,25 @@ def dev_hist(mhc, data, prev0=0x20):
 
 def test_histogram_conservation_check_catches_a_spilled_counter(mhc):
     """64 MiB of zeros: every add of a workgroup goes to ONE 16-bit LDS field.  The product (two guard bits) counts
-    them all and the device-side check (sum of counts == n, src/main.cpp:176-178) stays silent; the debug variant
-    with ONE guard bit — round 1's kernel — lets the field spill into its neighbour, and the check reports it."""
+    them all and the device-side check (sum of counts == n, src/main.cpp:176-178) stays silent; the debug variants
+    with one guard bit (round 1's kernel) or none let the field spill into its neighbour, and the check reports it."""
     data = np.zeros(64 << 20, dtype=np.uint8)
     lib = mhc.lib()
     d_data, d_counts, d_hws, hws = dev_hist(mhc, data)
     assert lib.mh_dev_status(d_hws.ptr, None) == 0
     counts = d_counts.download(np.uint64)
     assert int(counts.sum()) == data.size and int(counts[0]) == data.size - 1
-    os.environ["MH_DEBUG_HIST_GUARD1"] = "1"
-    try:
-        d_data, d_counts, d_hws, hws = dev_hist(mhc, data)
-        rc = lib.mh_dev_status(d_hws.ptr, None)
-        lost = data.size - int(d_counts.download(np.uint64).sum())
-    finally:
-        del os.environ["MH_DEBUG_HIST_GUARD1"]
-    assert lost != 0, "the one-guard-bit variant did not lose counts here: the test no longer exercises the check"
-    assert rc == mhc.MH_ERR_CORRUPT
+    for bits in ("0", "1"):          # no guard bit: a wrapping field always carries into its neighbour; one: timing decides
+        os.environ["MH_DEBUG_HIST_GUARD_BITS"] = bits
+        try:
+            d_data, d_counts, d_hws, hws = dev_hist(mhc, data)
+            rc = lib.mh_dev_status(d_hws.ptr, None)
+            lost = data.size - int(d_counts.download(np.uint64).sum())
+        finally:
+            del os.environ["MH_DEBUG_HIST_GUARD_BITS"]
+        if bits == "0":
+            assert lost != 0, "the debug variant without guard bits did not lose counts: the test no longer exercises the check"
+        assert (rc == mhc.MH_ERR_CORRUPT) == (lost != 0), (bits, rc, lost)
 
 
 def encode_at(mhc, m, data, d_data, chunk=1024, fine=False):
