@@ -395,7 +395,8 @@ def main():
     nbits = int(codec.nbits[0].item())
     rc = codec.lib.mh_dev_status(codec.enc_ws.data_ptr(), codec.stream())
     rc2 = codec.lib.mh_dev_status(codec.dec_ws.data_ptr(), codec.stream())
-    round_trip = bool(rc == 0 and rc2 == 0 and torch.equal(codec.decoded, data))
+    rc3 = codec.lib.mh_dev_status(codec.hist_ws.data_ptr(), codec.stream()) if args.order == 1 else 0   # counts add up to n
+    round_trip = bool(rc == 0 and rc2 == 0 and rc3 == 0 and torch.equal(codec.decoded, data))
     if world > 1:     # the shard ended where its histogram said it would: the ranks' payloads tile the global stream
         round_trip = round_trip and nbits == (int(start_bit.item()) & 7) + int(my_bits.item())
     ok = torch.tensor([1 if round_trip else 0], device=device)
@@ -412,23 +413,33 @@ def main():
         total_bytes = float(total)
         gbps = total_bytes / (elapsed / K) / 1e9
         # algorithmic bytes per launch: hist 1, encode 1 + r, decode r + 1 per input byte
+        dec_name = "decode_tile_kernel" if codec.use_fine else "decode_kernel"
         kernels = {
             "hist_o1_kernel": (1.0 * n, ms["hist"]),
-            "encode_kernel": ((1.0 + r) * n, ms["encode"]),
-            "decode_kernel": ((1.0 + r) * n, ms["decode"]),
+            "enc_region_kernel": ((1.0 + r) * n, ms["encode"]),
+            dec_name: ((1.0 + r) * n, ms["decode"]),
         }
         dom = max(kernels, key=lambda k: kernels[k][1])
         if args.order == 2:
-            kernels = {k.replace("hist_o1", "hist_o2").replace("encode_kernel", "enc2_emit_kernel").replace("decode_kernel", "decode2_kernel"): v
+            kernels = {k.replace("hist_o1", "hist_o2").replace("enc_region_kernel", "enc2_emit_kernel").replace("decode_kernel", "decode2_kernel"): v
                        for k, v in kernels.items()}
             dom = max(kernels, key=lambda k: kernels[k][1])
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("%s:%d" % (dom, n))
-            except Exception:
-                traffic = None
+        # counter-derived figures of the dominant kernel come from the committed --pmc summaries (profiles/): HBM
+        # traffic per launch, and the secondary bounds — share of the kernel's time its vector ALUs issue, its LDS is
+        # busy, its texture-address units are busy — because every kernel of this path is issue-/LDS-bound long before
+        # HBM (tools/make_traffic_json.py writes both files from gpurun_out/<pmc run>)
+        traffic, secondary = None, None
+        for fname, key in (("traffic.json", "traffic"), ("secondary.json", "secondary")):
+            fpath = os.path.join(ROOT, "profiles", fname)
+            if os.path.exists(fpath):
+                try:
+                    v = json.load(open(fpath)).get("%s:%d" % (dom, n))
+                except Exception:
+                    v = None
+                if key == "traffic":
+                    traffic = v
+                else:
+                    secondary = v
         ach = kernels[dom][0] / (kernels[dom][1] * 1e-3) / 1e9
         kname = {"zipf": "Zipf(s=1.1)", "uniform": "uniform", "text": "Lorem-Ipsum-style ASCII"}[kind]
         if mode == "weak":
@@ -446,10 +457,14 @@ def main():
             "config": {"workload": workload, "baseline_config": args.config, "bytes_per_gpu": n, "total_bytes": int(total),
                        "generator": "counter-based splitmix64 (seed %d), byte i = f(seed, i): any shard regenerable alone" % seed
                                     if kind != "text" else "8 MiB of seeded Lorem-Ipsum-style text, tiled",
-                       "sharding": ("contiguous byte ranges, histogram all-reduce (RCCL, %s)" % ("512 KiB" if args.order == 1 else "128 MiB"))
-                                   if world > 1 else "single GPU"},
+                       "sharding": ("contiguous byte ranges, histogram all-reduce (%s, %s)" %
+                                    ("RCCL over xGMI" if args.backend == "nccl" else "gloo staged through host memory: REHEARSAL, not RCCL",
+                                     "512 KiB" if args.order == 1 else "128 MiB")) if world > 1 else "single GPU",
+                       "backend": (dist.get_backend() if world > 1 else None), "ranks": (dist.get_world_size() if world > 1 else 1)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_ratio": round(traffic / kernels[dom][0], 3) if traffic else None,
+                         "secondary": secondary,
                          "algorithmic_bytes_per_launch": int(kernels[dom][0])},
             "stages_ms": {k: round(v, 3) for k, v in ms.items()},
             "compress_ms": round(ms["hist"] + ms["allreduce"] + ms["tree"] + ms["encode"], 3),      # compress = hist + tree + encode
@@ -458,6 +473,9 @@ def main():
             "kernel_roofline_frac": {k: round(b / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if t > 0 else None for k, (b, t) in kernels.items()},
             "encode_read_roofline_frac": round(n / (ms["encode"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms["encode"] > 0 else None,
             "compressed_ratio": round(r, 5), "total_payload_bits": int(tot_bits.item()), "round_trip_bit_exact": round_trip_all,
+            # out-of-band bytes the decoder is handed beside the payload: the sidecar chunk index (8 B per chunk) and the
+            # device-only fine index (4 B per 64 symbols); traffic of both kernels, never credit
+            "index_bytes": {"chunk_index": int(codec.nidx * 8), "fine_index": int(((n + 63) // 64) * 4) if codec.use_fine else 0},
             "max_code_len": model.max_code_len,
             "decode_tables": dict(zip(("primary_bits", "secondary_entries", "in_lds"), model.decode_layout())),
         }

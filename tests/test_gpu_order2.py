@@ -175,3 +175,37 @@ def test_order2_codes_longer_than_the_packed_entry_parity_unpinned(mhc, oracle):
     ref, ref_bits = o.compress(data)
     assert (nbits, blob) == (ref_bits, ref)
     assert m.decompress(blob, index=idx, chunk_symbols=256, n_symbols=n) == data
+
+
+def test_order2_config5_size_properties_parity_unpinned(mhc):
+    """BASELINE config 5's size on one card: 16 GiB of Lorem-Ipsum-style text under order-2 contexts.  No oracle can
+    run at this size (and the reference has no order 2 at all: parity unpinned), so the properties the domain gives:
+    the counts add up to n, the payload length is the dot product of histogram and code lengths, the stream round-trips,
+    and a model reloaded from the table file carries the same codewords."""
+    import torch
+    import bench
+    bench.CHUNK = 1024
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    n = 16 << 30
+    data = bench.generate("text", n, 1, 0, dev)
+    codec = bench.Codec(mhc, n, dev, order=2)
+    codec.histogram(data, 0x2020)
+    assert int(codec.counts.sum().item()) == n
+    model = codec.build_model()
+    want = torch.zeros(1, dtype=torch.int64, device=dev)
+    codec.payload_bits(model, codec.counts, want)
+    codec.encode(model, data, 0x2020)
+    codec.decode(model)
+    torch.cuda.synchronize()
+    assert codec.lib.mh_dev_status(codec.enc_ws.data_ptr(), codec.stream()) == 0
+    assert codec.lib.mh_dev_status(codec.dec_ws.data_ptr(), codec.stream()) == 0
+    nbits = int(codec.nbits[0].item())
+    assert nbits == int(want.item())                              # histogram . lengths
+    assert nbits < 0.3 * 8 * n                                    # order 2 on this text: ratio ~0.265 (order 1: 0.42)
+    assert torch.equal(codec.decoded, data)
+    table = model.table_bytes()
+    t = mhc.Model.from_table(table)
+    assert t.type == 2 and t.table_bytes() == table
+    for which in (1, 3):                                          # code lengths and codewords of all 16.7 M pairs
+        assert t.image(which) == model.image(which)

@@ -76,8 +76,10 @@ def _oracle_bits(oracle_model, lens, window, prev0):
     return np.unpackbits(np.frombuffer(blob[1:], dtype=np.uint8))[skip:nbits]
 
 
-def test_payload_windows_beyond_2_pow_32_bits_match_the_oracle(mhc, oracle, bench_mod):
-    """5 GiB + a ragged tail of device-generated Zipf(1.1), encoded in one call.  For three 64 MiB windows
+@pytest.mark.parametrize("gib", [5, 16])
+def test_payload_windows_beyond_2_pow_32_bits_match_the_oracle(mhc, oracle, bench_mod, gib):
+    """5 GiB, and BASELINE config 3's full 16 GiB, + a ragged tail of device-generated Zipf(1.1), encoded in one call
+    (the bench's own calls: region histogram, region encoder with fine index, tile decoder).  For three 64 MiB windows
     (the last one included) the window's start state comes from its index entry, the same input slice is
     encoded by the oracle with the GPU-built table, and the payload bits are compared: this covers the
     64-bit offset arithmetic (scan, seams, index) against the reference, where a round trip alone would
@@ -85,7 +87,7 @@ def test_payload_windows_beyond_2_pow_32_bits_match_the_oracle(mhc, oracle, benc
     import torch
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
-    n = (5 << 30) + 12345
+    n = (gib << 30) + 12345
     chunk = 1024
     data = bench_mod.generate("zipf", n, 2, 0, dev)
     codec = bench_mod.Codec(mhc, n, dev)
@@ -96,10 +98,14 @@ def test_payload_windows_beyond_2_pow_32_bits_match_the_oracle(mhc, oracle, benc
     assert codec.lib.mh_dev_status(codec.enc_ws.data_ptr(), codec.stream()) == 0
     nbits = int(codec.nbits[0].item())
     assert nbits > (1 << 34)
+    assert codec.lib.mh_dev_status(codec.hist_ws.data_ptr(), codec.stream()) == 0      # the counts add up to n
     om = oracle.Model.from_table(model.table_bytes())
     lens, _ = om.codes()
     W = 64 << 20
     starts = [1 << 30, 3 << 30, ((n - W) // chunk) * chunk]
+    if gib == 16:                                # one window past payload bit 2^36 (byte 12 GiB sits at bit ~7.5e10), the last one too
+        starts = [1 << 30, 12 << 30, ((n - W) // chunk) * chunk]
+        assert (int(codec.index[starts[1] // chunk].item()) & mhc.INDEX_BIT_MASK) > (1 << 36)
     for s in starts:
         e = min(s + W, n)
         entry0 = int(codec.index[s // chunk].item())
