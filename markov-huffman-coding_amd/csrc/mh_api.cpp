@@ -50,6 +50,14 @@ struct mh_model {
     uint32_t tile_nsec = 0;
     uint16_t *d_tprim = nullptr, *d_tsec = nullptr;
     void *d_tile_own = nullptr;  // their allocation when the model owns it
+    // order 2: tables of the live contexts, one slot each (dev_model_build2): the encoder's LDS image and the tile
+    // decoder's tables; o2_enc_ok / o2_dec_ok say whether they cover the model well enough to be used
+    void *d_o2hot = nullptr;     // one allocation: image | ctx2slot | slot_ctx | tprim | tsec
+    uint8_t *d_o2img = nullptr; uint32_t o2img_bytes = 0;
+    uint16_t *d_ctx2slot = nullptr;
+    uint32_t *d_tprim2 = nullptr, *d_tsec2 = nullptr;
+    uint32_t o2_nslots = 0, o2_p = 0, o2_h = 0, o2_nsec = 0;
+    bool o2_enc_ok = false, o2_dec_ok = false;
 };
 
 namespace {
@@ -598,6 +606,88 @@ void place2(mh_model *m, unsigned char *b, const Build2Layout &L, uint8_t **node
     m->d_enc64 = reinterpret_cast<uint64_t *>(b + L.off[11]);
 }
 
+// The live contexts' tables: slots for the heaviest live contexts whose two bytes are both among the 63 most frequent
+// byte values (ids 0..62; everything else is id 63 = escape).  Encoder image and tile-decoder tables are filled on the
+// device (o2_hot_pack_kernel); the host only ranks (it holds every context's weight after the build's one sync).
+//   o2_enc_ok: the slots carry all but 1e-5 of the input (an escape costs a whole wave sub-step the slow path)
+//   o2_dec_ok: EVERY live context has a slot (the decoder follows slot -> slot and has no other path)
+constexpr uint32_t O2_SLOTS_MAX = 440;   // (440 + 1) rows of 128 B + 8448 B of maps = 64896 B <= the length pass's 64 KiB of LDS
+constexpr uint32_t O2_TILE_P = 6;
+int o2_hot_setup(mh_model *m, const std::vector<uint64_t> &weight, const std::vector<uint8_t> &live, const uint8_t *, hipStream_t st) {
+    if (getenv("MH_O2_NO_HOT")) return MH_OK;
+    uint64_t bw[256] = {0};
+    long double total = 0;
+    uint32_t nlive = 0;
+    for (uint32_t c = 0; c < O2_CTX; ++c) {
+        if (!live[c]) continue;
+        ++nlive;
+        const uint64_t w = weight[c] ? weight[c] : 1;              // (a model from a table file has no weights)
+        bw[c >> 8] += w; bw[c & 255u] += w;
+        total += w;
+    }
+    if (nlive == 0) return MH_OK;
+    int order[256];
+    for (int i = 0; i < 256; ++i) order[i] = i;
+    std::stable_sort(order, order + 256, [&](int a, int b) { return bw[a] > bw[b]; });
+    uint8_t symid[256];
+    std::memset(symid, 63, sizeof symid);
+    mhk::O2HotArgs a{};
+    for (int i = 0; i < 63; ++i)
+        if (bw[order[i]]) { symid[order[i]] = uint8_t(i); a.id_sym[i] = uint8_t(order[i]); a.id_used[i] = 1; }
+    std::vector<uint32_t> cand;
+    for (uint32_t c = 0; c < O2_CTX; ++c)
+        if (live[c] && symid[c >> 8] < 63 && symid[c & 255u] < 63) cand.push_back(c);
+    std::stable_sort(cand.begin(), cand.end(), [&](uint32_t x, uint32_t y) { return weight[x] > weight[y]; });
+    const uint32_t nslots = uint32_t(std::min<size_t>(cand.size(), O2_SLOTS_MAX));
+    if (nslots == 0) return MH_OK;
+    long double covered = 0;
+    std::vector<uint16_t> slot_ctx(nslots), ctx2slot(O2_CTX, 0xFFFF);
+    std::vector<unsigned char> head(8448, 0);                      // symid | ctxmap
+    std::memcpy(head.data(), symid, 256);
+    uint16_t *ctxmap = reinterpret_cast<uint16_t *>(head.data() + 256);
+    for (int i = 0; i < 64 * 64; ++i) ctxmap[i] = uint16_t(nslots);    // the all-escape row
+    for (uint32_t s = 0; s < nslots; ++s) {
+        const uint32_t c = cand[s];
+        slot_ctx[s] = uint16_t(c);
+        ctx2slot[c] = uint16_t(s);
+        ctxmap[(uint32_t(symid[c >> 8]) << 6) | symid[c & 255u]] = uint16_t(s);
+        covered += weight[c] ? weight[c] : 1;
+    }
+    const bool all_hot = nslots == nlive;
+    const uint32_t P = O2_TILE_P, H = uint32_t(std::min(std::max(m->max_len - int(P), 1), 8));
+    const bool tiles = all_hot && m->d_node_left != nullptr;
+    const size_t img = 8448 + size_t(nslots + 1) * 128;
+    auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
+    const size_t off_map = up(img), off_sc = off_map + up(size_t(O2_CTX) * 2), off_tp = off_sc + up(size_t(nslots) * 2);
+    const size_t off_ts = off_tp + (tiles ? up((size_t(nslots) << P) * 4) : 0);
+    const size_t nsec = tiles ? ((size_t(nslots) << P) << H) : 0;
+    const size_t tot = off_ts + up(nsec * 4 + 64);
+    HIP_TRY(hipMalloc(&m->d_o2hot, tot));
+    unsigned char *b = static_cast<unsigned char *>(m->d_o2hot);
+    HIP_TRY(hipMemsetAsync(b + off_ts, 0, up(nsec * 4 + 64), st));
+    HIP_TRY(hipMemcpyAsync(b, head.data(), head.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(b + off_map, ctx2slot.data(), size_t(O2_CTX) * 2, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(b + off_sc, slot_ctx.data(), size_t(nslots) * 2, hipMemcpyHostToDevice, st));
+    a.slot_ctx = reinterpret_cast<const uint16_t *>(b + off_sc); a.nslots = nslots;
+    a.len8 = m->d_len8; a.code64 = reinterpret_cast<const unsigned long long *>(m->d_code64);
+    a.hot = reinterpret_cast<uint16_t *>(b + 8448);
+    a.ctx2slot = reinterpret_cast<const uint16_t *>(b + off_map);
+    a.P = P; a.H = H;
+    if (tiles) {
+        a.node_left = m->d_node_left; a.node_right = m->d_node_right; a.node_sym = m->d_node_sym; a.ctx_meta = m->d_meta;
+        a.tprim = reinterpret_cast<uint32_t *>(b + off_tp); a.tsec = reinterpret_cast<uint32_t *>(b + off_ts);
+    }
+    HIP_TRY(mhk::launch_o2_hot_pack(a, st));
+    HIP_TRY(hipStreamSynchronize(st));                            // the staging vectors above are on this frame
+    m->d_o2img = b; m->o2img_bytes = uint32_t(img);
+    m->d_ctx2slot = reinterpret_cast<uint16_t *>(b + off_map);
+    m->o2_nslots = nslots; m->o2_p = P; m->o2_h = H; m->o2_nsec = uint32_t(nsec);
+    m->d_tprim2 = tiles ? a.tprim : nullptr; m->d_tsec2 = tiles ? a.tsec : nullptr;
+    m->o2_enc_ok = covered >= total * (1.0L - 1e-5L);
+    m->o2_dec_ok = tiles;
+    return MH_OK;
+}
+
 // counts (1 << 24, device) -> 65536 trees, codes and decode tables, all on the device
 int dev_model_build2(const uint64_t *d_counts, hipStream_t st, mh_model **out) {
     mh_model *m = new (std::nothrow) mh_model;
@@ -642,6 +732,18 @@ int dev_model_build2(const uint64_t *d_counts, hipStream_t st, mh_model **out) {
     pa.P = 8; pa.direct = 0; pa.H = 0; pa.hcap = O2_HCAP;
     pa.prim = m->d_prim; pa.sec = m->d_sec; pa.tree = m->d_tree;
     HIP_TRY_M(mhk::launch_tree_pack(pa, int(O2_CTX), st));
+    // ---- the live contexts' own tables (text-like sources: a few hundred contexts over a few dozen byte values)
+    {
+        std::vector<uint64_t> weight(O2_CTX);
+        std::vector<uint8_t> live(O2_CTX);
+        for (uint32_t c = 0; c < O2_CTX; ++c) {
+            const uint32_t *mt = &meta[size_t(c) * mhk::TB_META_STRIDE];
+            weight[c] = (uint64_t(mt[14]) << 32) | mt[13];
+            live[c] = mt[1] != 0xFFFFFFFFu;
+        }
+        const int rc2 = o2_hot_setup(m, weight, live, d_node_height, st);
+        if (rc2 != MH_OK) return fail(rc2);
+    }
     HIP_TRY_M(hipStreamSynchronize(st));                         // sec_base lives in pageable host memory
 #undef HIP_TRY_M
     *out = m;
@@ -662,9 +764,11 @@ int model2_from_table(const uint8_t *bytes, size_t n, mh_model **out) {
     std::vector<uint32_t> tree(ne, 0), sec_base(O2_CTX, 0);
     mh::BitReader in(bytes + 37, n - 37);
     mh::ContextCoder cc;
+    std::vector<uint8_t> live2(O2_CTX, 0);
     for (uint32_t c = 0; c < O2_CTX; ++c) {
         sec_base[c] = uint32_t(sec.size());
         if (in.bit()) {
+            live2[c] = 1;
             if (!cc.load(in)) { delete m; return MH_ERR_BADTABLE; }
             int live = 0;
             for (int sy = 0; sy < 256; ++sy) {
@@ -701,6 +805,10 @@ int model2_from_table(const uint8_t *bytes, size_t n, mh_model **out) {
     HIP_TRY_M(hipMemcpy(m->d_prim, prim.data(), ne * 2, hipMemcpyHostToDevice));
     HIP_TRY_M(hipMemcpy(m->d_sec_base, sec_base.data(), size_t(O2_CTX) * 4, hipMemcpyHostToDevice));
     if (!sec.empty()) HIP_TRY_M(hipMemcpy(m->d_sec, sec.data(), sec.size() * 2, hipMemcpyHostToDevice));
+    {   // the encoder's LDS image of the live contexts (no weights in a table file: every live context counts the same)
+        const int rc2 = o2_hot_setup(m, std::vector<uint64_t>(O2_CTX, 0), live2, nullptr, nullptr);
+        if (rc2 != MH_OK) return fail(rc2);
+    }
 #undef HIP_TRY_M
     *out = m;
     return MH_OK;
@@ -865,6 +973,7 @@ void mh_model_free(mh_model *m) {
     if (m->d_build) (void)hipFree(m->d_build);
     if (m->d_sec_own) (void)hipFree(m->d_sec_own);
     if (m->d_tile_own) (void)hipFree(m->d_tile_own);
+    if (m->d_o2hot) (void)hipFree(m->d_o2hot);
     delete m;
 }
 
@@ -949,7 +1058,8 @@ static int dev_encode_ctx(const mh_model *m, const uint8_t *d_data, size_t n, ui
     p.nbits = reinterpret_cast<unsigned long long *>(d_nbits);
     p.index = reinterpret_cast<unsigned long long *>(d_index);
     p.start_bit = reinterpret_cast<const unsigned long long *>(d_start_bit);
-    p.fine = m->type == 2 ? nullptr : d_fine;
+    p.fine = d_fine;
+    if (m->type == 2 && m->o2_enc_ok) { p.o2hot = m->d_o2img; p.o2hot_bytes = m->o2img_bytes; }
     HIP_TRY(mhk::launch_encode(p, d_ws, static_cast<hipStream_t>(stream)));
     return MH_OK;
 }
@@ -993,7 +1103,6 @@ int mh_dev_encode_hist(const mh_model *m, const uint8_t *d_data, size_t n, uint8
 int mh_dev_encode_fine(const mh_model *m, const uint8_t *d_data, size_t n, uint8_t prev0, const uint64_t *d_start_bit,
                        uint8_t *d_payload, size_t cap, uint64_t *d_nbits, uint64_t *d_index, uint32_t chunk_symbols, uint32_t *d_fine,
                        const void *d_hist_ws, size_t hist_ws_bytes, void *d_ws, size_t ws_bytes, void *stream) {
-    if (m && m->type == 2) d_fine = nullptr;
     return dev_encode_hist(m, d_data, n, prev0, d_start_bit, d_payload, cap, d_nbits, d_index, chunk_symbols, d_hist_ws, hist_ws_bytes,
                            d_ws, ws_bytes, stream, d_fine);
 }

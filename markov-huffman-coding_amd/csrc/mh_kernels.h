@@ -29,6 +29,8 @@ struct EncodeArgs {
     const unsigned long long *start_bit;   // device: global bit position of this payload (low 3 bits used) or nullptr
     uint32_t *fine;               // out, optional: the device-only fine index (TileParams), one entry per 64 input bytes
     int max_len;                  // the model's longest code (the region encoder launches its escape variant only above 12)
+    const uint8_t *o2hot;         // order 2, optional: the live contexts' tables for LDS (mh_kernels.hip, o2hot_lookup16)
+    uint32_t o2hot_bytes;
 };
 
 struct LenParams {
@@ -38,6 +40,8 @@ struct LenParams {
     const uint8_t *len_slot;
     uint32_t *wt_bits;
     uint64_t nwt;
+    const uint8_t *o2hot;         // order 2 with the hot image in LDS (else nullptr)
+    uint32_t o2hot_bytes;
 };
 
 struct ScanParams {
@@ -64,7 +68,9 @@ struct EmitParams {
     uint64_t nwt;
     unsigned long long *index;
     const int *status;
-    uint32_t *fine;               // optional: fine index (see TileParams)
+    uint32_t *fine;               // optional: fine index (see TileParams; order 2: context << 16 | bits from the chunk's index entry)
+    const uint8_t *o2hot;         // order 2 with the hot image in LDS (else nullptr)
+    uint32_t o2hot_bytes;
 };
 
 struct DecParams {
@@ -118,6 +124,13 @@ struct TileParams {
     uint32_t *geom;                      // [0] = largest staged piece of a wave (bytes), written by tile_geom_kernel
     uint64_t ntiles;                     // full wave pieces (K tiles of 4096 symbols each)
     uint32_t probe;                      // timing probes (MH_TILE_PROBE): results are wrong and nothing is reported
+    // order 2 (extension, parity unpinned): the LIVE contexts' tables, one slot each.  prim / sec then hold uint32
+    // entries (low half as above, high half = slot of the context that follows the symbol), the first level has
+    // nslots << P entries, index entries carry two context bytes (bits 48..63) and a fine entry is
+    // context << 16 | bits from the chunk's index entry (0xFFFF: does not fit)
+    uint32_t o2;
+    uint32_t nslots;
+    const uint16_t *ctx2slot;            // 65536 entries: slot of a two-byte context, 0xFFFF = none
 };
 size_t decode_tile_workspace_extra();    // bytes the tile decoder needs in front of the redo list (status block included)
 hipError_t launch_decode_tile(TileParams p, const DecParams &legacy, void *d_ws, hipStream_t st);
@@ -180,6 +193,21 @@ struct TreePackArgs {
     uint32_t lsb;                 // 1: tables indexed by the window's bits LSB-first (first stream bit = bit 0): the
                                   // tile decoder's layout (mh_tile.hip); 0: MSB-first (first stream bit = top bit)
 };
+// order 2: tables of the live contexts (one slot each) for the LDS-resident encoder and the tile decoder
+struct O2HotArgs {
+    const uint16_t *slot_ctx;     // nslots: the context of each slot
+    uint32_t nslots;
+    uint8_t id_sym[64];           // byte value of id 0..62 (unused ids: any value with id_used 0)
+    uint8_t id_used[64];
+    const uint8_t *len8; const unsigned long long *code64;
+    uint16_t *hot;                // (nslots + 1) * 64 u16: the encoder's rows (mh_kernels.hip, o2hot_lookup16)
+    // tile decoder tables (nullptr: none)
+    const uint16_t *node_left, *node_right; const uint8_t *node_sym; const uint32_t *ctx_meta;
+    const uint16_t *ctx2slot;
+    uint32_t P, H;
+    uint32_t *tprim, *tsec;       // nslots << P entries; (nslots << P) << H entries
+};
+hipError_t launch_o2_hot_pack(const O2HotArgs &a, hipStream_t st);
 hipError_t launch_tree_build(const unsigned long long *d_counts, int nctx, const TreeBuildOut &o, hipStream_t st);
 hipError_t launch_tree_pack(const TreePackArgs &a, int nctx, hipStream_t st);
 

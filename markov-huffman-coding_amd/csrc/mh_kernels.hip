@@ -353,17 +353,53 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
+__device__ __forceinline__ uint32_t ctx_before(const uint8_t *__restrict__ data, uint64_t n, uint64_t off, uint32_t ctx0);
+__device__ __forceinline__ uint32_t head_ctx(const LaneIn &in);
+__device__ __forceinline__ LaneIn load_raw2(const uint8_t *__restrict__ data, uint64_t n, uint64_t off, uint32_t ctx0);
+// ---- order 2 with the live contexts' tables in LDS (BASELINE config 5: "LDS codeword-table staging") ----
+// Text-like sources use a few hundred two-byte contexts over a few dozen byte values.  The model builder (mh_api.cpp,
+// dev_model_build2) ranks the byte values (the 63 most frequent get ids 0..62, every other byte id 63) and gives the
+// heaviest contexts whose two bytes both have an id < 63 a slot; the image `o2hot` it hands over is
+//     symid[256] u8 | ctxmap[64 * 64] u16 (id of the byte before the previous << 6 | id of the previous -> slot) |
+//     hot[(nslots + 1) * 64] u16 (slot << 6 | id of the symbol -> len << 12 | code, as the order-1 table)
+// with the last slot all ENC16_ESCAPE (what ctxmap gives for every other context) and column 63 all ENC16_ESCAPE.  An
+// escape sends the wave's sub-step through the symbol-by-symbol path with the full tables in L2 (emit_substep_slow<2>), so
+// the image is only handed over when the slots cover (nearly) the whole input (the builder knows every context's weight).
+constexpr uint32_t O2H_MAP_OFF = 256, O2H_HOT_OFF = 256 + 64 * 64 * 2;
+__device__ __forceinline__ void o2hot_lookup16(const unsigned char *img, const uint4 &x4, uint32_t ctx, uint32_t (&e)[16]) {
+    const uint16_t *ctxmap = reinterpret_cast<const uint16_t *>(img + O2H_MAP_OFF);
+    const uint16_t *hot = reinterpret_cast<const uint16_t *>(img + O2H_HOT_OFF);
+    const uint32_t x[4] = {x4.x, x4.y, x4.z, x4.w};
+    uint32_t id[18];
+    id[0] = img[ctx >> 8];
+    id[1] = img[ctx & 255u];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) id[2 + j] = img[(x[j >> 2] >> (8 * (j & 3))) & 255u];
+    uint32_t cs[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) cs[j] = ctxmap[(id[j] << 6) | id[j + 1]];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) e[j] = hot[(cs[j] << 6) | id[j + 2]];
+}
+
 // ---- pass 1 ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(E_THREADS, 8) void enc_len_kernel(LenParams p) {
+// ORDER 2: the hot order-2 image in LDS (o2hot_lookup16); lengths of escapes come from p.len_slot = len8[ctx * 256 + sym]
+template <int ORDER>
+__global__ __launch_bounds__(E_THREADS, ORDER == 1 ? 8 : 4) void enc_len_kernel(LenParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint8_t *ltab = smem;   // code length per slot (0..64)
-    for (int i = threadIdx.x; i < 4096; i += E_THREADS)
-        reinterpret_cast<uint4 *>(ltab)[i] = reinterpret_cast<const uint4 *>(p.len_slot)[i];
+    if (ORDER == 1) {
+        for (int i = threadIdx.x; i < 4096; i += E_THREADS)
+            reinterpret_cast<uint4 *>(ltab)[i] = reinterpret_cast<const uint4 *>(p.len_slot)[i];
+    } else {
+        for (uint32_t i = threadIdx.x; i < (p.o2hot_bytes + 15u) / 16u; i += E_THREADS)
+            reinterpret_cast<uint4 *>(smem)[i] = reinterpret_cast<const uint4 *>(p.o2hot)[i];
+    }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t wave0 = uint64_t(blockIdx.x) * E_WAVES + (threadIdx.x >> 6);
     const uint64_t nwaves = uint64_t(gridDim.x) * E_WAVES;
-    LaneIn ahead = load_raw(p.data, p.n, wave0 * E_WT + lane * E_VEC, p.prev0);
+    LaneIn ahead = ORDER == 1 ? load_raw(p.data, p.n, wave0 * E_WT + lane * E_VEC, p.prev0) : load_raw2(p.data, p.n, wave0 * E_WT + lane * E_VEC, p.prev0);
     for (uint64_t wt = wave0; wt < p.nwt; wt += nwaves) {
         uint32_t sum = 0;
 #pragma unroll 1
@@ -372,7 +408,25 @@ __global__ __launch_bounds__(E_THREADS, 8) void enc_len_kernel(LenParams p) {
             {
                 const uint64_t nwt_ = (k + 1 < E_SUBSTEPS) ? wt : wt + nwaves;
                 const uint64_t noff = nwt_ * E_WT + uint64_t((k + 1) % E_SUBSTEPS) * E_SUB + lane * E_VEC;
-                ahead = load_raw(p.data, p.n, noff, p.prev0);
+                ahead = ORDER == 1 ? load_raw(p.data, p.n, noff, p.prev0) : load_raw2(p.data, p.n, noff, p.prev0);
+            }
+            if (ORDER == 2) {
+                uint32_t e[16];
+                uint32_t ctx = head_ctx(in);
+                o2hot_lookup16(smem, in.x, ctx, e);
+                const uint32_t x[4] = {in.x.x, in.x.y, in.x.z, in.x.w};
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const uint32_t sym = (x[j >> 2] >> (8 * (j & 3))) & 255u;
+                    uint32_t l = e[j] >> 12;
+                    if (e[j] >= 0xD000u) {                     // escape: the full table in L2 (rare by construction)
+                        l = uint32_t(j) < in.nvalid ? uint32_t(p.len_slot[(ctx << 8) | sym]) : 0u;
+                        if (l > 64u) l = 0;
+                    }
+                    sum += uint32_t(j) < in.nvalid ? l : 0u;
+                    ctx = ((ctx << 8) | sym) & 0xFFFFu;
+                }
+                continue;
             }
             uint32_t w[16];
             slots16(in.x, head_byte(in), w);
@@ -514,6 +568,16 @@ __device__ __forceinline__ void flush_words(uint32_t *stage, uint32_t *out32, ui
     if (lane == 0) { stage[nfull] = 0; stage[0] = tail; }
 }
 
+// Order-2 fine index entry of the lane's sub-chunk (every fourth lane): two context bytes << 16 | bits from the chunk's
+// index entry to the sub-chunk (exc = bits of the wave's 1 KiB sub-step in front of the lane; a chunk of S <= 1024
+// symbols starts inside the sub-step, at the lane whose offset is a multiple of S).  0xFFFF: does not fit 16 bits.
+__device__ __forceinline__ void fine2_entry(const EmitParams &p, uint32_t S, uint32_t lane, uint64_t off, uint32_t nvalid, uint32_t ctx, uint32_t exc) {
+    if (!p.fine || S > uint32_t(E_SUB)) return;                  // (wave-uniform)
+    const uint32_t first = lane & ~((S >> 4) - 1u);              // the lane that starts this lane's chunk
+    const uint32_t d = exc - uint32_t(__shfl(int(exc), int(first)));
+    if (nvalid && (lane & 3u) == 0u) p.fine[off >> T_SUB_SHIFT] = (ctx << 16) | (d > 0xFFFFu ? 0xFFFFu : d);
+}
+
 // Escape path of one sub-step (some code in the wave is longer than 12 bits): everything is recomputed
 // from the lane's 16 input bytes so that the hot path keeps no per-symbol state alive.  The sub-step
 // may carry up to 64 bits per symbol, so the image is filled and flushed in rounds.
@@ -578,6 +642,7 @@ __device__ __forceinline__ void emit_substep_slow(const EmitParams &p, const uin
         p.index[off >> p.chunk_shift] = (uint64_t(pb) << (ORDER == 2 ? 48 : 56)) | (abs_bits + exc);
     if (ORDER != 2 && p.fine && nvalid && (lane & 3u) == 0u)         // every fourth lane starts a 64-symbol sub-chunk
         p.fine[off >> T_SUB_SHIFT] = (pb << 24) | (uint32_t(abs_bits + exc) & FINE_POS_MASK);
+    if (ORDER == 2) fine2_entry(p, S, lane, off, nvalid, pb, exc);
 
     const uint32_t end = cur + sub_bits;     // image bit one past the sub-step (frame of this sub-step)
     const uint32_t nwords = uint32_t(E_STAGE_WORDS - 2);
@@ -605,13 +670,23 @@ __device__ __forceinline__ void emit_substep_slow(const EmitParams &p, const uin
     sub_bits_out = sub_bits;
 }
 
+// ORDER 2: the emit loop over the hot order-2 image (o2hot_lookup16) instead of the order-1 codeword table; the context of a
+// lane is the two bytes before its vector, index entries carry it in bits 48..63, and the fine index entry is
+// context << 16 | bit offset relative to the chunk's index entry (0xFFFF: does not fit; chunks of at most 1024 symbols)
+template <int ORDER>
 __global__ __launch_bounds__(E_THREADS) void enc_emit_kernel(EmitParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t *tab = reinterpret_cast<uint16_t *>(smem);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t *stage = reinterpret_cast<uint32_t *>(smem + 131072) + wave * E_STAGE_WORDS;
-    for (int i = threadIdx.x; i < 8192; i += E_THREADS)
-        reinterpret_cast<uint4 *>(tab)[i] = reinterpret_cast<const uint4 *>(p.enc16)[i];
+    const uint32_t tab_bytes = ORDER == 1 ? 131072u : ((p.o2hot_bytes + 15u) & ~15u);
+    uint32_t *stage = reinterpret_cast<uint32_t *>(smem + tab_bytes) + wave * E_STAGE_WORDS;
+    if (ORDER == 1) {
+        for (int i = threadIdx.x; i < 8192; i += E_THREADS)
+            reinterpret_cast<uint4 *>(tab)[i] = reinterpret_cast<const uint4 *>(p.enc16)[i];
+    } else {
+        for (uint32_t i = threadIdx.x; i < tab_bytes / 16u; i += E_THREADS)
+            reinterpret_cast<uint4 *>(smem)[i] = reinterpret_cast<const uint4 *>(p.o2hot)[i];
+    }
     for (int i = lane; i < E_STAGE_WORDS; i += 64) stage[i] = 0;
     __syncthreads();
     if (*p.status != MHK_STATUS_OK) return;     // capacity overrun found by the scan: write nothing
@@ -629,15 +704,18 @@ __global__ __launch_bounds__(E_THREADS) void enc_emit_kernel(EmitParams p) {
         return (wave0 + (i >> 2) * nwaves) * E_WT + (i & 3u) * E_SUB + lane * E_VEC;
     };
     auto lookup16 = [&](const LaneIn &in, uint32_t pb, uint32_t (&e)[16]) {
+        if (ORDER == 2) { o2hot_lookup16(smem, in.x, pb, e); return; }
         uint32_t w[16];
         slots16(in.x, pb, w);
 #pragma unroll
         for (int j = 0; j < 16; ++j) e[j] = uint32_t(tab[w[j]]);
     };
-    LaneIn cur_in = load_raw(p.data, p.n, offset_of(0), p.prev0);
-    LaneIn next_in = load_raw(p.data, p.n, offset_of(1), p.prev0);
-    LaneIn next2_in = load_raw(p.data, p.n, offset_of(2), p.prev0);
-    uint32_t cur_pb = head_byte(cur_in);
+    auto load = [&](uint64_t off) -> LaneIn { return ORDER == 1 ? load_raw(p.data, p.n, off, p.prev0) : load_raw2(p.data, p.n, off, p.prev0); };
+    auto head = [&](const LaneIn &in) -> uint32_t { return ORDER == 1 ? head_byte(in) : head_ctx(in); };
+    LaneIn cur_in = load(offset_of(0));
+    LaneIn next_in = load(offset_of(1));
+    LaneIn next2_in = load(offset_of(2));
+    uint32_t cur_pb = head(cur_in);
     uint32_t E[16];
     lookup16(cur_in, cur_pb, E);
     uint64_t gbase = 0, abs_bits = 0;
@@ -657,8 +735,8 @@ __global__ __launch_bounds__(E_THREADS) void enc_emit_kernel(EmitParams p) {
         }
         const uint64_t off = wt * E_WT + uint64_t(k) * E_SUB + lane * E_VEC;
         // the next sub-steps: input three ahead (its first use, the lookups, comes two sub-steps from now), lookups one ahead
-        const LaneIn in3 = load_raw(p.data, p.n, offset_of(i + 3), p.prev0);      // past the end: zeros, nothing is read
-        const uint32_t next_pb = head_byte(next_in);
+        const LaneIn in3 = load(offset_of(i + 3));      // past the end: zeros, nothing is read
+        const uint32_t next_pb = head(next_in);
         uint32_t En[16];
         lookup16(next_in, next_pb, En);
         // ---- this sub-step
@@ -683,7 +761,7 @@ __global__ __launch_bounds__(E_THREADS) void enc_emit_kernel(EmitParams p) {
         }
         uint32_t sub_bits;
         if (__any(emax >= 0xD000u)) {        // wave-uniform: an escape code or a ragged vector somewhere
-            emit_substep_slow<1>(p, tab, stage, out32, x, pb, nvalid, lane, off, abs_bits, gbase, cur, seam0, sub_bits);
+            emit_substep_slow<ORDER>(p, tab, stage, out32, x, pb, nvalid, lane, off, abs_bits, gbase, cur, seam0, sub_bits);
         } else {
             // exclusive wave scan of the lane totals
             const uint32_t inc = wave_inclusive_sum(L);
@@ -691,9 +769,13 @@ __global__ __launch_bounds__(E_THREADS) void enc_emit_kernel(EmitParams p) {
             const uint32_t exc = inc - L;
             // chunk index: the lane whose first byte starts a chunk records (context, bit offset)
             if (p.index && nvalid && ((uint32_t(off) & (S - 1u)) == 0u))
-                p.index[off >> p.chunk_shift] = (uint64_t(pb) << 56) | (abs_bits + exc);
-            if (p.fine && nvalid && (lane & 3u) == 0u)             // fine index (mh_kernels.h, TileParams): every fourth lane
-                p.fine[off >> T_SUB_SHIFT] = (pb << 24) | (uint32_t(abs_bits + exc) & FINE_POS_MASK);
+                p.index[off >> p.chunk_shift] = (uint64_t(pb) << (ORDER == 2 ? 48 : 56)) | (abs_bits + exc);
+            if (ORDER == 1) {
+                if (p.fine && nvalid && (lane & 3u) == 0u)         // fine index (mh_kernels.h, TileParams): every fourth lane
+                    p.fine[off >> T_SUB_SHIFT] = (pb << 24) | (uint32_t(abs_bits + exc) & FINE_POS_MASK);
+            } else {
+                fine2_entry(p, S, lane, off, nvalid, pb, exc);
+            }
             uint32_t o = cur + exc;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -2272,6 +2354,7 @@ __global__ __launch_bounds__(E_THREADS) void enc2_emit_kernel(EmitParams p) {
                 const uint32_t S = 1u << p.chunk_shift;
                 if (p.index && in.nvalid && ((uint32_t(off) & (S - 1u)) == 0u))
                     p.index[off >> p.chunk_shift] = (uint64_t(ctx0) << 48) | (abs_bits + exc);
+                fine2_entry(p, S, lane, off, in.nvalid, ctx0, exc);
                 uint32_t o = cur + exc;
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
@@ -2555,8 +2638,10 @@ hipError_t launch_encode(const EncodeArgs &a, void *d_ws, hipStream_t st) {
         return hipGetLastError();
     }
     e = once_per_device(&DeviceState::encode_ready, [] {
-        hipError_t r = allow_lds(reinterpret_cast<const void *>(enc_len_kernel), LEN_LDS_BYTES);
-        return r != hipSuccess ? r : allow_lds(reinterpret_cast<const void *>(enc_emit_kernel), EMIT_LDS_BYTES);
+        hipError_t r = allow_lds(reinterpret_cast<const void *>(enc_len_kernel<1>), LEN_LDS_BYTES);
+        if (r == hipSuccess) r = allow_lds(reinterpret_cast<const void *>(enc_len_kernel<2>), LEN_LDS_BYTES);
+        if (r == hipSuccess) r = allow_lds(reinterpret_cast<const void *>(enc_emit_kernel<2>), EMIT_LDS_BYTES);
+        return r != hipSuccess ? r : allow_lds(reinterpret_cast<const void *>(enc_emit_kernel<1>), EMIT_LDS_BYTES);
     });
     if (e != hipSuccess) return e;
     // which encoder ran (status block bytes 8..11, mh_dev_encode_path): ENC_PATH_LENGTH_PASS
@@ -2567,12 +2652,16 @@ hipError_t launch_encode(const EncodeArgs &a, void *d_ws, hipStream_t st) {
 
     uint64_t want = (L.nwt + E_WAVES - 1) / E_WAVES;
     int grid = int(want > uint64_t(2 * cu_count()) ? uint64_t(2 * cu_count()) : want);
-    if (a.order == 2) {                                      // lengths gathered from the full table (a.len8)
-        LenParams lp{a.data, a.n, a.prev0, a.len8, wt_bits, L.nwt};
+    const bool hot2 = a.order == 2 && a.o2hot && a.o2hot_bytes && a.o2hot_bytes <= uint32_t(LEN_LDS_BYTES);
+    if (hot2) {                                              // the live contexts' tables in LDS (o2hot_lookup16)
+        LenParams lp{a.data, a.n, a.prev0, a.len8, wt_bits, L.nwt, a.o2hot, a.o2hot_bytes};
+        hipLaunchKernelGGL(enc_len_kernel<2>, dim3(grid), dim3(E_THREADS), (a.o2hot_bytes + 15u) & ~15u, st, lp);
+    } else if (a.order == 2) {                               // lengths gathered from the full table (a.len8)
+        LenParams lp{a.data, a.n, a.prev0, a.len8, wt_bits, L.nwt, nullptr, 0};
         hipLaunchKernelGGL(enc2_len_kernel, dim3(grid), dim3(E_THREADS), 0, st, lp);
     } else {
-        LenParams lp{a.data, a.n, a.prev0, a.len_slot, wt_bits, L.nwt};
-        hipLaunchKernelGGL(enc_len_kernel, dim3(grid), dim3(E_THREADS), LEN_LDS_BYTES, st, lp);
+        LenParams lp{a.data, a.n, a.prev0, a.len_slot, wt_bits, L.nwt, nullptr, 0};
+        hipLaunchKernelGGL(enc_len_kernel<1>, dim3(grid), dim3(E_THREADS), LEN_LDS_BYTES, st, lp);
     }
 
     hipLaunchKernelGGL(scan_local_kernel, dim3(unsigned(L.nblk)), dim3(SCAN_THREADS), 0, st, wt_bits, L.nwt, wt_start, blk_sum);
@@ -2582,13 +2671,18 @@ hipError_t launch_encode(const EncodeArgs &a, void *d_ws, hipStream_t st) {
     hipLaunchKernelGGL(scan_apply_kernel, dim3(unsigned(L.nblk)), dim3(SCAN_THREADS), 0, st, sp);
 
     EmitParams ep{a.data, a.n, a.prev0, a.chunk_shift, a.out, a.enc16, a.len8, a.code64, a.enc64, wt_start, L.nwt, a.index, status,
-                  a.order == 2 ? nullptr : a.fine};
+                  a.fine, a.o2hot, a.o2hot_bytes};
+    if (hot2) {
+        grid = int(want > uint64_t(cu_count()) ? uint64_t(cu_count()) : want);
+        hipLaunchKernelGGL(enc_emit_kernel<2>, dim3(grid), dim3(E_THREADS), ((a.o2hot_bytes + 15u) & ~15u) + E_WAVES * E_STAGE_WORDS * 4, st, ep);
+        return hipGetLastError();
+    }
     if (a.order == 2) {                                      // no table in LDS: two workgroups per CU
         hipLaunchKernelGGL(enc2_emit_kernel, dim3(grid), dim3(E_THREADS), E_WAVES * E_STAGE_WORDS * 4, st, ep);
         return hipGetLastError();
     }
     grid = int(want > uint64_t(cu_count()) ? uint64_t(cu_count()) : want);
-    hipLaunchKernelGGL(enc_emit_kernel, dim3(grid), dim3(E_THREADS), EMIT_LDS_BYTES, st, ep);
+    hipLaunchKernelGGL(enc_emit_kernel<1>, dim3(grid), dim3(E_THREADS), EMIT_LDS_BYTES, st, ep);
     return hipGetLastError();
 }
 
@@ -2622,7 +2716,7 @@ hipError_t launch_encode_regions(const EncodeArgs &a, const void *d_hist_ws, siz
                        region_bits, region_esc, status);
     hipLaunchKernelGGL(region_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, region_bits, uint32_t(g.grid), region_start, a.start_bit,
                        a.out, a.cap & ~uint64_t(3), a.nbits, status);
-    EmitParams ep{a.data, a.n, a.prev0, a.chunk_shift, a.out, a.enc16, a.len8, a.code64, nullptr, nullptr, 0, a.index, status, a.fine};
+    EmitParams ep{a.data, a.n, a.prev0, a.chunk_shift, a.out, a.enc16, a.len8, a.code64, nullptr, nullptr, 0, a.index, status, a.fine, nullptr, 0};
     RegionParams rp{region_start, region_bits, region_esc, g.region_vecs, g.nvec_up, (a.cap & ~uint64_t(3)) >> 2, status};
     hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<uint32_t *>(ws + 8),
                        uint32_t(a.max_len > mh::ENC16_MAX_LEN ? ENC_PATH_REGIONS_ESCAPES : ENC_PATH_REGIONS));

@@ -454,6 +454,60 @@ __global__ __launch_bounds__(256) void tree_pack_kernel(TreePackArgs a) {
     if (a.tree) a.tree[c * TREE_STRIDE + tid] = tr[tid];      // (a second packing of the same trees leaves the walk tree alone)
 }
 
+// ---- order 2: the live contexts' tables ("LDS codeword-table staging") --------------------------
+// one wave per slot; the last block (slot == nslots) writes the encoder's all-escape row
+__global__ __launch_bounds__(64) void o2_hot_pack_kernel(O2HotArgs a) {
+    const uint32_t slot = blockIdx.x, lane = threadIdx.x;
+    if (slot == a.nslots) { a.hot[slot * 64u + lane] = mh::ENC16_ESCAPE; return; }
+    const uint32_t ctx = a.slot_ctx[slot];
+    {   // encoder row: id of the symbol -> len << 12 | code, ENC16_ESCAPE for codes over 12 bits, id 63 and unused ids
+        uint16_t e = mh::ENC16_ESCAPE;
+        if (lane < 63 && a.id_used[lane]) {
+            const uint32_t k = ctx * 256u + a.id_sym[lane];
+            const uint32_t l = a.len8[k];
+            e = l == 0 ? uint16_t(0) : (l > uint32_t(mh::ENC16_MAX_LEN) ? mh::ENC16_ESCAPE : uint16_t((l << 12) | uint32_t(a.code64[k])));
+        }
+        a.hot[slot * 64u + lane] = e;
+    }
+    if (!a.tprim) return;
+    // tile decoder: first level of P bits (lane = window value, LSB-first), uniform second-level tables of 2^H entries;
+    // entry = next slot << 16 | 0x8000 | length << 8 | symbol (leaf) or the table id (inner node at depth P)
+    const uint32_t P = a.P, H = a.H;
+    const uint16_t *left = a.node_left + size_t(ctx) * TB_NODE_STRIDE, *right = a.node_right + size_t(ctx) * TB_NODE_STRIDE;
+    const uint8_t *sym = a.node_sym + size_t(ctx) * TB_NODE_STRIDE;
+    const uint32_t root = a.ctx_meta[size_t(ctx) * TB_META_STRIDE + 1];
+    auto leaf_entry = [&](uint32_t node, uint32_t len) -> uint32_t {
+        const uint32_t s = sym[node];
+        uint32_t nxt = a.ctx2slot[((ctx & 255u) << 8) | s];
+        if (nxt == 0xFFFFu) nxt = 0;                              // no live context follows: only at the very end of a stream
+        return (nxt << 16) | DEC16_LEAF | (len << 8) | s;
+    };
+    for (uint32_t w = lane; w < (1u << P); w += 64u) {            // (P <= 6: one pass)
+        uint32_t node = root, depth = 0;
+        if (root != 0xFFFFFFFFu)
+            while (depth < P && left[node] != NONE) { node = ((w >> depth) & 1u) ? right[node] : left[node]; ++depth; }
+        const bool inner = root != 0xFFFFFFFFu && left[node] != NONE;
+        const unsigned long long m = __ballot(inner);
+        const uint32_t rank = uint32_t(__popcll(m & ((1ull << lane) - 1ull)));
+        const uint32_t id = (slot << P) + rank;                   // sparse ids: at most 2^P tables per slot
+        uint32_t e = DEC16_NULL;
+        if (root != 0xFFFFFFFFu) e = inner ? id : leaf_entry(node, depth);
+        a.tprim[(slot << P) + w] = e;
+        if (inner) {
+            for (uint32_t x = 0; x < (1u << H); ++x) {
+                uint32_t n2 = node, d2 = 0;
+                while (d2 < H && left[n2] != NONE) { n2 = ((x >> d2) & 1u) ? right[n2] : left[n2]; ++d2; }
+                a.tsec[(size_t(id) << H) + x] = left[n2] == NONE ? leaf_entry(n2, P + d2) : 0u;   // deeper than P + H: unresolved (redo pass)
+            }
+        }
+    }
+}
+
+hipError_t launch_o2_hot_pack(const O2HotArgs &a, hipStream_t st) {
+    hipLaunchKernelGGL(o2_hot_pack_kernel, dim3(a.nslots + 1), dim3(64), 0, st, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_tree_build(const unsigned long long *d_counts, int nctx, const TreeBuildOut &o, hipStream_t st) {
     hipLaunchKernelGGL(tree_build_kernel, dim3(nctx), dim3(64), 0, st, d_counts, o);
     return hipGetLastError();
