@@ -148,7 +148,7 @@ class Codec:
         self.nbits = torch.zeros(2, dtype=torch.int64, device=device)
         # device-only fine index (one uint32 per 64 symbols): what lets a wave decode 64 adjacent pieces from one
         # contiguous piece of the payload (mh_dev_encode_fine / mh_dev_decode_fine); MH_BENCH_NO_FINE=1: without it
-        self.use_fine = order == 1 and not os.environ.get("MH_BENCH_NO_FINE") and not os.environ.get("MH_BENCH_TWO_PASS_ENCODE")
+        self.use_fine = not os.environ.get("MH_BENCH_NO_FINE") and not (order == 1 and os.environ.get("MH_BENCH_TWO_PASS_ENCODE"))
         self.fine = torch.empty(max((n + 63) // 64, 1), dtype=torch.int32, device=device) if self.use_fine else None
         self.hist_ws_bytes = int(self.lib.mh_dev_histogram_workspace(n))
         self.hist_ws = torch.empty(self.hist_ws_bytes, dtype=torch.uint8, device=device)
@@ -198,11 +198,12 @@ class Codec:
                                                    self.hist_ws.data_ptr(), self.hist_ws_bytes,
                                                    self.enc_ws.data_ptr(), self.enc_ws_bytes, self.stream()), "encode")
             return
-        self.check(self.lib.mh_dev_encode_ctx(model.handle, data.data_ptr(), self.n, prev0,
-                                              start_bit.data_ptr() if start_bit is not None else None,
-                                              self.payload.data_ptr(), self.cap,
-                                              self.nbits.data_ptr(), self.index.data_ptr(), CHUNK, self.enc_ws.data_ptr(),
-                                              self.enc_ws_bytes, self.stream()), "encode")
+        self.check(self.lib.mh_dev_encode_ctx_fine(model.handle, data.data_ptr(), self.n, prev0,
+                                                   start_bit.data_ptr() if start_bit is not None else None,
+                                                   self.payload.data_ptr(), self.cap,
+                                                   self.nbits.data_ptr(), self.index.data_ptr(), CHUNK,
+                                                   self.fine.data_ptr() if self.use_fine else None, self.enc_ws.data_ptr(),
+                                                   self.enc_ws_bytes, self.stream()), "encode")
 
     def decode(self, model):
         """The payload length stays on the device (self.nbits[0], written by the encoder)."""

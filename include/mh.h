@@ -325,8 +325,10 @@ int mh_dev_decode_dn(const mh_model *m, const uint8_t *d_payload, const uint64_t
  * 64-symbol pieces: its compressed input and its output are each one contiguous run of memory (mh_tile.hip)
  * instead of 64 scattered cache lines per access.  It costs 1/16 of the input size in HBM, is written by
  * mh_dev_encode_fine alongside the payload (or by mh_dev_build_index_fine for a stream that came without any
- * index) and is consumed by mh_dev_decode_fine; it lives and dies in device memory.  Order-0/1 models only
- * (an order-2 model ignores d_fine); chunk_symbols <= 4096 for the decoder to use it.
+ * index) and is consumed by mh_dev_decode_fine; it lives and dies in device memory.  chunk_symbols <= 4096 for the
+ * decoder to use it.  Order-2 models (extension): entry = two context bytes << 16 | bits from the chunk's index entry
+ * to the piece (0xFFFF: does not fit), chunk_symbols <= 1024, and only models whose live contexts all have a slot in
+ * the decoder's LDS tables (text-like sources: a few hundred contexts) use it; mh_dev_build_index_fine writes none.
  */
 #define MH_FINE_SYMBOLS 64u
 static inline uint64_t mh_fine_entries(uint64_t n_symbols) { return (n_symbols + MH_FINE_SYMBOLS - 1) / MH_FINE_SYMBOLS; }
@@ -338,6 +340,12 @@ int mh_dev_encode_fine(const mh_model *m, const uint8_t *d_data, size_t n, uint8
                        uint64_t *d_index, uint32_t chunk_symbols, uint32_t *d_fine,
                        const void *d_hist_ws, size_t hist_ws_bytes,
                        void *d_ws, size_t ws_bytes, void *stream);
+/* mh_dev_encode_ctx (full start context: two bytes for an order-2 model) that also fills d_fine. */
+int mh_dev_encode_ctx_fine(const mh_model *m, const uint8_t *d_data, size_t n, uint32_t ctx0,
+                           const uint64_t *d_start_bit,
+                           uint8_t *d_payload, size_t cap, uint64_t *d_nbits,
+                           uint64_t *d_index, uint32_t chunk_symbols, uint32_t *d_fine,
+                           void *d_ws, size_t ws_bytes, void *stream);
 /* mh_dev_decode / mh_dev_decode_dn (d_nbits != NULL: the payload length is read there, nbits is a hint) with the
  * fine index of the same stream.  d_fine == NULL, a model without tile tables, chunk_symbols > 4096 or a small
  * stream: exactly mh_dev_decode.  Same output either way; same workspace size. */

@@ -1116,6 +1116,13 @@ int mh_dev_encode_ctx(const mh_model *m, const uint8_t *d_data, size_t n, uint32
     return dev_encode_ctx(m, d_data, n, ctx0, d_start_bit, d_payload, cap, d_nbits, d_index, chunk_symbols, d_ws, ws_bytes, stream, nullptr);
 }
 
+int mh_dev_encode_ctx_fine(const mh_model *m, const uint8_t *d_data, size_t n, uint32_t ctx0, const uint64_t *d_start_bit,
+                           uint8_t *d_payload, size_t cap, uint64_t *d_nbits, uint64_t *d_index, uint32_t chunk_symbols, uint32_t *d_fine,
+                           void *d_ws, size_t ws_bytes, void *stream) {
+    if (m && ctx0 > (m->type == 2 ? 0xFFFFu : 0xFFu)) return MH_ERR_ARG;
+    return dev_encode_ctx(m, d_data, n, ctx0, d_start_bit, d_payload, cap, d_nbits, d_index, chunk_symbols, d_ws, ws_bytes, stream, d_fine);
+}
+
 int mh_dev_encode_at(const mh_model *m, const uint8_t *d_data, size_t n, uint8_t prev0, const uint64_t *d_start_bit,
                      uint8_t *d_payload, size_t cap, uint64_t *d_nbits, uint64_t *d_index, uint32_t chunk_symbols,
                      void *d_ws, size_t ws_bytes, void *stream) {
@@ -1161,13 +1168,18 @@ static int dev_decode(const mh_model *m, const uint8_t *d_payload, uint64_t nbit
     p.P = uint32_t(m->dec_bits); p.nsec = m->nsec; p.sec_lds = m->dec_lds ? 1u : 0u;
     p.direct = m->dec_direct ? 1u : 0u; p.H = uint32_t(m->dec_h);
     const int path = decode_path_choice();
-    const bool tile_ok = d_fine && m->tile_p && m->type != 2 && shift <= 12 && path != 2;
+    const bool tile_ok = d_fine && path != 2 && (m->type == 2 ? (m->o2_dec_ok && shift <= 10) : (m->tile_p && shift <= 12));
     if (tile_ok && (path == 1 || n_symbols >= (uint64_t(8) << 20))) {
         mhk::TileParams t{};
         t.payload = d_payload; t.payload_bytes = p.payload_bytes; t.nbits = nbits; t.d_nbits = p.d_nbits;
         t.out = d_out; t.n = n_symbols; t.index = p.index; t.nchunks = p.nchunks; t.chunk_shift = p.chunk_shift;
         t.fine = d_fine;
         t.prim = m->d_tprim; t.sec = m->d_tsec; t.P = uint32_t(m->tile_p); t.H = uint32_t(m->tile_h); t.nsec = m->tile_nsec;
+        if (m->type == 2) {                                      // the live contexts' tables (32-bit entries)
+            t.o2 = 1; t.nslots = m->o2_nslots; t.ctx2slot = m->d_ctx2slot;
+            t.prim = reinterpret_cast<const uint16_t *>(m->d_tprim2); t.sec = reinterpret_cast<const uint16_t *>(m->d_tsec2);
+            t.P = m->o2_p; t.H = m->o2_h; t.nsec = m->o2_nsec;
+        }
         HIP_TRY(mhk::launch_decode_tile(t, p, d_ws, static_cast<hipStream_t>(stream)));
         return MH_OK;
     }

@@ -95,6 +95,7 @@ struct DecParams {
     uint32_t H;
     int *status;
     uint32_t *redo;               // [0] = number of chunks handed to the redo pass, [1..] their numbers (nchunks capacity)
+    uint32_t redo_list;           // order 2: decode only the chunks listed in `redo`
 };
 
 // ---- tile decoder (mh_tile.hip) ----------------------------------------------------------------------------

@@ -2384,7 +2384,10 @@ __global__ __launch_bounds__(256) void decode2_kernel(DecParams p) {
     const BitSrc src{p.payload, p.payload_bytes >> 2, p.payload_bytes};
     const DecTables tabs{p.sec, p.tree, p.P, 0u, 0u};
     const uint32_t S = 1u << p.chunk_shift;
-    for (uint64_t c = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; c < p.nchunks; c += uint64_t(gridDim.x) * blockDim.x) {
+    // redo_list: only the chunks the tile decoder handed over (p.redo[0] of them, numbers behind it)
+    const uint64_t nwork = p.redo_list ? uint64_t(p.redo[0]) : p.nchunks;
+    for (uint64_t w = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; w < nwork; w += uint64_t(gridDim.x) * blockDim.x) {
+        const uint64_t c = p.redo_list ? uint64_t(p.redo[1u + w]) : w;
         const uint64_t entry = p.index[c];
         uint64_t pos = entry & IDX2_POS;
         uint32_t ctx = uint32_t(entry >> 48);
@@ -2741,6 +2744,13 @@ hipError_t launch_enc64_pack(const uint8_t *len8, const uint64_t *code64, uint64
 // The redo pass: one lane per chunk listed in p.redo (count in [0]), runtime table widths, with the tree walk for
 // codes longer than both table levels.  Normally the list is empty and the launch returns at once.
 hipError_t launch_decode_redo(DecParams p, hipStream_t st) {
+    if (p.order == 2) {                                      // order 2: the one-lane-per-chunk decoder over the list
+        p.redo_list = 1;
+        const uint64_t want2 = (p.nchunks + 255) / 256;
+        const uint64_t cap2 = uint64_t(cu_count()) * 8;
+        hipLaunchKernelGGL(decode2_kernel, dim3(unsigned(want2 > cap2 ? cap2 : (want2 < 1 ? 1 : want2))), dim3(256), 0, st, p);
+        return hipGetLastError();
+    }
     auto r_lds = decode_kernel<true, 2, false, 1, 8, 1, 0, 0, true>;
     auto r_l2 = decode_kernel<false, 2, false, 1, 8, 1, 0, 0, true>;
     auto r_l2d = decode_kernel<false, 2, true, 1, 8, 1, 0, 0, true>;

@@ -43,7 +43,15 @@ constexpr int T_LDS_BYTES = 163840;
 constexpr uint64_t T_POS_MASK = 0x00FFFFFFFFFFFFFFull;
 
 // bit offset of sub-chunk j's first symbol: the chunk index entry in front of it supplies the high bits
+// (order 2: the fine entry's low half is the distance from the chunk's index entry; 0xFFFF = does not fit: a position
+// past the end of the payload results, which fails the tile's sanity check and sends it to the redo pass)
+constexpr uint64_t T_POS_MASK2 = 0x0000FFFFFFFFFFFFull;
+template <int O2>
 __device__ __forceinline__ uint64_t sub_pos(const TileParams &p, uint64_t j, uint32_t f) {
+    if (O2) {
+        const uint64_t base = p.index[(j << T_SUB_SHIFT) >> p.chunk_shift] & T_POS_MASK2;
+        return (f & 0xFFFFu) == 0xFFFFu ? ~0ull >> 1 : base + (f & 0xFFFFu);
+    }
     const uint64_t base = p.index[(j << T_SUB_SHIFT) >> p.chunk_shift] & T_POS_MASK;
     return base + ((f - uint32_t(base)) & FINE_POS_MASK);
 }
@@ -52,15 +60,15 @@ __device__ __forceinline__ uint64_t sub_pos(const TileParams &p, uint64_t j, uin
 __device__ __forceinline__ uint64_t stage_first(uint64_t start) { return (start >> 3) & ~uint64_t(15); }
 
 // ---- geometry: the largest piece any wave stages ----------------------------------------------------------
-template <int K>
+template <int K, int O2>
 __global__ __launch_bounds__(256) void tile_geom_kernel(TileParams p, uint32_t cap_bytes) {
     if (p.d_nbits) p.nbits = *p.d_nbits;
     const uint64_t nsub = (p.n + T_SUB - 1) >> T_SUB_SHIFT;
     uint32_t mx = 0;
     for (uint64_t t = uint64_t(blockIdx.x) * 256 + threadIdx.x; t < p.ntiles; t += uint64_t(gridDim.x) * 256) {
         const uint64_t j0 = t * (64u * K), j1 = j0 + 64u * K;
-        const uint64_t start = sub_pos(p, j0, p.fine[j0]);
-        const uint64_t end = j1 < nsub ? sub_pos(p, j1, p.fine[j1]) : p.nbits;
+        const uint64_t start = sub_pos<O2>(p, j0, p.fine[j0]);
+        const uint64_t end = j1 < nsub ? sub_pos<O2>(p, j1, p.fine[j1]) : p.nbits;
         if (end < start || end > p.nbits) continue;               // the decoder reports it
         const uint64_t bytes = ((end + 7) >> 3) - stage_first(start);
         if (bytes <= cap_bytes && uint32_t(bytes) > mx) mx = uint32_t(bytes);
@@ -104,11 +112,12 @@ __device__ __forceinline__ uint32_t tile_put_byte(uint32_t d, uint32_t e, int j)
 // OUT: how a stream's 64 bytes leave (A/B, MH_TILE_OUT): 0 = a 16-byte store per 16 symbols (adjacent lanes 64 bytes apart),
 // 1 = four such stores back to back at the end of the tile, 2 = through the wave's LDS region, transposed, so that every
 // store instruction writes one contiguous KiB
-template <int K, int PC, int HC, int OUT, int WIN, int STAMP = 0>
+// O2: order-2 tables of the live contexts (TileParams): 32-bit entries whose high half is the next context's slot
+template <int K, int PC, int HC, int OUT, int WIN, int STAMP = 0, int O2 = 0>
 __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr uint32_t P = PC;
-    constexpr uint32_t PRIM_BYTES = (256u << P) * 2u;
+    const uint32_t PRIM_BYTES = O2 ? ((p.nslots << P) * 4u + 15u) & ~15u : (256u << P) * 2u;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (p.d_nbits) {
         p.nbits = *p.d_nbits;
@@ -143,7 +152,7 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
     }
     const uint32_t reg_bit0 = lds_addr_of(reg) * 8u;              // LDS bit address of the region's first bit
     const __amdgpu_buffer_rsrc_t sec_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.sec), 0, p.nsec ? int((p.nsec + 8u) * 2u) : 0, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.sec), 0, p.nsec ? int((p.nsec + 8u) * (O2 ? 4u : 2u)) : 0, 0x00020000);
     const uint32_t chunks_per_tile = T_TILE >> p.chunk_shift;     // >= 1: chunk_shift <= 12 (launch_decode_tile)
 
     unsigned long long seg[4] = {0, 0, 0, 0};
@@ -158,12 +167,12 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
         for (int k = 0; k < K; ++k) {
             const uint64_t j = j0 + uint64_t(k) * 64u + lane;
             const uint32_t f = p.fine[j];
-            pos[k] = sub_pos(p, j, f);
-            cf[k] = f >> 24;
+            pos[k] = sub_pos<O2>(p, j, f);
+            cf[k] = O2 ? uint32_t(p.ctx2slot[f >> 16]) << 16 : f >> 24;     // order 2: the context's slot (0xFFFF: none)
         }
         const uint64_t jn = j0 + 64u * K;
         uint64_t end = p.nbits;
-        if (jn < nsub) end = sub_pos(p, jn, p.fine[jn]);          // same address in every lane
+        if (jn < nsub) end = sub_pos<O2>(p, jn, p.fine[jn]);      // same address in every lane
         const uint64_t start = __shfl(pos[0], 0);
         const uint64_t b0 = stage_first(start);
         const uint64_t nbytes = ((end + 7) >> 3) - b0;
@@ -171,6 +180,17 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
         bool sane = end >= start && end <= p.nbits;
 #pragma unroll
         for (int k = 0; k < K; ++k) sane = sane && pos[k] >= start && pos[k] <= end;
+        if (O2) {
+            // a sub-chunk whose offset did not fit its fine entry, or whose context has no slot: the chunk decoder takes the piece
+            bool fits = true;
+#pragma unroll
+            for (int k = 0; k < K; ++k) fits = fits && (cf[k] >> 16) < p.nslots;
+            if (!__all(sane && fits)) {
+                const uint64_t c0 = (t * (uint32_t(K) * T_TILE)) >> p.chunk_shift;
+                for (uint32_t c = lane; c < (T_TILE >> p.chunk_shift) * K; c += 64) p.redo[1u + atomicAdd(p.redo, 1u)] = uint32_t(c0 + c);
+                continue;
+            }
+        }
         if (!__all(sane)) {
             if (lane == 0) atomicExch(p.status, MHK_STATUS_CORRUPT);
             continue;
@@ -265,15 +285,24 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
                 for (int k = 0; k < K; ++k) {
                     win[k] = WIN ? lo[k] : __builtin_amdgcn_alignbit(w1[k], w0[k], q[k]);   // 32 stream bits from bit q on, first in bit 0
                     // byte address of the entry (the table starts at LDS address 0, checked at entry): context << (P + 1) | bits << 1
-                    const uint32_t csh = P == 7 ? __builtin_amdgcn_perm(0u, cf[k], 0x0C0C000Cu)       // byte 0 -> byte 1
-                                                : (cf[k] & 255u) << (P + 1);
-                    e[k] = *lds_ptr<uint16_t>(((win[k] << 1) & ((2u << P) - 2u)) | csh);
+                    if (O2) {                                      // slot << (P + 2) | bits << 2: 32-bit entries
+                        e[k] = *lds_ptr<uint32_t>(((win[k] << 2) & ((4u << P) - 4u)) | ((cf[k] >> 16) << (P + 2)));
+                    } else {
+                        const uint32_t csh = P == 7 ? __builtin_amdgcn_perm(0u, cf[k], 0x0C0C000Cu)       // byte 0 -> byte 1
+                                                    : (cf[k] & 255u) << (P + 1);
+                        e[k] = *lds_ptr<uint16_t>(((win[k] << 1) & ((2u << P) - 2u)) | csh);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
-                    const uint32_t idx2 = (e[k] << (H + 1)) | ((win[k] >> (P - 1)) & ((2u << H) - 2u));   // byte offset of the entry
-                    e2[k] = uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(sec_rsrc, int(idx2), 0, 0)));
+                    if (O2) {      // (a leaf carries bit 15: shifted by H + 2 it lies past the (nslots << P) << H entries whatever its high half holds)
+                        const uint32_t idx2 = (e[k] << (H + 2)) | ((win[k] >> (P - 2)) & ((4u << H) - 4u));
+                        e2[k] = uint32_t(__builtin_amdgcn_raw_buffer_load_b32(sec_rsrc, int(idx2), 0, 0));
+                    } else {
+                        const uint32_t idx2 = (e[k] << (H + 1)) | ((win[k] >> (P - 1)) & ((2u << H) - 2u));   // byte offset of the entry
+                        e2[k] = uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(sec_rsrc, int(idx2), 0, 0)));
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -372,7 +401,7 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
 size_t decode_tile_workspace_extra() { return 64; }
 
 
-template <int K>
+template <int K, int O2 = 0>
 static hipError_t launch_tile_with(void (*kern)(TileParams), TileParams p, const DecParams &legacy, void *d_ws, hipStream_t st) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -391,9 +420,11 @@ static hipError_t launch_tile_with(void (*kern)(TileParams), TileParams p, const
     e = hipMemsetAsync(d_ws, 0, 64 + 16, st);
     if (e != hipSuccess) return e;
     if (p.ntiles) {
-        const uint32_t cap = uint32_t(T_LDS_BYTES) - ((256u << p.P) * 2u) - 32u;
+        const uint32_t prim_bytes = O2 ? (((p.nslots << p.P) * 4u + 15u) & ~15u) : (256u << p.P) * 2u;
+        if (prim_bytes + 4096u > uint32_t(T_LDS_BYTES)) return hipErrorInvalidValue;
+        const uint32_t cap = uint32_t(T_LDS_BYTES) - prim_bytes - 32u;
         const uint64_t gwant = (p.ntiles + 255) / 256;
-        hipLaunchKernelGGL((tile_geom_kernel<K>), dim3(unsigned(gwant > 1024 ? 1024 : gwant)), dim3(256), 0, st, p, cap);
+        hipLaunchKernelGGL((tile_geom_kernel<K, O2>), dim3(unsigned(gwant > 1024 ? 1024 : gwant)), dim3(256), 0, st, p, cap);
     }
     // one workgroup per CU (the first-level table takes most of the LDS); with few pieces, fewer workgroups
     const uint64_t want = (p.ntiles + T_WAVES - 1) / T_WAVES;
@@ -407,7 +438,7 @@ static hipError_t launch_tile_with(void (*kern)(TileParams), TileParams p, const
     return launch_decode_redo(r, st);
 }
 
-template <int K, int OUT, int WIN = 1>
+template <int K, int OUT, int WIN = 0>
 static hipError_t launch_tile_k(TileParams p, const DecParams &legacy, void *d_ws, hipStream_t st) {
     void (*kern[9])(TileParams) = {nullptr, nullptr, nullptr, nullptr, nullptr, decode_tile_kernel<K, 5, 0, OUT, WIN>, decode_tile_kernel<K, 6, 0, OUT, WIN>,
                                    decode_tile_kernel<K, 7, 0, OUT, WIN>, decode_tile_kernel<K, 8, 0, OUT, WIN>};
@@ -417,16 +448,20 @@ static hipError_t launch_tile_k(TileParams p, const DecParams &legacy, void *d_w
 
 hipError_t launch_decode_tile(TileParams p, const DecParams &legacy, void *d_ws, hipStream_t st) {
     if (p.chunk_shift > 12 || p.chunk_shift < T_SUB_SHIFT) return hipErrorInvalidValue;
+    if (p.o2) {                                  // order 2: first level of 6 bits per live context, two tiles per wave
+        if (p.P != 6 || p.chunk_shift > 10 || !p.ctx2slot || !p.nslots) return hipErrorInvalidValue;
+        void (*k2)(TileParams) = decode_tile_kernel<2, 6, 0, 2, 0, 0, 1>;
+        return launch_tile_with<2, 1>(k2, p, legacy, d_ws, st);
+    }
     // timing probe (MH_TILE_PROBE=1): the second-level table has zero records, so every gather is answered by the
     // bounds check — the instruction stream and the waits stay, the trips to L2 go (results are wrong)
     if (const char *pr = getenv("MH_TILE_PROBE")) { p.probe = uint32_t(atoi(pr)); if (p.probe & 1) p.nsec = 0; }
-    // tiles per wave: 2 by default; MH_TILE_K (1..4) for A/B runs
+    // tiles per wave: 2 by default; MH_TILE_K (1, 2) for A/B runs
     const char *e = getenv("MH_TILE_K");
     const int k = e ? atoi(e) : 2;
     const char *eo = getenv("MH_TILE_OUT");
     const int o = eo ? atoi(eo) : 2;
-    if (o == 0) return k == 1 ? launch_tile_k<1, 0>(p, legacy, d_ws, st) : k == 4 ? launch_tile_k<4, 0>(p, legacy, d_ws, st) : launch_tile_k<2, 0>(p, legacy, d_ws, st);
-    if (o == 1) return k == 1 ? launch_tile_k<1, 1>(p, legacy, d_ws, st) : k == 3 ? launch_tile_k<3, 1>(p, legacy, d_ws, st) : launch_tile_k<2, 1>(p, legacy, d_ws, st);
+    if (o == 1) return k == 1 ? launch_tile_k<1, 1>(p, legacy, d_ws, st) : launch_tile_k<2, 1>(p, legacy, d_ws, st);
     if (const char *es = getenv("MH_TILE_STAMP")) {
         if (atoi(es)) {
             void (*ks)(TileParams) = decode_tile_kernel<2, 7, 0, 2, 0, 1>;
@@ -434,9 +469,9 @@ hipError_t launch_decode_tile(TileParams p, const DecParams &legacy, void *d_ws,
             return launch_tile_with<2>(ks, p, legacy, d_ws, st);
         }
     }
-    const char *ew = getenv("MH_TILE_WIN");
-    if (ew && atoi(ew) == 0) return k == 1 ? launch_tile_k<1, 2, 0>(p, legacy, d_ws, st) : launch_tile_k<2, 2, 0>(p, legacy, d_ws, st);
-    return k == 1 ? launch_tile_k<1, 2>(p, legacy, d_ws, st) : k == 3 ? launch_tile_k<3, 2>(p, legacy, d_ws, st) : launch_tile_k<2, 2>(p, legacy, d_ws, st);
+    const char *ew = getenv("MH_TILE_WIN");                       // 1: the register-window variant (measured level with the LDS window)
+    if (ew && atoi(ew) == 1) return launch_tile_k<2, 2, 1>(p, legacy, d_ws, st);
+    return k == 1 ? launch_tile_k<1, 2>(p, legacy, d_ws, st) : launch_tile_k<2, 2>(p, legacy, d_ws, st);
 }
 
 }  // namespace mhk

@@ -205,3 +205,61 @@ def test_tile_decode_reports_a_damaged_fine_index(mhc):
     mhc._check(s.lib.mh_dev_upload(s.d_fine.ptr, fine.ctypes.data, fine.nbytes), "upload")
     rc, out = s.decode()
     assert rc == 0 and np.array_equal(out, data)
+
+
+# ------------------------------------------------------------------ order 2 (extension: parity unpinned)
+
+def o2_round_trip(mhc, oracle, data, chunk=1024, expect_tiles=None):
+    """Device path of an order-2 model: histogram, device tree build (the live contexts get LDS tables), encode with
+    fine index, decode with it (tile decoder when every live context has a slot, the chunk decoder otherwise)."""
+    lib = mhc.lib()
+    n = data.size
+    d_data = mhc.DeviceBuffer(n + 32, init=np.concatenate([data, np.zeros(32, dtype=np.uint8)]))
+    d_counts = mhc.DeviceBuffer((1 << 24) * 8)
+    mhc._check(lib.mh_dev_histogram_o2(d_data.ptr, n, 0x2020, d_counts.ptr, None), "hist2")
+    m = mhc.Model.from_device_counts(d_counts.ptr, 2)
+    cap = lib.mh_encode_bound(m.handle, n) + 64
+    nidx, nfine = max((n + chunk - 1) // chunk, 1), max((n + 63) // 64, 1)
+    wsb = lib.mh_dev_encode_workspace(n)
+    d_payload = mhc.DeviceBuffer(cap, init=np.full(cap, 0xEE, dtype=np.uint8))
+    d_nbits, d_index, d_fine = mhc.DeviceBuffer(8), mhc.DeviceBuffer(nidx * 8), mhc.DeviceBuffer(nfine * 4)
+    d_ws = mhc.DeviceBuffer(wsb + 64)
+    mhc._check(lib.mh_dev_encode_ctx_fine(m.handle, d_data.ptr, n, 0x2020, None, d_payload.ptr, cap, d_nbits.ptr, d_index.ptr, chunk,
+                                          d_fine.ptr, d_ws.ptr, wsb, None), "encode")
+    mhc._check(lib.mh_dev_status(d_ws.ptr, None), "encode status")
+    nbits = int(d_nbits.download(np.uint64)[0])
+    ref, ref_bits = oracle.Model.from_data(data.tobytes(), 2).compress(data.tobytes())
+    assert nbits == ref_bits and d_payload.download()[:(nbits + 7) // 8].tobytes() == ref[1:]
+    d_out = mhc.DeviceBuffer(n + 64, init=np.full(n + 64, 0xAB, dtype=np.uint8))
+    dws = int(lib.mh_dev_decode_workspace(nbits, n, chunk))
+    d_dws = mhc.DeviceBuffer(dws)
+    mhc._check(lib.mh_dev_decode_fine(m.handle, d_payload.ptr, nbits, None, d_out.ptr, n, d_index.ptr, chunk, d_fine.ptr,
+                                      d_dws.ptr, dws, None), "decode")
+    assert lib.mh_dev_status(d_dws.ptr, None) == 0
+    out = d_out.download()
+    assert np.all(out[n:] == 0xAB) and np.array_equal(out[:n], data)
+    if expect_tiles is not None:                 # bytes 4..7 of the status block: the largest staged piece (tile decoder only)
+        staged = int(d_dws.download(np.uint32)[1])
+        assert (staged > 0) == expect_tiles, staged
+
+
+@pytest.mark.parametrize("chunk", [256, 1024])
+def test_order2_tile_decode_text_parity_unpinned(mhc, oracle, chunk):
+    data = text_like((3 << 20) + 1234, 11)
+    o2_round_trip(mhc, oracle, data, chunk=chunk, expect_tiles=True)
+
+
+def test_order2_many_contexts_takes_the_chunk_decoder_parity_unpinned(mhc, oracle):
+    data = zipf_bytes((1 << 20) + 99, 12)        # tens of thousands of live contexts: no slots for all of them
+    o2_round_trip(mhc, oracle, data, expect_tiles=False)
+
+
+def test_order2_tile_decode_long_codes_parity_unpinned(mhc, oracle):
+    """Rare successors get codes beyond the 6 + H bits the tile tables resolve: those pieces go to the chunk decoder."""
+    rng = np.random.default_rng(4)
+    base = text_like(4 << 20, 5).copy()
+    for k in range(26):                          # after "t " (sit, amet, elit), very rarely, one of 26 capital letters
+        pos = np.flatnonzero((base[:-3] == ord("t")) & (base[1:-2] == ord(" ")))
+        pick = pos[rng.integers(0, pos.size, 1 + k)]
+        base[pick + 2] = ord("A") + k
+    o2_round_trip(mhc, oracle, base)
