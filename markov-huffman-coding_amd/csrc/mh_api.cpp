@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
@@ -222,10 +224,36 @@ PinnedRing &ring_for_current_device() {
     return g_rings[ring_slot_for_device(dev)];
 }
 
+// MH_TIMING=1: the host-buffer calls account their time to three phases — upload (caller memory -> HBM, the page-cache
+// read of a mapped file included), device (kernels, waited for), download (HBM -> caller memory, the page faults of
+// a fresh file mapping included) — and print one stderr line per phase in the CLI's [mh-timing] format, so that
+// tools/cli_rate.py can tell the pipeline's rate from the file system's.  Each phase is waited for before the next
+// starts when timing is on (the calls overlap them otherwise).
+struct PhaseClock {
+    bool on = getenv("MH_TIMING") != nullptr;
+    double upload = 0, device = 0, download = 0;
+    size_t up_bytes = 0, down_bytes = 0;
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    void report(const char *call, size_t n) const {
+        if (!on) return;
+        fprintf(stderr, "[mh-timing] %s.upload %zu bytes %.4f s %.2f GB/s\n", call, up_bytes, upload, upload > 0 ? up_bytes / upload / 1e9 : 0.0);
+        fprintf(stderr, "[mh-timing] %s.device %zu bytes %.4f s %.2f GB/s\n", call, n, device, device > 0 ? n / device / 1e9 : 0.0);
+        fprintf(stderr, "[mh-timing] %s.download %zu bytes %.4f s %.2f GB/s\n", call, down_bytes, download, download > 0 ? down_bytes / download / 1e9 : 0.0);
+    }
+};
+thread_local PhaseClock *g_phase = nullptr;
+
 // small transfers keep the plain call (the ring pays from a few MiB on)
 hipError_t stage_h2d(void *d_dst, const void *h_src, size_t n, hipStream_t st) {
-    if (n < (size_t(4) << 20)) return hipMemcpyAsync(d_dst, h_src, n, hipMemcpyHostToDevice, st);   // pageable: returns after staging
-    return ring_for_current_device().upload(d_dst, h_src, n, st);
+    const double t0 = g_phase && g_phase->on ? PhaseClock::now() : 0;
+    hipError_t e = n < (size_t(4) << 20) ? hipMemcpyAsync(d_dst, h_src, n, hipMemcpyHostToDevice, st)   // pageable: returns after staging
+                                        : ring_for_current_device().upload(d_dst, h_src, n, st);
+    if (g_phase && g_phase->on && e == hipSuccess) {
+        e = hipStreamSynchronize(st);
+        g_phase->upload += PhaseClock::now() - t0;
+        g_phase->up_bytes += n;
+    }
+    return e;
 }
 // Device -> caller memory.  Measured on the GPU box (tools/cli_rate.py, 4 GiB): going through the ring costs
 // MORE than the runtime's own pageable path when the destination is a freshly grown file mapping — the
@@ -235,9 +263,22 @@ hipError_t stage_h2d(void *d_dst, const void *h_src, size_t n, hipStream_t st) {
 // the ring for destinations that are already resident.
 hipError_t stage_d2h(void *h_dst, const void *d_src, size_t n, hipStream_t st) {
     static const bool use_ring = getenv("MH_D2H_RING") && atoi(getenv("MH_D2H_RING")) != 0;
-    if (use_ring && n >= (size_t(4) << 20)) return ring_for_current_device().download(h_dst, d_src, n, st);
-    hipError_t e = hipMemcpyAsync(h_dst, d_src, n, hipMemcpyDeviceToHost, st);
-    return e != hipSuccess ? e : hipStreamSynchronize(st);
+    const bool timing = g_phase && g_phase->on;
+    double t0 = 0;
+    if (timing) {                                                // what is still running on the device belongs to the device phase
+        const double td = PhaseClock::now();
+        (void)hipStreamSynchronize(st);
+        t0 = PhaseClock::now();
+        g_phase->device += t0 - td;
+    }
+    hipError_t e;
+    if (use_ring && n >= (size_t(4) << 20)) e = ring_for_current_device().download(h_dst, d_src, n, st);
+    else {
+        e = hipMemcpyAsync(h_dst, d_src, n, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    if (timing) { g_phase->download += PhaseClock::now() - t0; g_phase->down_bytes += n; }
+    return e;
 }
 
 // Host tables are always built; the device images are uploaded when a device exists.  Without one the
@@ -1255,8 +1296,10 @@ int mh_dev_index_path(const void *d_ws, void *stream) {
 int mh_dev_status(const void *d_ws, void *stream) {
     if (!d_ws) return MH_ERR_ARG;
     int s = 0;
+    const double t0 = g_phase && g_phase->on ? PhaseClock::now() : 0;
     HIP_TRY(hipMemcpyAsync(&s, d_ws, sizeof s, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
     HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    if (g_phase && g_phase->on) g_phase->device += PhaseClock::now() - t0;
     return status_from_device(s);
 }
 
@@ -1316,6 +1359,8 @@ static int histogram_host(const uint8_t *data, size_t n, uint8_t prev0, uint64_t
     if (!have_device()) return MH_ERR_NO_DEVICE;
     const size_t nc = order == 2 ? (size_t(1) << 24) : order ? 65536 : 256;
     const size_t seg = segment_bytes();
+    PhaseClock clock;
+    struct Scope { PhaseClock *c; size_t n; Scope(PhaseClock *cc, size_t nn) : c(cc), n(nn) { g_phase = c; } ~Scope() { c->report("histogram", n); g_phase = nullptr; } } scope(&clock, n);
     DevBuf d_data, d_counts, d_hws;
     // with residency on, the whole input stays on the card (when it leaves half of the free memory alone)
     uint8_t *d_all = nullptr;
@@ -1398,6 +1443,8 @@ int mh_encode(const mh_model *m, const uint8_t *data, size_t n, uint8_t prev0, u
     if (!have_device()) return MH_ERR_NO_DEVICE;
     if (m->max_len > mh::MAX_CODE_BITS) return MH_ERR_CODE_TOO_LONG;
     hipStream_t st = nullptr;
+    PhaseClock clock;
+    struct Scope { PhaseClock *c; size_t n; Scope(PhaseClock *cc, size_t nn) : c(cc), n(nn) { g_phase = c; } ~Scope() { c->report("encode", n); g_phase = nullptr; } } scope(&clock, n);
     // Segment by segment: each one is encoded pre-shifted to the bit where the previous one ended
     // (mh_dev_encode_at), so its bytes drop into the output with one OR-merged seam byte.
     const size_t seg = segment_bytes();
@@ -1476,6 +1523,8 @@ int mh_decode_to(const mh_model *m, const uint8_t *payload, uint64_t nbits, uint
     if (!index) chunk_symbols = MH_CHUNK_DEFAULT;
     if (chunk_shift_of(chunk_symbols) < 0) return MH_ERR_ARG;
     hipStream_t st = nullptr;
+    PhaseClock clock;
+    struct Scope { PhaseClock *c; size_t *n; Scope(PhaseClock *cc, size_t *nn) : c(cc), n(nn) { g_phase = c; } ~Scope() { c->report("decode", *n); g_phase = nullptr; } } scope(&clock, nbytes);
     size_t pbytes = size_t((nbits + 7) / 8);
     if (index) {
         // With an index the stream is decoded segment by segment: a run of whole chunks needs only the

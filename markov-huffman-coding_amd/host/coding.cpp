@@ -161,7 +161,14 @@ struct OutputView {
         fflush(f);
         if (n && fstat(fileno(f), &st) == 0 && S_ISREG(st.st_mode) && ftell(f) == 0 && ftruncate(fileno(f), (off_t)n) == 0) {
             void* m = mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_SHARED, fileno(f), 0);
-            if (m != MAP_FAILED) { map = m; data = (unsigned char*)m; start_populate(); return; }
+            if (m != MAP_FAILED) {
+                map = m; data = (unsigned char*)m;
+                start_populate();
+                // MH_PREFAULT_WAIT=1 (tools/cli_rate.py): wait for the pages here, under a stage line of its own, so that the
+                // library call that follows shows the pipeline's rate and this line the file system's
+                if (getenv("MH_PREFAULT_WAIT")) { StageTimer t("prefault", n); join_populate(); }
+                return;
+            }
         }
         own.assign(n ? n : 1, 0);
         data = own.data();

@@ -29,13 +29,16 @@ BIN = os.path.join(ROOT, "bin", "markovhuffman")
 
 
 stages = []
+# MH_RATE_PREFAULT=1: the output mapping's pages are allocated before the library call and timed on their own
+# ("prefault"), so encode.* / decode.* show upload + kernels + download and nothing of the file system's page allocation
+EXTRA_ENV = {"MH_PREFAULT_WAIT": "1"} if os.environ.get("MH_RATE_PREFAULT") else {}
 
 
 def timed(args):
     """Wall time of the whole process (start-up and HIP initialisation included); the time spent inside
     the library calls comes back on stderr (MH_TIMING=1) and is collected in `stages`."""
     t = time.perf_counter()
-    r = subprocess.run([BIN] + args, stderr=subprocess.PIPE, env=dict(os.environ, MH_TIMING="1"))
+    r = subprocess.run([BIN] + args, stderr=subprocess.PIPE, env=dict(os.environ, MH_TIMING="1", **EXTRA_ENV))
     assert r.returncode == 0, (args, r.stderr[-500:])
     wall = time.perf_counter() - t
     inside = [l.split() for l in r.stderr.decode().splitlines() if l.startswith("[mh-timing]")]
@@ -48,7 +51,16 @@ tc = timed([d + "/in", "-o", d + "/c", "-d", d + "/t", "--index", d + "/c.idx"])
 tx = timed([d + "/c", "-o", d + "/d", "-x", "-e", d + "/t"])
 txi = timed([d + "/c", "-o", d + "/di", "-x", "-e", d + "/t", "--index", d + "/c.idx"])
 same = subprocess.run(["cmp", d + "/in", d + "/d"]).returncode == 0 and subprocess.run(["cmp", d + "/in", d + "/di"]).returncode == 0
-print({"GiB": gib, "dir": d, "compress_s": round(tc, 2), "compress_GBps": round(n / tc / 1e9, 2),
+def pipeline(stage, call):
+    """bytes / (upload + device + download) of one library call: the pipeline without the file system's share"""
+    ins = stage["inside"]
+    t = sum(ins.get("%s.%s" % (call, k), 0.0) for k in ("upload", "device", "download"))
+    return round(n / t / 1e9, 2) if t > 0 else None
+
+
+print({"GiB": gib, "dir": d, "prefault": bool(EXTRA_ENV),
+       "pipeline_GBps": {"compress(encode call)": pipeline(stages[0], "encode"), "histogram call": pipeline(stages[0], "histogram"),
+                         "decompress": pipeline(stages[1], "decode"), "decompress_indexed": pipeline(stages[2], "decode")}, "compress_s": round(tc, 2), "compress_GBps": round(n / tc / 1e9, 2),
        "decompress_s": round(tx, 2), "decompress_GBps": round(n / tx / 1e9, 2),
        "decompress_indexed_s": round(txi, 2), "decompress_indexed_GBps": round(n / txi / 1e9, 2), "round_trip_ok": same,
        "stages": stages})
