@@ -1210,7 +1210,12 @@ static int dev_decode(const mh_model *m, const uint8_t *d_payload, uint64_t nbit
     p.direct = m->dec_direct ? 1u : 0u; p.H = uint32_t(m->dec_h);
     const int path = decode_path_choice();
     const bool tile_ok = d_fine && path != 2 && (m->type == 2 ? (m->o2_dec_ok && shift <= 10) : (m->tile_p && shift <= 12));
-    if (tile_ok && (path == 1 || n_symbols >= (uint64_t(8) << 20))) {
+    // The tile decoder's first level is tile_p (7) bits wide: when the average code is about that long (near-uniform
+    // bytes: 8-bit codes everywhere), nearly every symbol takes the second-level gather and every tile stages a full
+    // 4 KiB — the chunk decoder with its 8-bit first level in LDS is 4x faster there (measured: 4 GiB uniform 3.0 vs 13.4
+    // ms; Zipf 6.3 vs 4.5 ms; text 4.4 vs 4.0 ms).  nbits == 0 (unknown): the tile decoder.
+    const bool long_codes = m->type != 2 && nbits && n_symbols && double(nbits) > (double(m->tile_p) - 0.5) * double(n_symbols);
+    if (tile_ok && (path == 1 || (n_symbols >= (uint64_t(8) << 20) && !long_codes))) {
         mhk::TileParams t{};
         t.payload = d_payload; t.payload_bytes = p.payload_bytes; t.nbits = nbits; t.d_nbits = p.d_nbits;
         t.out = d_out; t.n = n_symbols; t.index = p.index; t.nchunks = p.nchunks; t.chunk_shift = p.chunk_shift;

@@ -152,13 +152,16 @@ struct RegHeap {
     }
     // src/min_pq.tpp:38-52: the hole at the root takes the smaller child — the right one only when STRICTLY
     // smaller than the left — while that child is STRICTLY smaller than the sinking key.
+    // LMAX = deepest level that still holds entries: the path is followed, and written back, no further (the heap
+    // shrinks from 256 entries to one during the merge: on average two levels less than the full eight)
+    template <int LMAX>
     __device__ __forceinline__ void sink_flat(uint32_t lo, uint32_t hi, uint32_t it) {
-        uint32_t pos[9], clo[9], chi[9], cit[9];                 // the min-child path: entry (clo, chi, cit)[l] at (l, pos[l])
+        uint32_t pos[LMAX + 1], clo[LMAX + 1], chi[LMAX + 1], cit[LMAX + 1];   // the min-child path: entry (clo, chi, cit)[l] at (l, pos[l])
         pos[0] = 0; clo[0] = lo; chi[0] = hi; cit[0] = it;       // level 0 is the hole itself
         uint32_t moves = 0;                                      // children that move up
         bool going = true;
 #pragma unroll
-        for (int l = 0; l < 8; ++l) {
+        for (int l = 0; l < LMAX; ++l) {
             const uint32_t li = ((2u << l) - 1u) + 2u * pos[l];  // heap index of the left child
             uint32_t llo, lhi, lit, rlo, rhi, rit;
             get_dyn(l + 1, 2u * pos[l], llo, lhi, lit);
@@ -170,11 +173,11 @@ struct RegHeap {
             moves += going ? 1u : 0u;
         }
 #pragma unroll
-        for (int l = 0; l <= 8; ++l) {
+        for (int l = 0; l <= LMAX; ++l) {
             // level l gets: its child's entry if that child moved up, the sinking entry at level `moves`, else itself
             const bool from_child = uint32_t(l) < moves;
             const bool self = uint32_t(l) > moves;
-            const int c = l < 8 ? l + 1 : 8;
+            const int c = l < LMAX ? l + 1 : LMAX;
             const uint32_t wlo = from_child ? clo[c] : self ? clo[l] : lo;
             const uint32_t whi = from_child ? chi[c] : self ? chi[l] : hi;
             const uint32_t wit = from_child ? cit[c] : self ? cit[l] : it;
@@ -189,18 +192,17 @@ struct RegHeap {
         const uint32_t level = 31u - uint32_t(__builtin_clz(hn + 1u));
         const uint32_t pos = hn + 1u - (1u << level);
         uint32_t lo, hi, it;
-        switch (level) {
-            case 0: get<0>(pos, lo, hi, it); break;
-            case 1: get<1>(pos, lo, hi, it); break;
-            case 2: get<2>(pos, lo, hi, it); break;
-            case 3: get<3>(pos, lo, hi, it); break;
-            case 4: get<4>(pos, lo, hi, it); break;
-            case 5: get<5>(pos, lo, hi, it); break;
-            case 6: get<6>(pos, lo, hi, it); break;
-            case 7: get<7>(pos, lo, hi, it); break;
-            default: get<8>(pos, lo, hi, it); break;
+        switch (level) {                                          // the last entry leaves (level, pos) and sinks from the root
+            case 0: get<0>(pos, lo, hi, it); sink_flat<0>(lo, hi, it); break;
+            case 1: get<1>(pos, lo, hi, it); sink_flat<1>(lo, hi, it); break;
+            case 2: get<2>(pos, lo, hi, it); sink_flat<2>(lo, hi, it); break;
+            case 3: get<3>(pos, lo, hi, it); sink_flat<3>(lo, hi, it); break;
+            case 4: get<4>(pos, lo, hi, it); sink_flat<4>(lo, hi, it); break;
+            case 5: get<5>(pos, lo, hi, it); sink_flat<5>(lo, hi, it); break;
+            case 6: get<6>(pos, lo, hi, it); sink_flat<6>(lo, hi, it); break;
+            case 7: get<7>(pos, lo, hi, it); sink_flat<7>(lo, hi, it); break;
+            default: get<8>(pos, lo, hi, it); sink_flat<8>(lo, hi, it); break;
         }
-        sink_flat(lo, hi, it);
         return top;
     }
 };
