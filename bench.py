@@ -149,7 +149,8 @@ class Codec:
         # device-only fine index (one uint32 per 64 symbols): what lets a wave decode 64 adjacent pieces from one
         # contiguous piece of the payload (mh_dev_encode_fine / mh_dev_decode_fine); MH_BENCH_NO_FINE=1: without it
         self.use_fine = not os.environ.get("MH_BENCH_NO_FINE") and not (order == 1 and os.environ.get("MH_BENCH_TWO_PASS_ENCODE"))
-        self.fine = torch.empty(max((n + 63) // 64, 1), dtype=torch.int32, device=device) if self.use_fine else None
+        self.fine_symbols = int(os.environ.get("MH_FINE_SYMBOLS", "64"))     # (an experimental library build may use 32)
+        self.fine = torch.empty(max((n + self.fine_symbols - 1) // self.fine_symbols, 1), dtype=torch.int32, device=device) if self.use_fine else None
         self.hist_ws_bytes = int(self.lib.mh_dev_histogram_workspace(n))
         self.hist_ws = torch.empty(self.hist_ws_bytes, dtype=torch.uint8, device=device)
         self.enc_ws_bytes = self.lib.mh_dev_encode_workspace(n)
@@ -476,7 +477,7 @@ def main():
             "compressed_ratio": round(r, 5), "total_payload_bits": int(tot_bits.item()), "round_trip_bit_exact": round_trip_all,
             # out-of-band bytes the decoder is handed beside the payload: the sidecar chunk index (8 B per chunk) and the
             # device-only fine index (4 B per 64 symbols); traffic of both kernels, never credit
-            "index_bytes": {"chunk_index": int(codec.nidx * 8), "fine_index": int(((n + 63) // 64) * 4) if codec.use_fine else 0},
+            "index_bytes": {"chunk_index": int(codec.nidx * 8), "fine_index": int(((n + codec.fine_symbols - 1) // codec.fine_symbols) * 4) if codec.use_fine else 0},
             "max_code_len": model.max_code_len,
             "decode_tables": dict(zip(("primary_bits", "secondary_entries", "in_lds"), model.decode_layout())),
         }

@@ -330,7 +330,10 @@ int mh_dev_decode_dn(const mh_model *m, const uint8_t *d_payload, const uint64_t
  * to the piece (0xFFFF: does not fit), chunk_symbols <= 1024, and only models whose live contexts all have a slot in
  * the decoder's LDS tables (text-like sources: a few hundred contexts) use it; mh_dev_build_index_fine writes none.
  */
-#define MH_FINE_SYMBOLS 64u
+#ifndef MH_T_SUB_SHIFT            /* (an experimental build may halve the piece: csrc/Makefile, MH_T_SUB_SHIFT=5) */
+#define MH_T_SUB_SHIFT 6
+#endif
+#define MH_FINE_SYMBOLS (1u << MH_T_SUB_SHIFT)
 static inline uint64_t mh_fine_entries(uint64_t n_symbols) { return (n_symbols + MH_FINE_SYMBOLS - 1) / MH_FINE_SYMBOLS; }
 /* mh_dev_encode_hist (d_hist_ws may be NULL: then mh_dev_encode_at) that also fills d_fine[mh_fine_entries(n)]
  * (d_fine may be NULL).  Payload, index and *d_nbits do not depend on d_fine. */

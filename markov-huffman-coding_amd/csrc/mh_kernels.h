@@ -104,7 +104,10 @@ struct DecParams {
 // symbol & 0xFFFFFF).  The full offset is recovered from the chunk index entry in front of it (a chunk holds
 // far fewer than 2^24 bits).  With it a WAVE decodes 64 adjacent sub-chunks: its compressed bytes are one
 // contiguous piece of the payload (staged through LDS with coalesced loads) and so is its output.
-constexpr int T_SUB_SHIFT = 6;
+#ifndef MH_T_SUB_SHIFT
+#define MH_T_SUB_SHIFT 6
+#endif
+constexpr int T_SUB_SHIFT = MH_T_SUB_SHIFT;
 constexpr uint32_t FINE_POS_MASK = 0x00FFFFFFu;
 struct TileParams {
     const uint8_t *payload;

@@ -575,7 +575,7 @@ __device__ __forceinline__ void fine2_entry(const EmitParams &p, uint32_t S, uin
     if (!p.fine || S > uint32_t(E_SUB)) return;                  // (wave-uniform)
     const uint32_t first = lane & ~((S >> 4) - 1u);              // the lane that starts this lane's chunk
     const uint32_t d = exc - uint32_t(__shfl(int(exc), int(first)));
-    if (nvalid && (lane & 3u) == 0u) p.fine[off >> T_SUB_SHIFT] = (ctx << 16) | (d > 0xFFFFu ? 0xFFFFu : d);
+    if (nvalid && (lane & (uint32_t(1u << T_SUB_SHIFT) / 16u - 1u)) == 0u) p.fine[off >> T_SUB_SHIFT] = (ctx << 16) | (d > 0xFFFFu ? 0xFFFFu : d);
 }
 
 // Escape path of one sub-step (some code in the wave is longer than 12 bits): everything is recomputed
@@ -640,7 +640,7 @@ __device__ __forceinline__ void emit_substep_slow(const EmitParams &p, const uin
     const uint32_t S = 1u << p.chunk_shift;
     if (p.index && nvalid && ((uint32_t(off) & (S - 1u)) == 0u))
         p.index[off >> p.chunk_shift] = (uint64_t(pb) << (ORDER == 2 ? 48 : 56)) | (abs_bits + exc);
-    if (ORDER != 2 && p.fine && nvalid && (lane & 3u) == 0u)         // every fourth lane starts a 64-symbol sub-chunk
+    if (ORDER != 2 && p.fine && nvalid && (lane & (uint32_t(1u << T_SUB_SHIFT) / 16u - 1u)) == 0u)         // every fourth lane starts a 64-symbol sub-chunk
         p.fine[off >> T_SUB_SHIFT] = (pb << 24) | (uint32_t(abs_bits + exc) & FINE_POS_MASK);
     if (ORDER == 2) fine2_entry(p, S, lane, off, nvalid, pb, exc);
 
@@ -771,7 +771,7 @@ __global__ __launch_bounds__(E_THREADS) void enc_emit_kernel(EmitParams p) {
             if (p.index && nvalid && ((uint32_t(off) & (S - 1u)) == 0u))
                 p.index[off >> p.chunk_shift] = (uint64_t(pb) << (ORDER == 2 ? 48 : 56)) | (abs_bits + exc);
             if (ORDER == 1) {
-                if (p.fine && nvalid && (lane & 3u) == 0u)         // fine index (mh_kernels.h, TileParams): every fourth lane
+                if (p.fine && nvalid && (lane & (uint32_t(1u << T_SUB_SHIFT) / 16u - 1u)) == 0u)         // fine index (mh_kernels.h, TileParams): every fourth lane
                     p.fine[off >> T_SUB_SHIFT] = (pb << 24) | (uint32_t(abs_bits + exc) & FINE_POS_MASK);
             } else {
                 fine2_entry(p, S, lane, off, nvalid, pb, exc);
@@ -1123,7 +1123,7 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
         const uint32_t nvalid = FULL ? uint32_t(E_VEC) : nvalid0;
         if (p.index && nvalid && ((uint32_t(off) & (S - 1u)) == 0u))
             p.index[off >> p.chunk_shift] = (uint64_t(pb0) << 56) | (abs_round + exc);
-        if (p.fine && nvalid && (lane & 3u) == 0u)               // fine index (mh_kernels.h, TileParams): every fourth lane
+        if (p.fine && nvalid && (lane & (uint32_t(1u << T_SUB_SHIFT) / 16u - 1u)) == 0u)               // fine index (mh_kernels.h, TileParams): every fourth lane
             p.fine[off >> T_SUB_SHIFT] = (pb0 << 24) | (uint32_t(abs_round + exc) & FINE_POS_MASK);
         const bool fits = !ESC || cur + tot <= R_IMG_CAP_BITS;   // workgroup-uniform: the round fits the image (always, without escapes)
         if (fits) {

@@ -37,6 +37,10 @@ using mh::DEC16_LEAF;
 
 constexpr int T_SUB = 1 << T_SUB_SHIFT;          // symbols per sub-chunk = per fine-index entry
 constexpr int T_TILE = 64 * T_SUB;               // symbols per tile: one sub-chunk per lane
+constexpr int T_NU = T_SUB / 16;                 // 16-byte pieces of a stream's output
+constexpr int T_LPK = 1024 / T_SUB;              // lanes whose pieces make one KiB of output
+constexpr int T_NG = 64 / T_LPK;
+static_assert(T_SUB == 32 || T_SUB == 64, "the output transposition below is written for 32- or 64-symbol sub-chunks");
 constexpr int T_THREADS = 1024;
 constexpr int T_WAVES = T_THREADS / 64;
 constexpr int T_LDS_BYTES = 163840;
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
         uint4 *o16[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) o16[k] = reinterpret_cast<uint4 *>(p.out + ((j0 + uint64_t(k) * 64u + lane) << T_SUB_SHIFT));
-        uint4 Q[OUT ? K : 1][4];                                  // OUT 1, 2: the stream's 64 bytes; the pieces rotate through
+        uint4 Q[OUT ? K : 1][T_NU];                               // OUT 1, 2: the stream's output bytes; the pieces rotate through
         // WIN 1: the bit window lives in registers — lo/hi hold the next cnt stream bits (first in bit 0 of lo), `ahead`
         // the LDS dword behind them, loaded one refill early; every second symbol a lane with fewer than 32 bits
         // left takes `ahead` in (two table-resolved codes are at most 2 (P + H) <= 32 bits).  One masked ds_read_b32
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
         //   C  second-level gathers on their way (every lane; a leaf indexes past the end: 0, no cache access)
         //   D  the resolving entry, position, context, output byte
 #pragma unroll 1
-        for (int u = 0; u < 4; ++u) {                             // 16 symbols -> one 16-byte store per stream
+        for (int u = 0; u < T_NU; ++u) {                          // 16 symbols -> one 16-byte piece per stream
             uint32_t w4[K][4];
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
@@ -326,7 +330,11 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
             for (int k = 0; k < K; ++k) {
                 const uint4 v = make_uint4(w4[k][0], w4[k][1], w4[k][2], w4[k][3]);
                 if (OUT == 0) o16[k][u] = v;
-                else { Q[k][0] = Q[k][1]; Q[k][1] = Q[k][2]; Q[k][2] = Q[k][3]; Q[k][3] = v; }
+                else {
+#pragma unroll
+                    for (int i = 0; i + 1 < T_NU; ++i) Q[k][i] = Q[k][i + 1];
+                    Q[k][T_NU - 1] = v;
+                }
             }
         }
         if (STAMP) t3 = tile_stamp();
@@ -334,29 +342,29 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
 #pragma unroll
             for (int k = 0; k < K; ++k)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) o16[k][u] = Q[k][u];
+                for (int u = 0; u < T_NU; ++u) o16[k][u] = Q[k][u];
         }
         if (OUT == 2) {
-            // The input piece is used up: its LDS region now turns the tile's 64 x 64 bytes around, one KiB (16 lanes'
-            // pieces) at a time, so that every store instruction writes 64 x 16 contiguous bytes.  A lane's piece u goes
-            // to slot u ^ (lane >> 1 & 3) of its 64 bytes: the eight lanes one ds_write_b128 group serves then hit eight
-            // different bank quads.
+            // The input piece is used up: its LDS region now turns the tile's output around, one KiB (T_LPK lanes' pieces) at a
+            // time, so that every store instruction writes 64 x 16 contiguous bytes.  A lane's piece u goes to slot
+            // u ^ swz(lane) of its T_SUB bytes: the eight lanes one ds_write_b128 group serves then hit different bank quads.
             const uint32_t rb = reg_bit0 >> 3;
+            auto swz = [](uint32_t l) -> uint32_t { return T_SUB == 64 ? (l >> 1) & 3u : (l >> 2) & 1u; };
 #pragma unroll
             for (int k = 0; k < K; ++k) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    if ((lane >> 4) == uint32_t(g)) {
+                for (int g = 0; g < T_NG; ++g) {
+                    if (lane / uint32_t(T_LPK) == uint32_t(g)) {
 #pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                            *lds_wptr<u32x4>(rb + (lane & 15u) * 64u + ((uint32_t(u) ^ ((lane >> 1) & 3u)) << 4)) =
+                        for (int u = 0; u < T_NU; ++u)
+                            *lds_wptr<u32x4>(rb + (lane % uint32_t(T_LPK)) * uint32_t(T_SUB) + ((uint32_t(u) ^ swz(lane)) << 4)) =
                                 u32x4{Q[k][u].x, Q[k][u].y, Q[k][u].z, Q[k][u].w};
                     }
                     __builtin_amdgcn_wave_barrier();                    // (compiler fence: other lanes' writes, same wave, in order)
                     asm volatile("" ::: "memory");
-                    const uint32_t l = lane >> 2, u = lane & 3u;       // reader: piece u of lane l (within the group)
-                    const u32x4 v = *lds_ptr<u32x4>(rb + l * 64u + ((u ^ ((l >> 1) & 3u)) << 4));
-                    reinterpret_cast<uint4 *>(p.out + ((j0 + uint64_t(k) * 64u + uint32_t(g) * 16u) << T_SUB_SHIFT))[lane] = make_uint4(v.x, v.y, v.z, v.w);
+                    const uint32_t l = lane / uint32_t(T_NU), u = lane % uint32_t(T_NU);       // reader: piece u of lane l (within the group)
+                    const u32x4 v = *lds_ptr<u32x4>(rb + l * uint32_t(T_SUB) + ((u ^ swz(l)) << 4));
+                    reinterpret_cast<uint4 *>(p.out + ((j0 + uint64_t(k) * 64u + uint32_t(g) * uint32_t(T_LPK)) << T_SUB_SHIFT))[lane] = make_uint4(v.x, v.y, v.z, v.w);
                     __builtin_amdgcn_wave_barrier();
                     asm volatile("" ::: "memory");
                 }
@@ -471,7 +479,7 @@ hipError_t launch_decode_tile(TileParams p, const DecParams &legacy, void *d_ws,
     }
     const char *ew = getenv("MH_TILE_WIN");                       // 1: the register-window variant (measured level with the LDS window)
     if (ew && atoi(ew) == 1) return launch_tile_k<2, 2, 1>(p, legacy, d_ws, st);
-    return k == 1 ? launch_tile_k<1, 2>(p, legacy, d_ws, st) : launch_tile_k<2, 2>(p, legacy, d_ws, st);
+    return k == 1 ? launch_tile_k<1, 2>(p, legacy, d_ws, st) : k == 4 ? launch_tile_k<4, 2>(p, legacy, d_ws, st) : k == 3 ? launch_tile_k<3, 2>(p, legacy, d_ws, st) : launch_tile_k<2, 2>(p, legacy, d_ws, st);
 }
 
 }  // namespace mhk
