@@ -1103,7 +1103,9 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
     uint4 x0 = D0.x;                             // round r's input (the escape path re-reads it) and valid bytes
     uint32_t nvalid0 = D0.nvalid;
     static_assert(E_WAVES == 16, "the scan below is one DPP row");
-    auto round = [&](uint64_t r, auto full_c) __attribute__((always_inline)) {
+    // Ea holds the entries of round r + 1 (packed here), Eb receives those of round r + 2: the steady-state loop runs two
+    // rounds per trip with the two arrays swapping roles, so the sixteen entries are never copied
+    auto round = [&](uint64_t r, auto full_c, uint32_t (&Ea)[16], uint32_t (&Eb)[16]) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_c)::value, ESC = ESCK;
         uint32_t *sbr = sb + (r & 1u) * 16u, *sbn = sb + ((r + 1u) & 1u) * 16u;
         ENC_STAMP(0);                            // flush of the previous round (+ loop overhead)
@@ -1158,9 +1160,8 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
         // ---- while the LDS works the deposits off: the next rounds
         const LaneIn D4 = FULL ? fetch_full(r + 4) : fetch(r + 4);
         const uint32_t pb2 = head_byte(D2);
-        uint32_t E2[16];
-        lookup16(D2, pb2, E2);
-        const Packed Pn = pack(E1, D1, pb1, full_c, ESC_T{});
+        lookup16(D2, pb2, Eb);
+        const Packed Pn = pack(Ea, D1, pb1, full_c, ESC_T{});
         if (lane == 63) sbn[wave] = Pn.inc;      // round r + 1's piece count (the other half of sb: round r's is still being read)
         ENC_STAMP(3);                            // lookups issued + pack + scan of the next round
         if (fits) {
@@ -1180,18 +1181,24 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
         D1 = D2; pb1 = pb2;
         D2 = D3;
         D3 = D4;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) E1[j] = E2[j];
     };
     // leading rounds whose 16 KiB, and those of the four rounds behind them, are whole: the steady state
     const uint64_t whole = (p.n >> 4) < v1 ? (p.n >> 4) : v1;       // vectors with all 16 bytes inside the stream
     const uint64_t rounds_full = whole > v0 ? (whole - v0) / E_THREADS : 0;
     const uint64_t r_fast = rounds_full > 4 ? rounds_full - 4 : 0;
     uint64_t r = 0;
+    uint32_t E2[16];
 #pragma unroll 1
-    for (; r < r_fast; ++r) round(r, std::true_type{});
+    for (; r + 1 < r_fast; r += 2) {
+        round(r, std::true_type{}, E1, E2);
+        round(r + 1, std::true_type{}, E2, E1);
+    }
 #pragma unroll 1
-    for (; r < rounds; ++r) round(r, std::false_type{});
+    for (; r < rounds; ++r) {
+        round(r, std::false_type{}, E1, E2);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) E1[j] = E2[j];
+    }
     // the region's last partial dword: shared with the next region (or the stream's end), zeroed by the scan
     if (cur != 0 && gbase < rp.cap_words) {
         if (carry) atomicOr(&out32[gbase], __builtin_bswap32(carry));
