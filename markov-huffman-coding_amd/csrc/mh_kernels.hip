@@ -172,15 +172,16 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_o1_kernel(const uint8_t *__
         for (int k = 0; k < 4; ++k) {
             // prev ^ sym ^ (sym << 3) for the four symbols of the dword (hist_mix, bytewise)
             const uint32_t y = x[k] ^ ((x[k] << 3) & 0xF8F8F8F8u) ^ ((x[k] << 8) | pb);
+            const uint32_t xm = x[k] & 0x7F7F7F7Fu;              // the symbols without their top bits: the shuffle below then yields the WORD index
             pb = x[k] >> 24;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int i = 4 * k + j;
-                slot[i] = __builtin_amdgcn_perm(x[k], y, 0x0C0C0400u + uint32_t(j) * 0x0101u);   // x.byte j << 8 | y.byte j
+                slot[i] = __builtin_amdgcn_perm(xm, y, 0x0C0C0400u + uint32_t(j) * 0x0101u);   // (x.byte j & 0x7F) << 8 | y.byte j: slot & 0x7FFF
                 // 1, or 0x10000 for the upper half: top bit of the symbol * 0xFFFF + 1 (the compiler would turn
                 // the multiply into compare + select, one instruction more)
                 asm("v_mad_u32_u24 %0, %1, %2, 1" : "=v"(inc[i]) : "v"(__builtin_amdgcn_ubfe(x[k], 8 * j + 7, 1)), "s"(0xFFFFu));
-                old[i] = atomicAdd(&h[slot[i] & 0x7FFFu], inc[i]);
+                old[i] = atomicAdd(&h[slot[i]], inc[i]);
             }
         }
 #pragma unroll
@@ -188,7 +189,8 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_o1_kernel(const uint8_t *__
         if (newly & CROSS) {                                     // some add of this lane crossed a multiple of 0x4000
 #pragma unroll
             for (int i = 0; i < 16; ++i)
-                if (((old[i] + inc[i]) ^ old[i]) & CROSS) hist_fixup<GUARD>(h, counts, slot[i], cross, cross_cap);
+                if (((old[i] + inc[i]) ^ old[i]) & CROSS)        // (the slot's bit 15, the symbol's top bit, says which half was added to)
+                    hist_fixup<GUARD>(h, counts, slot[i] | (inc[i] != 1u ? 0x8000u : 0u), cross, cross_cap);
         }
     }
     // ragged tail (< 16 bytes): one lane of block 0 — in region mode of the workgroup whose region holds that vector
