@@ -269,6 +269,9 @@ def main():
     ap.add_argument("--kind", default=None, choices=["zipf", "uniform", "text"])
     ap.add_argument("--order", type=int, default=1, choices=[1, 2],
                     help="2 = order-2 contexts (BASELINE configs[4]; extension the reference does not have: parity unpinned; 1 GPU)")
+    ap.add_argument("--o2-exchange", default="scatter", choices=["scatter", "allreduce"],
+                    help="order 2, N > 1: reduce-scatter of the 1 << 24 counts + per-rank tree build of 65536 / N contexts + all-gather of "
+                         "the per-context arrays (SURVEY 8e), or all-reduce the counts and build everything on every rank")
     ap.add_argument("--cpu-sample", type=int, default=256 << 20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -309,6 +312,8 @@ def main():
 
     mhc = entry.load_package()
     mhc.lib()                      # fails loudly if libmhc.so is missing: there is no fallback path
+    import importlib
+    sharded = importlib.import_module("mhc_amd.sharded")
     kind = args.kind or ("uniform" if args.config == 4 else "zipf")
     # ---- what each rank holds: bytes [first, first + n) of ONE seeded stream
     if args.total_size is not None:
@@ -352,11 +357,16 @@ def main():
         e[0].record()
         codec.histogram(data, prev0)
         e[1].record()
+        o2_shared = world > 1 and args.order == 2 and args.o2_exchange == "scatter" and 65536 % world == 0
         if world > 1:
             local_counts.copy_(codec.counts)          # the shard's own histogram fixes its payload length
-            all_reduce(codec.counts)                  # the one collective: 512 KiB sum over xGMI (order 2: 128 MiB)
+            if not o2_shared:
+                all_reduce(codec.counts)              # the one collective: 512 KiB sum over xGMI (order 2: 128 MiB)
         e[2].record()
-        model = codec.build_model()                   # the step's one host wait (16 KiB of table sizes)
+        if o2_shared:                                 # reduce-scatter, 65536 / N trees per rank, all-gather of the per-context arrays
+            model = sharded.order2_model(mhc, codec.counts, codec.stream(), exchange="scatter")
+        else:
+            model = codec.build_model()               # the step's one host wait (16 KiB of table sizes)
         e[3].record()
         if world > 1:
             # placement before encoding: shard bits = local histogram . code lengths, all-gather,
@@ -461,7 +471,8 @@ def main():
                                     if kind != "text" else "8 MiB of seeded Lorem-Ipsum-style text, tiled",
                        "sharding": ("contiguous byte ranges, histogram all-reduce (%s, %s)" %
                                     ("RCCL over xGMI" if args.backend == "nccl" else "gloo staged through host memory: REHEARSAL, not RCCL",
-                                     "512 KiB" if args.order == 1 else "128 MiB")) if world > 1 else "single GPU",
+                                     "512 KiB" if args.order == 1 else ("128 MiB" if args.o2_exchange != "scatter" or 65536 % world else
+                                                                        "order 2: reduce-scatter of the counts, 65536 / N trees per rank, all-gather of the per-context arrays"))) if world > 1 else "single GPU",
                        "backend": (dist.get_backend() if world > 1 else None), "ranks": (dist.get_world_size() if world > 1 else 1)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,

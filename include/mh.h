@@ -148,6 +148,18 @@ void mh_model_free(mh_model *m);
  *   - `prev0` arguments stand for BOTH context bytes.
  * All tables live in HBM and are served from L2 / the Infinity Cache (16.7 M codewords do not fit LDS).
  */
+/* The order-2 model build in two steps, for ranks that share it: after a reduce-scatter of the 1 << 24
+ * counts every rank holds the summed counts of its 65536 / G contexts, builds THEIR trees into a workspace of
+ * mh_dev_model2_workspace() bytes (mh_dev_model2_build_slice; d_counts_slice = first count of context ctx_first), the
+ * ranks all-gather the per-context arrays in place — mh_dev_model2_array(which, &offset, &bytes_per_context), which = 0..6:
+ * a rank's share of array `which` is the byte range [offset + ctx_first * bytes_per_context, offset + ctx_end *
+ * bytes_per_context) — and mh_dev_model2_finish derives every table from them (one stream synchronisation).  The model
+ * borrows the workspace.  mh_dev_model_from_counts(order 2) is the same two steps over all contexts. */
+size_t mh_dev_model2_workspace(void);
+int mh_dev_model2_array(int which, size_t *offset, size_t *bytes_per_context);
+int mh_dev_model2_build_slice(const uint64_t *d_counts_slice, uint32_t ctx_first, uint32_t ctx_end,
+                              void *d_ws, size_t ws_bytes, void *stream);
+int mh_dev_model2_finish(void *d_ws, size_t ws_bytes, void *stream, mh_model **out);
 int mh_histogram_o2(const uint8_t *data, size_t n, uint64_t *counts /* 1 << 24 */);
 int mh_dev_histogram_o2(const uint8_t *d_data, size_t n, uint16_t ctx0, uint64_t *d_counts /* 1 << 24 */, void *stream);
 

@@ -38,6 +38,7 @@ EXPORTS = [
     "mh_dev_histogram_workspace", "mh_dev_histogram_o1", "mh_dev_histogram_o0",
     "mh_decode_to", "mh_model_payload_bits", "mh_dev_encode_workspace", "mh_dev_encode", "mh_dev_payload_bits", "mh_dev_encode_at", "mh_dev_encode_ctx", "mh_dev_encode_hist", "mh_dev_decode_workspace", "mh_dev_decode", "mh_dev_decode_dn",
     "mh_dev_build_index_workspace", "mh_dev_build_index", "mh_dev_status",
+    "mh_dev_model2_workspace", "mh_dev_model2_array", "mh_dev_model2_build_slice", "mh_dev_model2_finish",
     "mh_dev_encode_fine", "mh_dev_encode_ctx_fine", "mh_dev_decode_fine", "mh_dev_build_index_fine", "mh_dev_index_path", "mh_dev_encode_path",
 ]
 
@@ -114,6 +115,11 @@ def lib():
         l.mh_dev_build_index.argtypes = [vp, vp, u64, u8, vp, u64, u32, vp, vp, sz, vp]
         l.mh_dev_status.argtypes = [vp, vp]
         l.mh_dev_encode_fine.argtypes = [vp, vp, sz, u8, vp, vp, sz, vp, vp, u32, vp, vp, sz, vp, sz, vp]
+        l.mh_dev_model2_workspace.argtypes = []
+        l.mh_dev_model2_workspace.restype = sz
+        l.mh_dev_model2_array.argtypes = [i32, psz, psz]
+        l.mh_dev_model2_build_slice.argtypes = [vp, u32, u32, vp, sz, vp]
+        l.mh_dev_model2_finish.argtypes = [vp, sz, vp, C.POINTER(vp)]
         l.mh_dev_encode_ctx_fine.argtypes = [vp, vp, sz, u32, vp, vp, sz, vp, vp, u32, vp, vp, sz, vp]
         l.mh_dev_decode_fine.argtypes = [vp, vp, u64, vp, vp, u64, vp, u32, vp, vp, sz, vp]
         l.mh_dev_build_index_fine.argtypes = [vp, vp, u64, u8, vp, u64, u32, vp, u64, vp, vp, sz, vp]

@@ -729,22 +729,37 @@ int o2_hot_setup(mh_model *m, const std::vector<uint64_t> &weight, const std::ve
     return MH_OK;
 }
 
-// counts (1 << 24, device) -> 65536 trees, codes and decode tables, all on the device
-int dev_model_build2(const uint64_t *d_counts, hipStream_t st, mh_model **out) {
+// Order-2 model build in two steps, so that G ranks can share it (reduce-scatter of the 1 << 24 counts,
+// every rank builds the trees of its 65536 / G contexts, all-gather of the per-context arrays):
+//   build2_slice   trees, code lengths, codewords and node arrays of contexts [c0, c1) from their counts, written to
+//                  their place in the (caller's or the model's own) workspace — every array is laid out by context, so
+//                  a rank's share of each is ONE contiguous range that a collective can gather in place
+//   build2_finish  with all 65536 contexts in place: the packed encoder entries, the decode tables, the live contexts'
+//                  LDS tables; one sync for the 4 MiB of per-context sizes
+int build2_slice(const uint64_t *d_counts_slice, uint32_t c0, uint32_t c1, unsigned char *b, hipStream_t st) {
+    if (c0 >= c1 || c1 > O2_CTX) return MH_ERR_ARG;
+    const Build2Layout L = build2_layout();
+    mhk::TreeBuildOut tb{b + L.off[0] + size_t(c0) * 256, reinterpret_cast<unsigned long long *>(b + L.off[1]) + size_t(c0) * 256, nullptr, nullptr,
+                         reinterpret_cast<uint16_t *>(b + L.off[5]) + size_t(c0) * mhk::TB_NODE_STRIDE,
+                         reinterpret_cast<uint16_t *>(b + L.off[6]) + size_t(c0) * mhk::TB_NODE_STRIDE,
+                         b + L.off[7] + size_t(c0) * mhk::TB_NODE_STRIDE, b + L.off[8] + size_t(c0) * mhk::TB_NODE_STRIDE,
+                         reinterpret_cast<uint32_t *>(b + L.off[9]) + size_t(c0) * mhk::TB_META_STRIDE, O2_HCAP};
+    HIP_TRY(mhk::launch_tree_build(reinterpret_cast<const unsigned long long *>(d_counts_slice), int(c1 - c0), tb, st));
+    return MH_OK;
+}
+
+int build2_finish(unsigned char *b, bool owned, hipStream_t st, mh_model **out) {
     mh_model *m = new (std::nothrow) mh_model;
     if (!m) return MH_ERR_NOMEM;
     m->type = 2; m->nctx = O2_CTX; m->mirror_ready = false;
     m->dec_bits = 8; m->dec_lds = false; m->dec_direct = false; m->dec_h = 0;
+    if (owned) m->d_build = b;
     auto fail = [&](int rc) { mh_model_free(m); return rc; };
 #define HIP_TRY_M(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(hip_fail(_e)); } while (0)
     HIP_TRY_M(hipGetDevice(&m->device));
     const Build2Layout L = build2_layout();
-    HIP_TRY_M(hipMalloc(&m->d_build, L.total));
     uint8_t *d_node_height = nullptr;
-    place2(m, static_cast<unsigned char *>(m->d_build), L, &d_node_height);
-    mhk::TreeBuildOut tb{m->d_len8, reinterpret_cast<unsigned long long *>(m->d_code64), nullptr, nullptr,
-                         m->d_node_left, m->d_node_right, m->d_node_sym, d_node_height, m->d_meta, O2_HCAP};
-    HIP_TRY_M(mhk::launch_tree_build(reinterpret_cast<const unsigned long long *>(d_counts), int(O2_CTX), tb, st));
+    place2(m, b, L, &d_node_height);
     HIP_TRY_M(mhk::launch_enc64_pack(m->d_len8, m->d_code64, m->d_enc64, uint64_t(O2_CTX) * 256, st));
     std::vector<uint32_t> meta(size_t(O2_CTX) * mhk::TB_META_STRIDE);
     HIP_TRY_M(hipMemcpyAsync(meta.data(), m->d_meta, meta.size() * 4, hipMemcpyDeviceToHost, st));
@@ -789,6 +804,15 @@ int dev_model_build2(const uint64_t *d_counts, hipStream_t st, mh_model **out) {
 #undef HIP_TRY_M
     *out = m;
     return MH_OK;
+}
+
+// counts (1 << 24, device) -> 65536 trees, codes and decode tables, all on the device
+int dev_model_build2(const uint64_t *d_counts, hipStream_t st, mh_model **out) {
+    void *b = nullptr;
+    HIP_TRY(hipMalloc(&b, build2_layout().total));
+    const int rc = build2_slice(d_counts, 0, O2_CTX, static_cast<unsigned char *>(b), st);
+    if (rc != MH_OK) { (void)hipFree(b); return rc; }
+    return build2_finish(static_cast<unsigned char *>(b), true, st, out);     // (the model frees `b`, also when it fails)
 }
 
 // order-2 table file -> host-derived images (ContextCoder per non-empty context) -> device
@@ -900,6 +924,32 @@ int mh_dev_model_from_counts_ws(const uint64_t *d_counts, int order, void *d_ws,
     // the rare model the device packer does not lay out: built on the host instead (that model owns its memory)
     if (rc == BUILD_NEEDS_HOST) return model_from_device_counts_via_host(d_counts, order, static_cast<hipStream_t>(stream), out);
     return rc;
+}
+
+size_t mh_dev_model2_workspace(void) { return build2_layout().total; }
+
+int mh_dev_model2_array(int which, size_t *offset, size_t *bytes_per_context) {
+    // the per-context arrays a slice build fills: 0 code lengths, 1 codewords, 2..5 tree nodes (left, right, symbol,
+    // height), 6 per-context sizes
+    static const int idx[7] = {0, 1, 5, 6, 7, 8, 9};
+    static const size_t per[7] = {256, 256 * 8, size_t(mhk::TB_NODE_STRIDE) * 2, size_t(mhk::TB_NODE_STRIDE) * 2, size_t(mhk::TB_NODE_STRIDE),
+                                  size_t(mhk::TB_NODE_STRIDE), size_t(mhk::TB_META_STRIDE) * 4};
+    if (which < 0 || which >= 7 || !offset || !bytes_per_context) return MH_ERR_ARG;
+    *offset = build2_layout().off[idx[which]];
+    *bytes_per_context = per[which];
+    return MH_OK;
+}
+
+int mh_dev_model2_build_slice(const uint64_t *d_counts_slice, uint32_t ctx_first, uint32_t ctx_end, void *d_ws, size_t ws_bytes, void *stream) {
+    if (!d_counts_slice || !d_ws || !aligned16(d_ws) || ws_bytes < build2_layout().total) return MH_ERR_ARG;
+    if (!have_device()) return MH_ERR_NO_DEVICE;
+    return build2_slice(d_counts_slice, ctx_first, ctx_end, static_cast<unsigned char *>(d_ws), static_cast<hipStream_t>(stream));
+}
+
+int mh_dev_model2_finish(void *d_ws, size_t ws_bytes, void *stream, mh_model **out) {
+    if (!d_ws || !out || !aligned16(d_ws) || ws_bytes < build2_layout().total) return MH_ERR_ARG;
+    if (!have_device()) return MH_ERR_NO_DEVICE;
+    return build2_finish(static_cast<unsigned char *>(d_ws), false, static_cast<hipStream_t>(stream), out);
 }
 
 int mh_dev_model_from_counts(const uint64_t *d_counts, int order, void *stream, mh_model **out) {

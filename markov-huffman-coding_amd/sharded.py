@@ -65,6 +65,61 @@ def merged_histogram(local_counts, group=None):
     return local_counts
 
 
+def order2_model(mhc, local_counts, stream=None, group=None, exchange="scatter"):
+    """Order-2 model (extension, parity unpinned) shared by the ranks of `group` from each rank's LOCAL counts
+    (int64[1 << 24] on the device).  exchange:
+      "scatter"    SURVEY.md 8e's alternative to all-reducing 128 MiB: reduce-scatter of the counts (each rank gets the
+                   global counts of its 65536 / G contexts), every rank builds the trees of THOSE contexts
+                   (mh_dev_model2_build_slice), the per-context arrays (code lengths, codewords, tree nodes, sizes) are
+                   all-gathered in place, mh_dev_model2_finish derives the tables.  Needs G to divide 65536.
+      "allreduce"  all-reduce the counts, every rank builds everything (local_counts becomes the global histogram).
+    Returns the Model; it borrows a workspace tensor that is kept alive on the object.  With gloo (rehearsals with the
+    shards on one card) the collectives are staged through host memory and the reduce-scatter is an all-reduce + slice
+    (gloo has none)."""
+    import ctypes as C
+    lib = mhc.lib()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    staged = local_counts.is_cuda and dist.get_backend(group) != "nccl"
+    nctx = 65536
+    if exchange != "scatter" or nctx % world != 0:
+        merged_histogram(local_counts, group)
+        return mhc.Model.from_device_counts(local_counts.data_ptr(), 2, stream)
+    per = nctx // world
+    c0, c1 = rank * per, (rank + 1) * per
+    mine = torch.empty(per * 256, dtype=torch.int64, device=local_counts.device)
+    if staged:
+        host = local_counts.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        mine.copy_(host[c0 * 256:c1 * 256])
+    else:
+        dist.reduce_scatter_tensor(mine, local_counts, op=dist.ReduceOp.SUM, group=group)
+    wsb = int(lib.mh_dev_model2_workspace())
+    ws = torch.empty(wsb, dtype=torch.uint8, device=local_counts.device)
+    rc = lib.mh_dev_model2_build_slice(mine.data_ptr(), c0, c1, ws.data_ptr(), wsb, stream)
+    if rc != 0:
+        raise mhc.MhError(rc, "mh_dev_model2_build_slice")
+    off, stride = C.c_size_t(), C.c_size_t()
+    for which in range(7):                       # every array is laid out by context: a rank's share is one contiguous range
+        rc = lib.mh_dev_model2_array(which, C.byref(off), C.byref(stride))
+        if rc != 0:
+            raise mhc.MhError(rc, "mh_dev_model2_array")
+        whole = ws[off.value:off.value + nctx * stride.value]
+        part = whole[c0 * stride.value:c1 * stride.value]
+        if staged:
+            hw, hp = whole.cpu(), part.cpu()
+            dist.all_gather_into_tensor(hw, hp, group=group)
+            whole.copy_(hw)
+        else:
+            dist.all_gather_into_tensor(whole, part, group=group)      # in place: the input is the rank's own range of the output
+    h = C.c_void_p()
+    rc = lib.mh_dev_model2_finish(ws.data_ptr(), wsb, stream, C.byref(h))
+    if rc != 0:
+        raise mhc.MhError(rc, "mh_dev_model2_finish")
+    model = mhc.Model(h)
+    model._workspace = ws                        # the model borrows it
+    return model
+
+
 def global_bit_offsets(local_nbits, group=None):
     """All-gather of the shard payload lengths -> (this rank's global start bit, total bits, all lengths)."""
     world = dist.get_world_size(group)

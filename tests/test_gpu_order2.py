@@ -209,3 +209,56 @@ def test_order2_config5_size_properties_parity_unpinned(mhc):
     assert t.type == 2 and t.table_bytes() == table
     for which in (1, 3):                                          # code lengths and codewords of all 16.7 M pairs
         assert t.image(which) == model.image(which)
+
+
+# ------------------------------------------------------------------ the model build shared by two ranks (reduce-scatter path)
+
+def _o2_rank(rank, world, port, data, q):
+    import os, sys, importlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)                 # both ranks share the one card of the test box
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import __graft_entry__ as e2
+        mhc = e2.load_package()
+        lib = mhc.lib()
+        sharded = importlib.import_module("mhc_amd.sharded")
+        lo, hi = sharded.shard_bounds(len(data), world)[rank]
+        shard = torch.frombuffer(bytearray(data[lo:hi] + bytes(32)), dtype=torch.uint8)[:hi - lo].cuda()
+        ctx0 = 0x2020 if lo == 0 else (data[lo - 2] << 8 | data[lo - 1])
+        counts = torch.zeros(1 << 24, dtype=torch.int64, device="cuda")
+        assert lib.mh_dev_histogram_o2(shard.data_ptr(), hi - lo, ctx0, counts.data_ptr(), None) == 0
+        model = sharded.order2_model(mhc, counts, None, exchange="scatter")
+        q.put((rank, model.table_bytes(), bytes(model.image(1)), model.max_code_len))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_order2_model_shared_by_two_ranks_parity_unpinned(mhc, oracle):
+    """SURVEY.md 8e's order-2 exchange with the shipped code, two gloo ranks on the one card: local histograms,
+    reduce-scatter (staged: gloo), each rank builds the trees of ITS half of the contexts, the per-context arrays are
+    all-gathered in place, mh_dev_model2_finish — both ranks end with the table file and the code lengths the oracle
+    derives from the whole input."""
+    import socket
+    import torch.multiprocessing as mp
+    data = text_like((2 << 20) + 77, 21)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_o2_rank, args=(r, 2, port, data, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    o = oracle.Model.from_data(data, 2)
+    lo, _ = o.codes_o2()
+    for g in got:
+        assert g[1] == o.table_bytes()
+        assert np.array_equal(np.frombuffer(g[2], dtype=np.uint8), lo)

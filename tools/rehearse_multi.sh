@@ -26,4 +26,5 @@ run weak_zipf_2g --size 2147483648
 run strong_zipf_4g --total-size 4294967296
 run config4_1g --config 4 --size 1073741824
 run order2_text_1g --order 2 --kind text --size 1073741824
+run order2_text_1g_allreduce --order 2 --kind text --size 1073741824 --o2-exchange allreduce
 cat $OUT/rehearse.txt
