@@ -683,6 +683,7 @@ int o2_hot_setup(mh_model *m, const std::vector<uint64_t> &weight, const std::ve
     if (nslots == 0) return MH_OK;
     long double covered = 0;
     std::vector<uint16_t> slot_ctx(nslots), ctx2slot(O2_CTX, 0xFFFF);
+    std::vector<uint8_t> slot_id1(nslots);
     std::vector<unsigned char> head(8448, 0);                      // symid | ctxmap
     std::memcpy(head.data(), symid, 256);
     uint16_t *ctxmap = reinterpret_cast<uint16_t *>(head.data() + 256);
@@ -690,8 +691,9 @@ int o2_hot_setup(mh_model *m, const std::vector<uint64_t> &weight, const std::ve
     for (uint32_t s = 0; s < nslots; ++s) {
         const uint32_t c = cand[s];
         slot_ctx[s] = uint16_t(c);
+        slot_id1[s] = symid[c & 255u];
         ctx2slot[c] = uint16_t(s);
-        ctxmap[(uint32_t(symid[c >> 8]) << 6) | symid[c & 255u]] = uint16_t(s);
+        ctxmap[(uint32_t(symid[c >> 8]) << 6) | (symid[c & 255u] ^ symid[c >> 8])] = uint16_t(s);   // column XOR-ed with the row's id (bank spreading)
         covered += weight[c] ? weight[c] : 1;
     }
     const bool all_hot = nslots == nlive;
@@ -699,7 +701,7 @@ int o2_hot_setup(mh_model *m, const std::vector<uint64_t> &weight, const std::ve
     const bool tiles = all_hot && m->d_node_left != nullptr;
     const size_t img = 8448 + size_t(nslots + 1) * 128;
     auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
-    const size_t off_map = up(img), off_sc = off_map + up(size_t(O2_CTX) * 2), off_tp = off_sc + up(size_t(nslots) * 2);
+    const size_t off_map = up(img), off_sc = off_map + up(size_t(O2_CTX) * 2), off_s1 = off_sc + up(size_t(nslots) * 2), off_tp = off_s1 + up(nslots);
     const size_t off_ts = off_tp + (tiles ? up((size_t(nslots) << P) * 4) : 0);
     const size_t nsec = tiles ? ((size_t(nslots) << P) << H) : 0;
     const size_t tot = off_ts + up(nsec * 4 + 64);
@@ -709,7 +711,9 @@ int o2_hot_setup(mh_model *m, const std::vector<uint64_t> &weight, const std::ve
     HIP_TRY(hipMemcpyAsync(b, head.data(), head.size(), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(b + off_map, ctx2slot.data(), size_t(O2_CTX) * 2, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(b + off_sc, slot_ctx.data(), size_t(nslots) * 2, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(b + off_s1, slot_id1.data(), size_t(nslots), hipMemcpyHostToDevice, st));
     a.slot_ctx = reinterpret_cast<const uint16_t *>(b + off_sc); a.nslots = nslots;
+    a.slot_id1 = b + off_s1;
     a.len8 = m->d_len8; a.code64 = reinterpret_cast<const unsigned long long *>(m->d_code64);
     a.hot = reinterpret_cast<uint16_t *>(b + 8448);
     a.ctx2slot = reinterpret_cast<const uint16_t *>(b + off_map);

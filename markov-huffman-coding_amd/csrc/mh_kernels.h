@@ -200,6 +200,7 @@ struct TreePackArgs {
 // order 2: tables of the live contexts (one slot each) for the LDS-resident encoder and the tile decoder
 struct O2HotArgs {
     const uint16_t *slot_ctx;     // nslots: the context of each slot
+    const uint8_t *slot_id1;      // nslots: id of each slot's second context byte (column permutation of the encoder rows)
     uint32_t nslots;
     uint8_t id_sym[64];           // byte value of id 0..62 (unused ids: any value with id_used 0)
     uint8_t id_used[64];

@@ -362,8 +362,8 @@ __device__ __forceinline__ LaneIn load_raw2(const uint8_t *__restrict__ data, ui
 // Text-like sources use a few hundred two-byte contexts over a few dozen byte values.  The model builder (mh_api.cpp,
 // dev_model_build2) ranks the byte values (the 63 most frequent get ids 0..62, every other byte id 63) and gives the
 // heaviest contexts whose two bytes both have an id < 63 a slot; the image `o2hot` it hands over is
-//     symid[256] u8 | ctxmap[64 * 64] u16 (id of the byte before the previous << 6 | id of the previous -> slot) |
-//     hot[(nslots + 1) * 64] u16 (slot << 6 | id of the symbol -> len << 12 | code, as the order-1 table)
+//     symid[256] u8 | ctxmap[64 * 64] u16 (id of the byte before the previous << 6 | (id of the previous ^ that id) -> slot) |
+//     hot[(nslots + 1) * 64] u16 (slot << 6 | (id of the symbol ^ id of the previous byte) -> len << 12 | code, as the order-1 table)
 // with the last slot all ENC16_ESCAPE (what ctxmap gives for every other context) and column 63 all ENC16_ESCAPE.  An
 // escape sends the wave's sub-step through the symbol-by-symbol path with the full tables in L2 (emit_substep_slow<2>), so
 // the image is only handed over when the slots cover (nearly) the whole input (the builder knows every context's weight).
@@ -377,11 +377,14 @@ __device__ __forceinline__ void o2hot_lookup16(const unsigned char *img, const u
     id[1] = img[ctx & 255u];
 #pragma unroll
     for (int j = 0; j < 16; ++j) id[2 + j] = img[(x[j >> 2] >> (8 * (j & 3))) & 255u];
+    // Both tables are read at a column XOR-ed with the id of the byte in front: with a few dozen byte values, and
+    // rows of 64 two-byte entries = 32 banks, the bank of a plain [row][id] access is id / 2 whatever the row — every
+    // lane that looks at a frequent letter lands on the same bank (the builder stores the rows permuted accordingly)
     uint32_t cs[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) cs[j] = ctxmap[(id[j] << 6) | id[j + 1]];
+    for (int j = 0; j < 16; ++j) cs[j] = ctxmap[(id[j] << 6) | (id[j + 1] ^ id[j])];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) e[j] = hot[(cs[j] << 6) | id[j + 2]];
+    for (int j = 0; j < 16; ++j) e[j] = hot[(cs[j] << 6) | (id[j + 2] ^ id[j + 1])];
 }
 
 // ---- pass 1 ------------------------------------------------------------------------------------

@@ -290,7 +290,8 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
                     win[k] = WIN ? lo[k] : __builtin_amdgcn_alignbit(w1[k], w0[k], q[k]);   // 32 stream bits from bit q on, first in bit 0
                     // byte address of the entry (the table starts at LDS address 0, checked at entry): context << (P + 1) | bits << 1
                     if (O2) {                                      // slot << (P + 2) | bits << 2: 32-bit entries
-                        e[k] = *lds_ptr<uint32_t>(((win[k] << 2) & ((4u << P) - 4u)) | ((cf[k] >> 16) << (P + 2)));
+                        // (column XOR-ed with the slot: text's frequent codes otherwise put every lane on the same few banks)
+                        e[k] = *lds_ptr<uint32_t>((((win[k] ^ (cf[k] >> 16)) << 2) & ((4u << P) - 4u)) | ((cf[k] >> 16) << (P + 2)));
                     } else {
                         const uint32_t csh = P == 7 ? __builtin_amdgcn_perm(0u, cf[k], 0x0C0C000Cu)       // byte 0 -> byte 1
                                                     : (cf[k] & 255u) << (P + 1);

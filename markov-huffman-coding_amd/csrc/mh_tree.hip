@@ -469,7 +469,8 @@ __global__ __launch_bounds__(64) void o2_hot_pack_kernel(O2HotArgs a) {
             const uint32_t l = a.len8[k];
             e = l == 0 ? uint16_t(0) : (l > uint32_t(mh::ENC16_MAX_LEN) ? mh::ENC16_ESCAPE : uint16_t((l << 12) | uint32_t(a.code64[k])));
         }
-        a.hot[slot * 64u + lane] = e;
+        // stored at column id ^ (id of the context's second byte): the encoders read it there (bank spreading)
+        a.hot[slot * 64u + (lane ^ a.slot_id1[slot])] = e;
     }
     if (!a.tprim) return;
     // tile decoder: first level of P bits (lane = window value, LSB-first), uniform second-level tables of 2^H entries;
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(64) void o2_hot_pack_kernel(O2HotArgs a) {
         const uint32_t id = (slot << P) + rank;                   // sparse ids: at most 2^P tables per slot
         uint32_t e = DEC16_NULL;
         if (root != 0xFFFFFFFFu) e = inner ? id : leaf_entry(node, depth);
-        a.tprim[(slot << P) + w] = e;
+        a.tprim[(slot << P) + (w ^ (slot & ((1u << P) - 1u)))] = e;       // stored at column w ^ slot: the decoder reads it there (bank spreading)
         if (inner) {
             for (uint32_t x = 0; x < (1u << H); ++x) {
                 uint32_t n2 = node, d2 = 0;
