@@ -111,6 +111,7 @@ struct InputView {
             if (m != MAP_FAILED) {
                 map = m; map_len = (size_t)st.st_size;
                 (void)madvise(m, map_len, MADV_SEQUENTIAL);
+                populate_read();
                 data = (const unsigned char*)m + pos;
                 size = map_len - (size_t)pos;
                 fseek(f, 0, SEEK_END);
@@ -121,7 +122,27 @@ struct InputView {
         data = own.data();
         size = own.size();
     }
-    ~InputView() { if (map) munmap(map, map_len); }
+    // The mapping's pages are in the page cache but not in this process's page table: the first pass over it (the
+    // library's copy into its pinned upload ring) would take a minor fault per 4 KiB — a million of them for 4 GiB.  A few
+    // helper threads ask the kernel to map them in bulk (MADV_POPULATE_READ) while the process is still starting the device.
+    std::vector<std::thread> populate;
+    void populate_read() {
+#ifdef MADV_POPULATE_READ
+        if (!map || map_len < (size_t(64) << 20) || getenv("MH_NO_POPULATE_READ")) return;
+        const size_t threads = 4, step = size_t(64) << 20;
+        const size_t part = ((map_len / threads) + step - 1) / step * step;
+        for (size_t t = 0; t < threads; ++t) {
+            const size_t lo = t * part, hi = std::min(map_len, lo + part);
+            if (lo >= hi) break;
+            unsigned char* base = (unsigned char*)map;
+            populate.emplace_back([base, lo, hi, step] {
+                for (size_t o = lo; o < hi; o += step)
+                    if (madvise(base + o, std::min(step, hi - o), MADV_POPULATE_READ) != 0) return;   // old kernel: plain faults do it
+            });
+        }
+#endif
+    }
+    ~InputView() { for (std::thread& t : populate) t.join(); if (map) munmap(map, map_len); }
     InputView(const InputView&) = delete;
     InputView& operator=(const InputView&) = delete;
 };
