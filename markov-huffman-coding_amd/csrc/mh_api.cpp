@@ -32,6 +32,7 @@ struct mh_model {
     bool mirror_ready = true;
     std::mutex mu;
     void *d_build = nullptr;     // enc/dec images + node arrays + meta (device build)
+    bool build_cached = false;   // order 2: d_build goes back to the one-entry block cache when the model is freed
     void *d_sec_own = nullptr;   // second-level tables (device build)
     uint16_t *d_node_left = nullptr, *d_node_right = nullptr;
     uint8_t *d_node_sym = nullptr;
@@ -723,7 +724,7 @@ int o2_hot_setup(mh_model *m, const std::vector<uint64_t> &weight, const std::ve
         a.tprim = reinterpret_cast<uint32_t *>(b + off_tp); a.tsec = reinterpret_cast<uint32_t *>(b + off_ts);
     }
     HIP_TRY(mhk::launch_o2_hot_pack(a, st));
-    HIP_TRY(hipStreamSynchronize(st));                            // the staging vectors above are on this frame
+    HIP_TRY(hipStreamSynchronize(st));                            // the staging vectors above are on this frame (the caller syncs next anyway: the wait is paid once)
     m->d_o2img = b; m->o2img_bytes = uint32_t(img);
     m->d_ctx2slot = reinterpret_cast<uint16_t *>(b + off_map);
     m->o2_nslots = nslots; m->o2_p = P; m->o2_h = H; m->o2_nsec = uint32_t(nsec);
@@ -757,7 +758,7 @@ int build2_finish(unsigned char *b, bool owned, hipStream_t st, mh_model **out) 
     if (!m) return MH_ERR_NOMEM;
     m->type = 2; m->nctx = O2_CTX; m->mirror_ready = false;
     m->dec_bits = 8; m->dec_lds = false; m->dec_direct = false; m->dec_h = 0;
-    if (owned) m->d_build = b;
+    if (owned) { m->d_build = b; m->build_cached = true; }
     auto fail = [&](int rc) { mh_model_free(m); return rc; };
 #define HIP_TRY_M(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(hip_fail(_e)); } while (0)
     HIP_TRY_M(hipGetDevice(&m->device));
@@ -770,14 +771,16 @@ int build2_finish(unsigned char *b, bool owned, hipStream_t st, mh_model **out) 
     HIP_TRY_M(hipStreamSynchronize(st));
     std::vector<uint32_t> sec_base(O2_CTX);
     size_t nsec = 0;
+    uint32_t lenmask = 0;                                         // union of the contexts' code-length sets (gcd of a union = gcd of its members)
     for (uint32_t c = 0; c < O2_CTX; ++c) {
         const uint32_t *mt = &meta[size_t(c) * mhk::TB_META_STRIDE];
         m->max_len = std::max(m->max_len, int(mt[2]));
-        for (uint32_t l = 1; l <= 32; ++l)
-            if (mt[15] & (1u << (l - 1))) m->len_gcd = gcd_u32(m->len_gcd, l == 32 ? 1u : l);
+        lenmask |= mt[15];
         sec_base[c] = uint32_t(nsec);
         nsec += mt[4 + 8];                                        // tables under the depth-8 nodes, heights capped at O2_HCAP
     }
+    for (uint32_t l = 1; l <= 32; ++l)
+        if (lenmask & (1u << (l - 1))) m->len_gcd = gcd_u32(m->len_gcd, l == 32 ? 1u : l);
     if (nsec > 0xFFFFFFFFull - 4096) return fail(MH_ERR_CAPACITY);
     m->nsec = uint32_t(nsec);
     if (m->max_len > mh::MAX_CODE_BITS) { *out = m; return MH_OK; }
@@ -811,9 +814,29 @@ int build2_finish(unsigned char *b, bool owned, hipStream_t st, mh_model **out) 
 }
 
 // counts (1 << 24, device) -> 65536 trees, codes and decode tables, all on the device
+// The ~600 MiB build block of an order-2 model is kept when a model is freed and handed to the next build on the same
+// device (a codec that rebuilds its model per stream — bench.py — otherwise pays a hipMalloc / hipFree of that size per step).
+struct Build2Cache { std::mutex mu; void *p = nullptr; int device = -1; } g_build2_cache;
+void *build2_block_take() {
+    std::lock_guard<std::mutex> lock(g_build2_cache.mu);
+    int dev = -1;
+    if (g_build2_cache.p && hipGetDevice(&dev) == hipSuccess && dev == g_build2_cache.device) {
+        void *p = g_build2_cache.p;
+        g_build2_cache.p = nullptr;
+        (void)hipDeviceSynchronize();             // what hipFree would have waited for: nothing still reads the freed model's tables
+        return p;
+    }
+    return nullptr;
+}
+void build2_block_give(void *p, int device) {
+    std::lock_guard<std::mutex> lock(g_build2_cache.mu);
+    if (g_build2_cache.p) (void)hipFree(g_build2_cache.p);
+    g_build2_cache.p = p; g_build2_cache.device = device;
+}
+
 int dev_model_build2(const uint64_t *d_counts, hipStream_t st, mh_model **out) {
-    void *b = nullptr;
-    HIP_TRY(hipMalloc(&b, build2_layout().total));
+    void *b = build2_block_take();
+    if (!b) HIP_TRY(hipMalloc(&b, build2_layout().total));
     const int rc = build2_slice(d_counts, 0, O2_CTX, static_cast<unsigned char *>(b), st);
     if (rc != MH_OK) { (void)hipFree(b); return rc; }
     return build2_finish(static_cast<unsigned char *>(b), true, st, out);     // (the model frees `b`, also when it fails)
@@ -1065,7 +1088,10 @@ int mh_model_image(const mh_model *m, int which, void *out, size_t cap, size_t *
 void mh_model_free(mh_model *m) {
     if (!m) return;
     if (m->d_block) (void)hipFree(m->d_block);
-    if (m->d_build) (void)hipFree(m->d_build);
+    if (m->d_build) {
+        if (m->type == 2 && m->build_cached) build2_block_give(m->d_build, m->device);   // (waits for nothing: the caller has finished with the model)
+        else (void)hipFree(m->d_build);
+    }
     if (m->d_sec_own) (void)hipFree(m->d_sec_own);
     if (m->d_tile_own) (void)hipFree(m->d_tile_own);
     if (m->d_o2hot) (void)hipFree(m->d_o2hot);
