@@ -5,9 +5,9 @@ One "step" = one full pass of the hot path over one HBM-resident synthetic strea
     order-1 histogram -> [RCCL all-reduce of the 256x256 counts when N > 1] -> per-context tree build
     -> encode (payload + chunk index) -> decode (from payload + index)
 N = 1 workload: BASELINE.json configs[2] — 16 GiB of Zipf(s=1.1) bytes (the configuration the metric
-is quoted on; it fits one GPU).  N > 1, default: the stream is sharded into contiguous 16 GiB-per-GPU
-chunks (weak scaling).  `--total-size 17179869184` instead splits ONE 16 GiB stream over the N GPUs
-(strong scaling: the metric's "16 GB byte stream at 1/2/4/8 GPUs"), and `--config 4` is BASELINE.json
+is quoted on; it fits one GPU).  N > 1, default: that ONE 16 GiB stream is split into N contiguous shards
+(strong scaling: the metric's "16 GB byte stream at 1/2/4/8 GPUs"; `--total-size` for another total).
+`--size` instead gives every GPU that many bytes (weak scaling), and `--config 4` is BASELINE.json
 configs[3]: uniform random bytes, 8 GiB per GPU (64 GiB on 8).  Either way the only collective on the
 data path is the histogram all-reduce, and `config.workload` says which mode ran.
 
@@ -316,6 +316,10 @@ def main():
     sharded = importlib.import_module("mhc_amd.sharded")
     kind = args.kind or ("uniform" if args.config == 4 else "zipf")
     # ---- what each rank holds: bytes [first, first + n) of ONE seeded stream
+    if args.total_size is None and args.size is None and world > 1 and args.config == 3 and args.order == 1:
+        # BASELINE.json's metric is ONE 16 GB stream at 1/2/4/8 GPUs: with no size given, N > 1 splits that stream
+        # (strong scaling); --size keeps a fixed amount per GPU (weak scaling), --config 4 is 8 GiB per GPU by definition
+        args.total_size = 16 << 30
     if args.total_size is not None:
         mode, total = "strong", args.total_size
         unit = 16                                  # shards start on 16-byte boundaries (device loads are 16-byte vectors)

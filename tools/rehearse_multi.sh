@@ -22,6 +22,7 @@ except Exception as e:
     print(sys.argv[2].ljust(18), "failed:", e)
 PY
 }
+run default_strong_16g
 run weak_zipf_2g --size 2147483648
 run strong_zipf_4g --total-size 4294967296
 run config4_1g --config 4 --size 1073741824
