@@ -154,7 +154,9 @@ void mh_model_free(mh_model *m);
  * ranks all-gather the per-context arrays in place — mh_dev_model2_array(which, &offset, &bytes_per_context), which = 0..6:
  * a rank's share of array `which` is the byte range [offset + ctx_first * bytes_per_context, offset + ctx_end *
  * bytes_per_context) — and mh_dev_model2_finish derives every table from them (one stream synchronisation).  The model
- * borrows the workspace.  mh_dev_model_from_counts(order 2) is the same two steps over all contexts. */
+ * borrows the workspace.  mh_dev_model_from_counts(order 2) is the same two steps over all contexts, in a ~600 MiB block of
+ * its own; that block is kept when the model is freed and reused by the next order-2 build on the same device (a codec
+ * that rebuilds its model per stream would otherwise allocate and free it every time). */
 size_t mh_dev_model2_workspace(void);
 int mh_dev_model2_array(int which, size_t *offset, size_t *bytes_per_context);
 int mh_dev_model2_build_slice(const uint64_t *d_counts_slice, uint32_t ctx_first, uint32_t ctx_end,

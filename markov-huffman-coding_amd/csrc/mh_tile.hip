@@ -25,8 +25,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <mutex>
+#include <utility>
+#include <vector>
 
 #include "mh_kernels.h"
 #include "mh_model.hpp"
@@ -415,11 +418,21 @@ static hipError_t launch_tile_with(void (*kern)(TileParams), TileParams p, const
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    hipDeviceProp_t prop;
-    static int cus = 0;
-    if (cus == 0) cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    // the dynamic-LDS attribute is a per-device, per-function setting: made once per (function, device), under a lock
+    // (models are shared by threads and mh_set_device() may switch devices inside one process)
+    {
+        static std::mutex mu;
+        static std::vector<std::pair<const void *, int>> done;
+        std::lock_guard<std::mutex> lock(mu);
+        const std::pair<const void *, int> key(reinterpret_cast<const void *>(kern), dev);
+        if (std::find(done.begin(), done.end(), key) == done.end()) {
+            e = hipFuncSetAttribute(key.first, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
+            if (e != hipSuccess) return e;
+            done.push_back(key);
+        }
+    }
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     p.ntiles = p.n / (uint64_t(K) * T_TILE);
     // workspace: [0,64) status | [64, 64 + 16) redo count ... as launch_decode lays it out; the geometry word lives in
     // the status block (bytes 4..7; bytes 8..39 take the diagnostic build's cycle sums)
