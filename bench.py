@@ -494,7 +494,9 @@ def main():
             # device-only fine index (4 B per 64 symbols); traffic of both kernels, never credit
             "index_bytes": {"chunk_index": int(codec.nidx * 8), "fine_index": int(((n + codec.fine_symbols - 1) // codec.fine_symbols) * 4) if codec.use_fine else 0},
             "max_code_len": model.max_code_len,
-            "decode_tables": dict(zip(("primary_bits", "secondary_entries", "in_lds"), model.decode_layout())),
+            "decode_tables": {"chunk_decoder": dict(zip(("primary_bits", "secondary_entries", "in_lds"), model.decode_layout())),
+                              "tile_decoder": dict(zip(("primary_bits_in_lds", "secondary_bits", "secondary_entries_in_l2"),
+                                                       model.tile_layout()))},
         }
         if args.order == 2:
             out["order"] = 2

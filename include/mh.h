@@ -124,6 +124,10 @@ int mh_model_get_lut(const mh_model *m, int prev, int w, int *present, int *is_i
  * is what makes both table levels fit LDS), *secondary_entries = second-level entries,
  * *in_lds = 1 when both levels are LDS-resident in the decode kernel. */
 int mh_model_decode_layout(const mh_model *m, int *primary_bits, int *secondary_entries, int *in_lds);
+/* The same for the tile decoder's tables (mh_dev_decode_fine; LSB-first indexed): *primary_bits = width of the
+ * LDS-resident first level (0: this model has no tile tables, mh_dev_decode_fine then runs the chunk decoder),
+ * *secondary_bits = height of the uniform second-level tables, *secondary_entries = their total entry count (L2). */
+int mh_model_tile_layout(const mh_model *m, int *primary_bits, int *secondary_bits, int *secondary_entries);
 /* Diagnostic: copies one of the model's device images to the host (tests compare the host-built and the
  * device-built tables bit for bit).  which: 0 enc16, 1 len8, 2 len_slot, 3 code64, 4 decode prim,
  * 5 decode sec, 6 sec_base, 7 walk tree, 8 / 9 the tile decoder's first- / second-level tables (LSB-first

@@ -31,7 +31,7 @@ EXPORTS = [
     "mh_dev_malloc", "mh_dev_free", "mh_dev_upload", "mh_dev_download",
     "mh_model_from_counts", "mh_dev_model_from_counts", "mh_dev_model_workspace", "mh_dev_model_from_counts_ws",
     "mh_model_from_table_bits", "mh_model_write_table",
-    "mh_model_type", "mh_model_max_code_len", "mh_model_get_code", "mh_model_get_lut", "mh_model_decode_layout",
+    "mh_model_type", "mh_model_max_code_len", "mh_model_get_code", "mh_model_get_lut", "mh_model_decode_layout", "mh_model_tile_layout",
     "mh_model_image", "mh_model_free",
     "mh_set_input_residency", "mh_histogram_o1", "mh_histogram_o0", "mh_histogram_o2", "mh_dev_histogram_o2", "mh_encode", "mh_encode_bound", "mh_stream_header",
     "mh_stream_parse_header", "mh_decode",
@@ -81,6 +81,7 @@ def lib():
         l.mh_model_get_code.argtypes = [vp, i32, i32, pi, pu64]
         l.mh_model_get_lut.argtypes = [vp, i32, i32, pi, pi, pi, pi]
         l.mh_model_decode_layout.argtypes = [vp, pi, pi, pi]
+        l.mh_model_tile_layout.argtypes = [vp, pi, pi, pi]
         l.mh_model_image.argtypes = [vp, i32, vp, sz, psz]
         l.mh_model_free.argtypes = [vp]
         l.mh_model_free.restype = None
@@ -256,6 +257,12 @@ class Model:
         a, b, c = C.c_int(), C.c_int(), C.c_int()
         _check(lib().mh_model_decode_layout(self._h, C.byref(a), C.byref(b), C.byref(c)), "mh_model_decode_layout")
         return a.value, b.value, bool(c.value)
+
+    def tile_layout(self):
+        """(primary_bits, secondary_bits, secondary_entries) of the tile decoder's tables; primary_bits 0 = none."""
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        _check(lib().mh_model_tile_layout(self._h, C.byref(a), C.byref(b), C.byref(c)), "mh_model_tile_layout")
+        return a.value, b.value, c.value
 
     def image(self, which):
         """Device image `which` (see mh.h: 0 enc16 ... 7 walk tree) as bytes."""

@@ -1059,6 +1059,15 @@ int mh_model_decode_layout(const mh_model *m, int *primary_bits, int *secondary_
     return MH_OK;
 }
 
+int mh_model_tile_layout(const mh_model *m, int *primary_bits, int *secondary_bits, int *secondary_entries) {
+    if (!m || !primary_bits || !secondary_bits || !secondary_entries) return MH_ERR_ARG;
+    const bool o2 = m->type == 2;
+    *primary_bits = o2 ? (m->o2_dec_ok ? int(m->o2_p) : 0) : m->tile_p;
+    *secondary_bits = o2 ? int(m->o2_h) : m->tile_h;
+    *secondary_entries = o2 ? int(m->o2_nsec) : int(m->tile_nsec);
+    return MH_OK;
+}
+
 int mh_model_image(const mh_model *m, int which, void *out, size_t cap, size_t *bytes) {
     if (!m || !bytes) return MH_ERR_ARG;
     if (!m->d_len8) return MH_ERR_NO_DEVICE;
