@@ -397,7 +397,9 @@ int mh_dev_build_index_fine(const mh_model *m, const uint8_t *d_payload, uint64_
 int mh_dev_index_path(const void *d_ws, void *stream);
 /* Diagnostic: which encoder the last mh_dev_encode* call on this workspace ran — 1 the region encoder (priced from a
  * histogram of the input, one read), 3 the same with its escape variant launched too (model with codes over 12
- * bits), 2 the length pass + emit pair (order-2 models, inputs under 4 MiB without a histogram).  Synchronises. */
+ * bits), 2 the length pass + emit pair (inputs under 4 MiB without a histogram; order-2 models whose live contexts
+ * do not fit the LDS image, or MH_ENCODE2_PATH=two_pass), 4 the one-pass order-2 encoder (enc_chain_kernel: every
+ * symbol looked up once, start bits by a chained scan over groups of wave-tiles).  Synchronises. */
 int mh_dev_encode_path(const void *d_ws, void *stream);
 /* Synchronises `stream` and returns the device-side status word of a workspace (MH_OK, MH_ERR_CORRUPT,
  * MH_ERR_TIMEOUT, MH_ERR_CAPACITY). */

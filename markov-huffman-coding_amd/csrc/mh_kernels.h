@@ -170,7 +170,7 @@ struct IdxParams {
     uint64_t fine_cap;            // entries available at `fine`
 };
 // which encoder a launch_encode* call used (its workspace's status block, bytes 8..11)
-enum { ENC_PATH_NONE = 0, ENC_PATH_REGIONS = 1, ENC_PATH_LENGTH_PASS = 2, ENC_PATH_REGIONS_ESCAPES = 3 };
+enum { ENC_PATH_NONE = 0, ENC_PATH_REGIONS = 1, ENC_PATH_LENGTH_PASS = 2, ENC_PATH_REGIONS_ESCAPES = 3, ENC_PATH_CHAIN = 4 };
 // how launch_build_index arrived at the index (status block bytes 8..11)
 enum { IDX_PATH_NONE = 0, IDX_PATH_SEGMENTS = 1, IDX_PATH_GROUP_MAPS = 2, IDX_PATH_STATE_MAPS = 3, IDX_PATH_WALK = 4 };
 

@@ -16,6 +16,7 @@
 #include <stdint.h>
 
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <type_traits>
 
@@ -387,6 +388,23 @@ __device__ __forceinline__ void o2hot_lookup16(const unsigned char *img, const u
     for (int j = 0; j < 16; ++j) e[j] = hot[(cs[j] << 6) | (id[j + 2] ^ id[j + 1])];
 }
 
+// eight symbols (two dwords) — enc_chain_kernel holds a whole wave-tile's results in registers and has no room for sixteen in flight
+__device__ __forceinline__ void o2hot_lookup8(const unsigned char *img, uint32_t xa, uint32_t xb, uint32_t ctx, uint32_t (&e)[8]) {
+    const uint16_t *ctxmap = reinterpret_cast<const uint16_t *>(img + O2H_MAP_OFF);
+    const uint16_t *hot = reinterpret_cast<const uint16_t *>(img + O2H_HOT_OFF);
+    const uint32_t x[2] = {xa, xb};
+    uint32_t id[10];
+    id[0] = img[ctx >> 8];
+    id[1] = img[ctx & 255u];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) id[2 + j] = img[(x[j >> 2] >> (8 * (j & 3))) & 255u];
+    uint32_t cs[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cs[j] = ctxmap[(id[j] << 6) | (id[j + 1] ^ id[j])];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = hot[(cs[j] << 6) | (id[j + 2] ^ id[j + 1])];
+}
+
 // ---- pass 1 ------------------------------------------------------------------------------------
 // ORDER 2: the hot order-2 image in LDS (o2hot_lookup16); lengths of escapes come from p.len_slot = len8[ctx * 256 + sym]
 template <int ORDER>
@@ -559,15 +577,18 @@ __device__ __forceinline__ void deposit(uint32_t *stage, uint64_t vl, uint32_t o
 }
 
 // Stores image words [0, nfull) to output dwords gbase + j (MSB-first bytes), clears them, and moves
-// image word `nfull` (the partial tail) to word 0.  Word 0 goes out with an atomic OR when it is the
-// seam with the previous wave-tile (`seam0`).  Wave-synchronous: LDS ops of one wave execute in order.
+// image word `nfull` (the partial tail) to word 0.  Word 0 is the seam with the previous wave-tile when `seam0` is
+// set: SEAM_OR = it goes out with an atomic OR (both neighbours write their part of a zeroed dword), SEAM_DROP = it is
+// not written at all (enc_chain_kernel: the previous wave-tile writes that dword whole).
+// Wave-synchronous: LDS ops of one wave execute in order.
+constexpr uint32_t SEAM_NONE = 0, SEAM_OR = 1, SEAM_DROP = 2;
 __device__ __forceinline__ void flush_words(uint32_t *stage, uint32_t *out32, uint64_t gbase, uint32_t nfull,
-                                            bool seam0, uint32_t lane) {
+                                            uint32_t seam0, uint32_t lane) {
     const uint32_t tail = stage[nfull];
     for (uint32_t j = lane; j < nfull; j += 64u) {
         uint32_t v = __builtin_bswap32(stage[j]);
         stage[j] = 0;
-        if (j == 0 && seam0) atomicOr(&out32[gbase], v);
+        if (j == 0 && seam0 != SEAM_NONE) { if (seam0 == SEAM_OR) atomicOr(&out32[gbase], v); }
         else out32[gbase + j] = v;
     }
     if (lane == 0) { stage[nfull] = 0; stage[0] = tail; }
@@ -592,7 +613,7 @@ __device__ __forceinline__ void fine2_entry(const EmitParams &p, uint32_t S, uin
 template <int ORDER>
 __device__ __forceinline__ void emit_substep_slow(const EmitParams &p, const uint16_t *tab, uint32_t *stage, uint32_t *out32,
                                                   uint4 x, uint32_t pb, uint32_t nvalid, uint32_t lane, uint64_t off,
-                                                  uint64_t abs_bits, uint64_t &gbase, uint32_t &cur, bool &seam0,
+                                                  uint64_t abs_bits, uint64_t &gbase, uint32_t &cur, uint32_t &seam0,
                                                   uint32_t &sub_bits_out) {
     // opaque to the optimiser, so that nothing of the hot path is kept alive for this rare branch
     asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w), "+v"(pb));
@@ -666,7 +687,7 @@ __device__ __forceinline__ void emit_substep_slow(const EmitParams &p, const uin
         const bool more = nfull > nwords - 1u;
         if (more) nfull = nwords - 1u;        // keep one word as the moving tail
         flush_words(stage, out32, gbase, nfull, seam0, lane);
-        seam0 = seam0 && nfull == 0;
+        if (nfull) seam0 = SEAM_NONE;
         gbase += nfull;
         wbase += nfull;
         if (!more) break;
@@ -725,7 +746,7 @@ __global__ __launch_bounds__(E_THREADS) void enc_emit_kernel(EmitParams p) {
     lookup16(cur_in, cur_pb, E);
     uint64_t gbase = 0, abs_bits = 0;
     uint32_t cur = 0;
-    bool seam0 = false;
+    uint32_t seam0 = SEAM_NONE;
 #pragma unroll 1
     for (uint64_t i = 0;; ++i) {
         const uint64_t wt = wave0 + (i >> 2) * nwaves;
@@ -736,7 +757,7 @@ __global__ __launch_bounds__(E_THREADS) void enc_emit_kernel(EmitParams p) {
             gbase = s >> 5;                      // output dword under image word 0
             cur = uint32_t(s & 31u);             // image bit where the next code goes
             abs_bits = s;                        // absolute bit offset of image bit `cur`
-            seam0 = cur != 0;                    // word 0 is shared with the previous wave-tile
+            seam0 = cur != 0 ? SEAM_OR : SEAM_NONE;   // word 0 is shared with the previous wave-tile
         }
         const uint64_t off = wt * E_WT + uint64_t(k) * E_SUB + lane * E_VEC;
         // the next sub-steps: input three ahead (its first use, the lookups, comes two sub-steps from now), lookups one ahead
@@ -789,7 +810,7 @@ __global__ __launch_bounds__(E_THREADS) void enc_emit_kernel(EmitParams p) {
             }
             const uint32_t nfull = (cur + sub_bits) >> 5;
             flush_words(stage, out32, gbase, nfull, seam0, lane);
-            seam0 = seam0 && nfull == 0;
+            if (nfull) seam0 = SEAM_NONE;
             gbase += nfull;
             cur = (cur + sub_bits) & 31u;
         }
@@ -804,6 +825,290 @@ __global__ __launch_bounds__(E_THREADS) void enc_emit_kernel(EmitParams p) {
         next2_in = in3;
 #pragma unroll
         for (int j = 0; j < 16; ++j) E[j] = En[j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ORDER 2 in ONE pass: a chained scan over the wave-tiles
+// ------------------------------------------------------------------------------------------------
+// The length pass + emit pair looks every symbol up twice (three dependent LDS gathers per symbol each time: byte
+// ids, context slot, codeword), and the lookups are what both kernels spend their time on.  Here a wave looks its
+// 4 KiB wave-tile up ONCE, keeps the packed codeword groups in registers (rotating through four held sets so that the
+// loops over the sub-steps stay rolled), and the start bits come from a chained scan in the manner of Merrill &
+// Garland's decoupled look-back: a state word per GROUP of 16 wave-tiles (one round of one workgroup) is empty, then
+// AGGREGATE | the group's bits, then PREFIX | bits up to and including it; a look-back adds aggregates down to the
+// nearest prefix.  Groups are dealt round-robin over a grid of at most one workgroup per CU, all of which are resident
+// at once (1024 threads and > 64 KiB of LDS each), so every group a look-back can wait for belongs to a workgroup that
+// is running; the wait is bounded anyway (CH_SPIN_MAX polls, then MHK_STATUS_TIMEOUT, a bogus prefix so that nobody
+// else hangs, and the wave leaves).  The launcher keeps to the length pass + emit pair when a CU mask is set in the
+// environment, the one case in which fewer CUs than the device reports would be there for the grid.
+// (A ticket counter handing the groups out in order costs a same-address atomic and two barriers per round: 6.8 ms
+// for 4 GiB of text against 5.65; four rounds per ticket ran the launch in sequence, 938 ms — the first tiles of a
+// ticket wait for the aggregates of the previous ticket's LAST round.)
+// No dword of the output has two writers, so nothing needs zeroing and no global atomic is spent on seams: the dword
+// that holds a tile's last bits is written by THAT tile, which encodes the next few symbols of the input itself to
+// fill it (at most 31 bits, codes have at least one bit), and a tile never writes the part of its first dword that
+// lies before its first dword boundary (SEAM_DROP) — tile 0 excepted, which starts the stream.
+struct ChainParams {
+    EmitParams e;                            // (wt_start unused)
+    unsigned long long *state;               // one word per group of E_WAVES wave-tiles, zeroed
+    const unsigned long long *start_bit;     // nullptr or the global bit position the payload starts at (low 3 bits used)
+    uint64_t cap;                            // bytes, a multiple of 4
+    unsigned long long *nbits;
+    int *status;
+    uint32_t probe;
+};
+constexpr unsigned long long CH_AGG = 1ull << 62, CH_PFX = 2ull << 62, CH_VAL = (1ull << 62) - 1ull;
+constexpr uint32_t CH_SPIN_MAX = 1u << 20;                   // polls of one wait (~ a second) before giving up
+
+// bits of all tiles before `tile` (tile >= 1); false: gave up waiting
+__device__ __forceinline__ bool chain_lookback(const unsigned long long *state, uint64_t tile, uint32_t lane, uint64_t &excl) {
+    uint64_t sum = 0;
+    long long top = (long long)tile - 1;                      // nearest tile not yet accounted for
+    uint32_t spins = 0;
+    while (top >= 0) {
+        const long long my = top - (long long)lane;
+        unsigned long long st = CH_PFX;                       // in front of tile 0: an inclusive prefix of zero
+        if (my >= 0) st = __hip_atomic_load(&state[my], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t flag = uint32_t(st >> 62);
+        const unsigned long long pfx = __ballot(flag == 2u), emp = __ballot(flag == 0u);
+        const uint32_t fp = pfx ? uint32_t(__builtin_ctzll(pfx)) : 64u;     // nearest lane that holds an inclusive prefix
+        const unsigned long long need = fp >= 63u ? ~0ull : ((2ull << fp) - 1ull);   // lanes 0 .. fp
+        if (emp & need) {                                     // a tile in reach has not published anything yet
+            if (++spins > CH_SPIN_MAX) return false;
+            __builtin_amdgcn_s_sleep(2);
+            continue;
+        }
+        uint64_t v = lane <= fp ? (st & CH_VAL) : 0ull;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+        sum += v;
+        if (fp < 64u) break;
+        top -= 64;
+    }
+    excl = sum;
+    return true;
+}
+
+// one symbol through the hot image; escapes (and anything the image does not hold) through the full tables
+__device__ __forceinline__ void o2_code_of(const EmitParams &p, const unsigned char *img, uint32_t b2, uint32_t b1, uint32_t sym,
+                                           uint32_t &l, uint64_t &c) {
+    const uint16_t *ctxmap = reinterpret_cast<const uint16_t *>(img + O2H_MAP_OFF);
+    const uint16_t *hot = reinterpret_cast<const uint16_t *>(img + O2H_HOT_OFF);
+    const uint32_t i2 = img[b2], i1 = img[b1], i0 = img[sym];
+    const uint32_t cs = ctxmap[(i2 << 6) | (i1 ^ i2)];
+    const uint32_t e = hot[(cs << 6) | (i0 ^ i1)];
+    l = e >> 12;
+    c = e & 0xFFFu;
+    if (e >= 0xD000u) {
+        const uint32_t key = (b2 << 16) | (b1 << 8) | sym;
+        l = p.len8[key];
+        c = p.code64[key];
+        if (l > 64u) { l = 0; c = 0; }
+    }
+}
+
+__global__ __launch_bounds__(E_THREADS) void enc_chain_kernel(ChainParams cp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned long long s_tile[2][E_WAVES], s_base[2];
+    __shared__ uint32_t s_done[2], s_tag[2], s_bad[2];
+    const EmitParams &p = cp.e;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t tab_bytes = (p.o2hot_bytes + 15u) & ~15u;
+    uint32_t *stage = reinterpret_cast<uint32_t *>(smem + tab_bytes) + wave * E_STAGE_WORDS;
+    if (threadIdx.x < 2) { s_done[threadIdx.x] = 0; s_tag[threadIdx.x] = 0; }
+    for (uint32_t i = threadIdx.x; i < tab_bytes / 16u; i += E_THREADS)
+        reinterpret_cast<uint4 *>(smem)[i] = reinterpret_cast<const uint4 *>(p.o2hot)[i];
+    for (int i = lane; i < E_STAGE_WORDS; i += 64) stage[i] = 0;
+    uint32_t *out32 = reinterpret_cast<uint32_t *>(p.out);
+    const uint32_t S = 1u << p.chunk_shift;
+    const uint64_t cap_bits = cp.cap * 8;
+    const uint64_t carry = cp.start_bit ? (*cp.start_bit & 7ull) : 0ull;
+    __syncthreads();
+    const uint64_t stride = uint64_t(gridDim.x) * E_WAVES;
+    uint64_t wt = uint64_t(blockIdx.x) * E_WAVES + wave;      // neighbouring tiles run side by side
+    LaneIn ahead = load_raw2(p.data, p.n, wt * E_WT + lane * E_VEC, p.prev0);   // (past the end: zeros, nothing read)
+#pragma unroll 1
+    for (uint32_t round = 0; wt - wave < p.nwt; wt += stride, ++round) {       // (every wave of the workgroup takes part in every group)
+        const uint64_t wt_next = wt + stride;
+        const uint32_t par = round & 1u;
+        const uint64_t group = uint64_t(round) * gridDim.x + blockIdx.x;
+        struct Held { uint64_t g[4]; uint32_t gl, pb; };      // gl: the four group lengths, a byte each (escape sub-step: the lane's bits)
+        Held h0{}, h1{}, h2{}, h3{};
+        uint32_t escmask = 0;
+        uint64_t s = carry, tile_bits = 0;
+        bool emit = false;
+        if (wt < p.nwt) {
+            // ---- everything looked up once: per sub-step four packed groups of four codes, their lengths, the lane's bits.
+            // (Both loops over the sub-steps stay rolled — the slow path is inlined once, the registers hold one sub-step's
+            // working set beside the four held ones — so the held sets rotate: slot 0 is the oldest.)
+            uint32_t lane_bits = 0;
+#pragma unroll 1
+            for (int k = 0; k < E_SUBSTEPS; ++k) {
+                const LaneIn in = ahead;
+                if (k + 1 < E_SUBSTEPS) ahead = load_raw2(p.data, p.n, wt * E_WT + uint64_t(k + 1) * E_SUB + lane * E_VEC, p.prev0);
+                const uint32_t pb = head_ctx(in);
+                h0 = h1; h1 = h2; h2 = h3;
+                uint32_t L = 0, glk = 0;
+                uint32_t emax = in.nvalid == E_VEC ? 0u : 0xFFFFu;     // ragged vectors take the symbol-by-symbol path
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    uint32_t E[8];
+                    const uint32_t c8 = half == 0 ? pb : (((in.x.y >> 16) & 255u) << 8) | (in.x.y >> 24);
+                    o2hot_lookup8(smem, half == 0 ? in.x.x : in.x.z, half == 0 ? in.x.y : in.x.w, c8, E);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const uint32_t e0 = E[4 * q], e1 = E[4 * q + 1], e2 = E[4 * q + 2], e3 = E[4 * q + 3];
+                        uint32_t m01 = e0 > e1 ? e0 : e1, m23 = e2 > e3 ? e2 : e3;
+                        m01 = m01 > m23 ? m01 : m23;
+                        emax = m01 > emax ? m01 : emax;
+                        const uint32_t l0 = e0 >> 12, l1 = e1 >> 12, l2 = e2 >> 12, l3 = e3 >> 12;
+                        const uint32_t p01 = ((e0 & 0xFFFu) << l1) | (e1 & 0xFFFu);
+                        const uint32_t p23 = ((e2 & 0xFFFu) << l3) | (e3 & 0xFFFu);
+                        h3.g[2 * half + q] = (uint64_t(p01) << (l2 + l3)) | p23;
+                        const uint32_t glq = l0 + l1 + l2 + l3;
+                        glk |= glq << (8 * (2 * half + q));
+                        L += glq;
+                    }
+                }
+                if (__any(emax >= 0xD000u)) {                  // wave-uniform: the lengths symbol by symbol, escapes from the full table
+                    escmask |= 1u << k;
+                    uint4 x = in.x;                              // rolled, one symbol at a time: rare, and the registers are taken
+                    uint32_t ctx = pb;
+                    L = 0;
+#pragma unroll 1
+                    for (uint32_t j = 0; j < 16; ++j) {
+                        const uint32_t sym = x.x & 255u;
+                        x.x = __builtin_amdgcn_alignbyte(x.y, x.x, 1);
+                        x.y = __builtin_amdgcn_alignbyte(x.z, x.y, 1);
+                        x.z = __builtin_amdgcn_alignbyte(x.w, x.z, 1);
+                        x.w >>= 8;
+                        uint32_t l = 0;
+                        uint64_t c;
+                        if (j < in.nvalid) o2_code_of(p, smem, ctx >> 8, ctx & 255u, sym, l, c);
+                        L += l;
+                        ctx = ((ctx << 8) | sym) & 0xFFFFu;
+                    }
+                }
+                h3.gl = ((escmask >> k) & 1u) ? L : glk; h3.pb = pb;
+                lane_bits += L;
+            }
+            tile_bits = wave_sum(lane_bits);
+        }
+        // ---- the tile's place in the stream.  The 16 tiles of the workgroup are one GROUP in the chained scan (sixteen times
+        // fewer state words in memory, and the look-backs stay short: at most 256 groups are in flight).  The waves leave their
+        // bit counts in LDS; the last one to arrive adds them up, publishes the group's aggregate, looks back over the groups
+        // before it and leaves the group's start bit in LDS for the others, who poll LDS, not memory.  Nobody passes a round
+        // before its last wave has arrived, so a wave is at most one round ahead of another: two sets of slots.
+        // (Measured, 4 GiB of text: one state word per wave-tile 6.2 ms; this 5.65 ms; the first wave to arrive looking back
+        // while the others are still looking up 5.9 ms; no look-back at all, wrong output, 5.15 ms.)
+        bool waited_out = false;
+        {
+            const uint32_t tag = round + 1u;
+            uint32_t arrived = 0;
+            if (lane == 0) {
+                s_tile[par][wave] = tile_bits;
+                arrived = __hip_atomic_fetch_add(&s_done[par], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            arrived = uint32_t(__builtin_amdgcn_readfirstlane(int(arrived)));
+            if (arrived == uint32_t(E_WAVES) - 1u) {
+                uint64_t total = lane < uint32_t(E_WAVES) ? s_tile[par][lane] : 0ull;
+#pragma unroll
+                for (int d = 8; d >= 1; d >>= 1) total += __shfl_xor(total, d);
+                total = __shfl(total, 0);
+                uint64_t base = carry;
+                bool bad = false;
+                if (group != 0) {
+                    if (lane == 0) __hip_atomic_store(&cp.state[group], CH_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (cp.probe) base = group * 320000ull; else
+                    bad = !chain_lookback(cp.state, group, lane, base);      // (group 0's prefix carries the start offset)
+                }
+                if (lane == 0) {
+                    const uint64_t gend = base + total;
+                    __hip_atomic_store(&cp.state[group], CH_PFX | (gend & CH_VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((group + 1) * E_WAVES >= p.nwt) *cp.nbits = gend;
+                    if (bad) atomicExch(cp.status, MHK_STATUS_TIMEOUT);
+                    s_done[par] = 0;
+                    s_base[par] = base;
+                    s_bad[par] = bad ? 1u : 0u;
+                    __hip_atomic_store(&s_tag[par], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            uint32_t spins = 0;
+            while (__hip_atomic_load(&s_tag[par], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != tag) {
+                if (++spins > CH_SPIN_MAX) { waited_out = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            uint64_t mine = lane < wave ? s_tile[par][lane] : 0ull;          // the tiles of the group before this wave's
+#pragma unroll
+            for (int d = 8; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+            s = s_base[par] + __shfl(mine, 0);
+            if (s_bad[par]) waited_out = true;
+        }
+        if (wt < p.nwt) {
+            const uint64_t end = s + tile_bits;
+            if (lane == 0 && !waited_out && end > cap_bits) atomicExch(cp.status, MHK_STATUS_CAPACITY);
+            emit = !(waited_out || end > cap_bits);            // (wave-uniform) else nothing of this tile is written
+        }
+        if (waited_out) break;                                 // (the others of the workgroup run into their own bound)
+        ahead = load_raw2(p.data, p.n, wt_next * E_WT + lane * E_VEC, p.prev0);   // the next round's first vectors (past the end: zeros)
+        if (emit) {
+            // ---- emit from the registers
+            uint64_t gbase = s >> 5;                             // output dword under image word 0
+            uint32_t cur = uint32_t(s & 31u);                    // image bit where the next code goes
+            uint64_t abs_bits = s;
+            uint32_t seam0 = (cur != 0 && wt != 0) ? SEAM_DROP : SEAM_NONE;   // the tile before this one writes that dword
+#pragma unroll 1
+            for (int k = 0; k < E_SUBSTEPS; ++k) {
+                const uint64_t off = wt * E_WT + uint64_t(k) * E_SUB + lane * E_VEC;
+                const uint32_t nvalid = off + E_VEC <= p.n ? uint32_t(E_VEC) : off < p.n ? uint32_t(p.n - off) : 0u;
+                uint32_t sub_bits;
+                if ((escmask >> k) & 1u) {
+                    const LaneIn again = load_raw2(p.data, p.n, off, p.prev0);   // (kept out of the registers: rare)
+                    emit_substep_slow<2>(p, nullptr, stage, out32, again.x, h0.pb, nvalid, lane, off, abs_bits, gbase, cur, seam0, sub_bits);
+                } else {
+                    const uint32_t L = (h0.gl & 255u) + ((h0.gl >> 8) & 255u) + ((h0.gl >> 16) & 255u) + (h0.gl >> 24);
+                    const uint32_t inc = wave_inclusive_sum(L);
+                    sub_bits = __builtin_amdgcn_readlane(inc, 63);
+                    const uint32_t exc = inc - L;
+                    if (p.index && nvalid && ((uint32_t(off) & (S - 1u)) == 0u))
+                        p.index[off >> p.chunk_shift] = (uint64_t(h0.pb) << 48) | (abs_bits + exc);
+                    fine2_entry(p, S, lane, off, nvalid, h0.pb, exc);
+                    uint32_t o = cur + exc;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t glq = (h0.gl >> (8 * q)) & 255u;
+                        if (glq) deposit<false>(stage, h0.g[q] << (64u - glq), o, 0, 0);
+                        o += glq;
+                    }
+                    const uint32_t nfull = (cur + sub_bits) >> 5;
+                    flush_words(stage, out32, gbase, nfull, seam0, lane);
+                    if (nfull) seam0 = SEAM_NONE;
+                    gbase += nfull;
+                    cur = (cur + sub_bits) & 31u;
+                }
+                abs_bits += sub_bits;
+                h0 = h1; h1 = h2; h2 = h3;
+            }
+            // ---- the tile's last, partial dword
+            if (cur != 0 && seam0 == SEAM_NONE) {               // this tile's to write: filled up with the first bits of what follows
+                const uint64_t next = (wt + 1) * uint64_t(E_WT);   // (a ragged tile is the last one: nothing follows)
+                const uint64_t pos = next + lane;
+                const bool valid = lane < 32u && pos < p.n;
+                uint32_t l = 0;
+                uint64_t c = 0;
+                if (valid) o2_code_of(p, smem, p.data[pos - 2], p.data[pos - 1], p.data[pos], l, c);
+                const uint32_t inc = wave_inclusive_sum(l);
+                const uint32_t exc = inc - l;
+                if (l && exc < 32u - cur) deposit<true>(stage, c << (64u - l), cur + exc, 0u, 1u);
+                if (lane == 0) {
+                    out32[gbase] = __builtin_bswap32(stage[0]);
+                    stage[0] = 0;
+                }
+            } else if (cur != 0 && lane == 0) {                  // the whole tile lies inside a dword of the tile before it
+                stage[0] = 0;
+            }
+        }
     }
 }
 
@@ -2321,7 +2626,7 @@ __global__ __launch_bounds__(E_THREADS) void enc2_emit_kernel(EmitParams p) {
         uint64_t gbase = s >> 5;
         uint32_t cur = uint32_t(s & 31u);
         uint64_t abs_bits = s;
-        bool seam0 = cur != 0;
+        uint32_t seam0 = cur != 0 ? SEAM_OR : SEAM_NONE;
 #pragma unroll 1
         for (int k = 0; k < E_SUBSTEPS; ++k) {
             const uint64_t off = wt * E_WT + uint64_t(k) * E_SUB + lane * E_VEC;
@@ -2375,7 +2680,7 @@ __global__ __launch_bounds__(E_THREADS) void enc2_emit_kernel(EmitParams p) {
                 }
                 const uint32_t nfull = (cur + sub_bits) >> 5;
                 flush_words(stage, out32, gbase, nfull, seam0, lane);
-                seam0 = seam0 && nfull == 0;
+                if (nfull) seam0 = SEAM_NONE;
                 gbase += nfull;
                 cur = (cur + sub_bits) & 31u;
             } else {                                                          // very long codes: fill and flush in rounds
@@ -2459,7 +2764,7 @@ __global__ __launch_bounds__(256) void decode2_kernel(DecParams p) {
 constexpr int MAX_DEVICES = 64;
 struct DeviceState {
     int cu_count = 0;
-    bool hist_ready = false, hist2_ready = false, encode_ready = false, region_ready = false, decode_ready = false, redo_ready = false, index_ready = false;
+    bool hist_ready = false, hist2_ready = false, encode_ready = false, chain_ready = false, region_ready = false, decode_ready = false, redo_ready = false, index_ready = false;
 };
 static DeviceState g_dev[MAX_DEVICES];
 static std::mutex g_dev_mu;
@@ -2642,6 +2947,14 @@ hipError_t launch_payload_bits(const unsigned long long *d_counts, const uint8_t
     return hipGetLastError();
 }
 
+// MH_ENCODE2_PATH=two_pass: order 2 through the length pass + emit pair also when the hot image is there (A/B runs, tests)
+static bool encode2_two_pass() {
+    const char *v = getenv("MH_ENCODE2_PATH");
+    if (v && !strcmp(v, "two_pass")) return true;
+    // a CU mask leaves fewer CUs than the device reports: the chained scan's grid might not be resident all at once
+    return getenv("HSA_CU_MASK") || getenv("ROC_GLOBAL_CU_MASK") || getenv("HSA_CU_MASK_SKIP_INIT");
+}
+
 hipError_t launch_encode(const EncodeArgs &a, void *d_ws, hipStream_t st) {
     unsigned char *ws = static_cast<unsigned char *>(d_ws);
     const EncWs L = enc_ws_layout(a.n);
@@ -2668,6 +2981,26 @@ hipError_t launch_encode(const EncodeArgs &a, void *d_ws, hipStream_t st) {
     uint64_t want = (L.nwt + E_WAVES - 1) / E_WAVES;
     int grid = int(want > uint64_t(2 * cu_count()) ? uint64_t(2 * cu_count()) : want);
     const bool hot2 = a.order == 2 && a.o2hot && a.o2hot_bytes && a.o2hot_bytes <= uint32_t(LEN_LDS_BYTES);
+    if (hot2 && !encode2_two_pass()) {                       // one pass: enc_chain_kernel (all its workgroups resident at once)
+        e = once_per_device(&DeviceState::chain_ready, [] { return allow_lds(reinterpret_cast<const void *>(enc_chain_kernel), EMIT_LDS_BYTES); });
+        if (e != hipSuccess) return e;
+        const uint64_t groups = (L.nwt + E_WAVES - 1) / E_WAVES;
+        e = hipMemsetAsync(wt_start, 0, size_t(groups) * 8, st);            // the groups' state words
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<uint32_t *>(ws + 8), uint32_t(ENC_PATH_CHAIN));
+        ChainParams cp;
+        cp.e = EmitParams{a.data, a.n, a.prev0, a.chunk_shift, a.out, a.enc16, a.len8, a.code64, a.enc64, nullptr, L.nwt, a.index, status,
+                          a.fine, a.o2hot, a.o2hot_bytes};
+        cp.state = wt_start;
+        cp.start_bit = a.start_bit;
+        cp.cap = a.cap & ~uint64_t(3);                                       // whole dwords are stored
+        cp.nbits = a.nbits;
+        cp.status = status;
+        cp.probe = getenv("MH_CHAIN_PROBE") ? 1u : 0u;                       // (diagnostic: no look-back, output wrong)
+        const int cgrid = int(groups > uint64_t(cu_count()) ? uint64_t(cu_count()) : groups);
+        hipLaunchKernelGGL(enc_chain_kernel, dim3(cgrid), dim3(E_THREADS), ((a.o2hot_bytes + 15u) & ~15u) + E_WAVES * E_STAGE_WORDS * 4, st, cp);
+        return hipGetLastError();
+    }
     if (hot2) {                                              // the live contexts' tables in LDS (o2hot_lookup16)
         LenParams lp{a.data, a.n, a.prev0, a.len8, wt_bits, L.nwt, a.o2hot, a.o2hot_bytes};
         hipLaunchKernelGGL(enc_len_kernel<2>, dim3(grid), dim3(E_THREADS), (a.o2hot_bytes + 15u) & ~15u, st, lp);
