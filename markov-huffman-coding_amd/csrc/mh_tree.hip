@@ -86,6 +86,11 @@ struct RegHeap {
             klo[9] = wl(lo, 0, klo[9]); if (K64) khi[9] = wl(hi, 0, khi[9]); itm[9] = wl(it, 0, itm[9]);
         }
     }
+    // [r3] A compact variant was measured against this one: four register sets of 64 slots (children always side by side
+    // in one set), sifts as rolled loops, every write one asm statement that branches inside so that no join sees a
+    // register modified on one path only — 4 400 instructions of kernel instead of 16 000, all tests green, and 1.1 ms per
+    // launch instead of 0.74.  The time is the length of the dependent scalar chain (~250 instructions per heap operation
+    // either way, one wave per CU, nothing to hide behind), not the code size; the unrolled form below stays.
     // Both sifts are written as a read-only phase that follows the whole path with scalar selects, and a
     // write phase that stores ONE entry per level unconditionally — the moved entry, the sifted key, or
     // what the slot held anyway.  (Branches with early exits made the compiler copy all thirty heap registers
