@@ -1160,6 +1160,10 @@ static int dev_encode_hist(const mh_model *m, const uint8_t *d_data, size_t n, u
 
 // ctx0: the context before the first byte — the previous byte (orders 0/1) or, for an order-2 model,
 // (byte before previous) << 8 | previous byte
+// set around a retry: the one-pass order-2 encoder gave up waiting (its workgroups were not all resident: a device shared
+// with a long-running kernel of somebody else), the host-side callers that synchronise anyway run the two-pass pair instead
+static thread_local bool t_no_chain = false;
+
 static int dev_encode_ctx(const mh_model *m, const uint8_t *d_data, size_t n, uint32_t ctx0, const uint64_t *d_start_bit,
                           uint8_t *d_payload, size_t cap, uint64_t *d_nbits, uint64_t *d_index, uint32_t chunk_symbols,
                           void *d_ws, size_t ws_bytes, void *stream, uint32_t *d_fine) {
@@ -1190,6 +1194,7 @@ static int dev_encode_ctx(const mh_model *m, const uint8_t *d_data, size_t n, ui
     p.start_bit = reinterpret_cast<const unsigned long long *>(d_start_bit);
     p.fine = d_fine;
     if (m->type == 2 && m->o2_enc_ok) { p.o2hot = m->d_o2img; p.o2hot_bytes = m->o2img_bytes; }
+    p.no_chain = t_no_chain;
     HIP_TRY(mhk::launch_encode(p, d_ws, static_cast<hipStream_t>(stream)));
     return MH_OK;
 }
@@ -1579,6 +1584,13 @@ int mh_encode(const mh_model *m, const uint8_t *data, size_t n, uint8_t prev0, u
                                 d_nbits.as<uint64_t>(), index ? d_index.as<uint64_t>() : nullptr, chunk_symbols, d_ws.p, wsb, st, nullptr);
         if (rc != MH_OK) return rc;
         rc = mh_dev_status(d_ws.p, st);
+        if (rc == MH_ERR_TIMEOUT && !t_no_chain) {               // (see t_no_chain)
+            t_no_chain = true;
+            rc = dev_encode_ctx(m, d_seg, len, c0, d_start.as<uint64_t>(), d_out.as<uint8_t>(), dcap,
+                                d_nbits.as<uint64_t>(), index ? d_index.as<uint64_t>() : nullptr, chunk_symbols, d_ws.p, wsb, st, nullptr);
+            t_no_chain = false;
+            if (rc == MH_OK) rc = mh_dev_status(d_ws.p, st);
+        }
         if (rc != MH_OK) return rc;
         uint64_t end = 0;                                        // end position inside the segment's buffer
         HIP_TRY(hipMemcpy(&end, d_nbits.p, 8, hipMemcpyDeviceToHost));

@@ -31,6 +31,7 @@ struct EncodeArgs {
     int max_len;                  // the model's longest code (the region encoder launches its escape variant only above 12)
     const uint8_t *o2hot;         // order 2, optional: the live contexts' tables for LDS (mh_kernels.hip, o2hot_lookup16)
     uint32_t o2hot_bytes;
+    bool no_chain;                // order 2: the length pass + emit pair even where the one-pass encoder would run
 };
 
 struct LenParams {

@@ -1020,8 +1020,9 @@ __global__ __launch_bounds__(E_THREADS) void enc_chain_kernel(ChainParams cp) {
                 bool bad = false;
                 if (group != 0) {
                     if (lane == 0) __hip_atomic_store(&cp.state[group], CH_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (cp.probe) base = group * 320000ull; else
-                    bad = !chain_lookback(cp.state, group, lane, base);      // (group 0's prefix carries the start offset)
+                    if (cp.probe == 2u) bad = true;                            // (test hook: as if the wait had run out)
+                    else if (cp.probe) base = group * 320000ull;
+                    else bad = !chain_lookback(cp.state, group, lane, base);  // (group 0's prefix carries the start offset)
                 }
                 if (lane == 0) {
                     const uint64_t gend = base + total;
@@ -2981,7 +2982,7 @@ hipError_t launch_encode(const EncodeArgs &a, void *d_ws, hipStream_t st) {
     uint64_t want = (L.nwt + E_WAVES - 1) / E_WAVES;
     int grid = int(want > uint64_t(2 * cu_count()) ? uint64_t(2 * cu_count()) : want);
     const bool hot2 = a.order == 2 && a.o2hot && a.o2hot_bytes && a.o2hot_bytes <= uint32_t(LEN_LDS_BYTES);
-    if (hot2 && !encode2_two_pass()) {                       // one pass: enc_chain_kernel (all its workgroups resident at once)
+    if (hot2 && !a.no_chain && !encode2_two_pass()) {                       // one pass: enc_chain_kernel (all its workgroups resident at once)
         e = once_per_device(&DeviceState::chain_ready, [] { return allow_lds(reinterpret_cast<const void *>(enc_chain_kernel), EMIT_LDS_BYTES); });
         if (e != hipSuccess) return e;
         const uint64_t groups = (L.nwt + E_WAVES - 1) / E_WAVES;
@@ -2996,7 +2997,8 @@ hipError_t launch_encode(const EncodeArgs &a, void *d_ws, hipStream_t st) {
         cp.cap = a.cap & ~uint64_t(3);                                       // whole dwords are stored
         cp.nbits = a.nbits;
         cp.status = status;
-        cp.probe = getenv("MH_CHAIN_PROBE") ? 1u : 0u;                       // (diagnostic: no look-back, output wrong)
+        const char *probe = getenv("MH_CHAIN_PROBE");                        // diagnostics: "timeout" = report MHK_STATUS_TIMEOUT as if a
+        cp.probe = !probe ? 0u : !strcmp(probe, "timeout") ? 2u : 1u;        // wait had run out; anything else = no look-back, output wrong
         const int cgrid = int(groups > uint64_t(cu_count()) ? uint64_t(cu_count()) : groups);
         hipLaunchKernelGGL(enc_chain_kernel, dim3(cgrid), dim3(E_THREADS), ((a.o2hot_bytes + 15u) & ~15u) + E_WAVES * E_STAGE_WORDS * 4, st, cp);
         return hipGetLastError();

@@ -148,3 +148,18 @@ def test_chain_encoder_one_bit_codes_parity_unpinned(mhc, oracle):
     ref, ref_bits = oracle.Model.from_data(data.tobytes(), 2).compress(data.tobytes())
     a = encode(mhc, m, data)
     assert (a[1], a[2][:(a[1] + 7) // 8].tobytes()) == (ref_bits, ref[1:])
+
+
+def test_chain_encoder_giving_up_is_reported_and_the_host_path_retries_parity_unpinned(mhc, oracle, text_model):
+    """The one-pass encoder's waits are bounded; when one runs out (forced here) the workspace says MH_ERR_TIMEOUT, and
+    mh_encode*, which synchronises anyway, runs the two-pass pair instead."""
+    data = text_like(4096 * 40 + 5, 21)
+    os.environ["MH_CHAIN_PROBE"] = "timeout"
+    try:
+        rc, _, _, _, _, path = encode(mhc, text_model, data)
+        assert rc == mhc.MH_ERR_TIMEOUT and path == ENC_CHAIN
+        blob, nbits, idx = text_model.compress(data.tobytes(), chunk_symbols=256)
+    finally:
+        del os.environ["MH_CHAIN_PROBE"]
+    ref, ref_bits = oracle.Model.from_table(text_model.table_bytes()).compress(data.tobytes())
+    assert (nbits, blob) == (ref_bits, ref)
