@@ -185,8 +185,13 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_o1_kernel(const uint8_t *__
                 old[i] = atomicAdd(&h[slot[i]], inc[i]);
             }
         }
+        // newly |= (old + inc) ^ old, as one add and one three-input bit operation per symbol (left to itself the compiler
+        // keeps all sixteen differences and ORs them three at a time: half an instruction more per symbol, sixteen registers)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) newly |= (old[i] + inc[i]) ^ old[i];
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t sum = old[i] + inc[i];
+            asm("v_bitop3_b32 %0, %1, %2, %0 bitop3:0xbe" : "+v"(newly) : "v"(sum), "v"(old[i]));
+        }
         if (newly & CROSS) {                                     // some add of this lane crossed a multiple of 0x4000
 #pragma unroll
             for (int i = 0; i < 16; ++i)
