@@ -287,12 +287,21 @@ def main():
         local = int(os.environ["MH_BENCH_DEVICE"])
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    # MH_BENCH_DIST1=1 (rehearsal on the one-GPU box): a single rank goes through the whole N > 1 path — process group,
+    # every collective on the real backend (RCCL), pre-shifted encode — so that its calls have run once before the
+    # driver's multi-GPU bench
+    multi = world > 1 or os.environ.get("MH_BENCH_DIST1") == "1"
+    if multi and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if multi:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group("gloo")
-    staged = world > 1 and args.backend == "gloo"
+    staged = multi and args.backend == "gloo"
 
     def all_reduce(t, op=dist.ReduceOp.SUM):
         if staged:
@@ -338,7 +347,7 @@ def main():
     # context of each shard's first byte = last byte of the previous shard (' ' for rank 0)
     # (order 2: the last TWO bytes; prev0 then is the 16-bit context)
     prev0 = 0x20 if args.order == 1 else 0x2020
-    if world > 1:
+    if multi:
         k = args.order
         last = torch.zeros(world * k, dtype=torch.uint8, device=device)
         all_gather(last, data[-k:].clone())
@@ -361,8 +370,8 @@ def main():
         e[0].record()
         codec.histogram(data, prev0)
         e[1].record()
-        o2_shared = world > 1 and args.order == 2 and args.o2_exchange == "scatter" and 65536 % world == 0
-        if world > 1:
+        o2_shared = multi and args.order == 2 and args.o2_exchange == "scatter" and 65536 % world == 0
+        if multi:
             local_counts.copy_(codec.counts)          # the shard's own histogram fixes its payload length
             if not o2_shared:
                 all_reduce(codec.counts)              # the one collective: 512 KiB sum over xGMI (order 2: 128 MiB)
@@ -372,7 +381,7 @@ def main():
         else:
             model = codec.build_model()               # the step's one host wait (16 KiB of table sizes)
         e[3].record()
-        if world > 1:
+        if multi:
             # placement before encoding: shard bits = local histogram . code lengths, all-gather,
             # exclusive sum -> global start bit; the shard is emitted pre-shifted by start % 8
             codec.payload_bits(model, local_counts, my_bits)
@@ -392,17 +401,17 @@ def main():
     for _ in range(args.warmup):
         step(False)
         codec.nbits_hint = int(codec.nbits[0].item())
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -413,11 +422,11 @@ def main():
     rc2 = codec.lib.mh_dev_status(codec.dec_ws.data_ptr(), codec.stream())
     rc3 = codec.lib.mh_dev_status(codec.hist_ws.data_ptr(), codec.stream()) if args.order == 1 else 0   # counts add up to n
     round_trip = bool(rc == 0 and rc2 == 0 and rc3 == 0 and torch.equal(codec.decoded, data))
-    if world > 1:     # the shard ended where its histogram said it would: the ranks' payloads tile the global stream
+    if multi:     # the shard ended where its histogram said it would: the ranks' payloads tile the global stream
         round_trip = round_trip and nbits == (int(start_bit.item()) & 7) + int(my_bits.item())
     ok = torch.tensor([1 if round_trip else 0], device=device)
-    tot_bits = torch.tensor([nbits - (int(start_bit.item()) & 7) if world > 1 else nbits], dtype=torch.int64, device=device)
-    if world > 1:
+    tot_bits = torch.tensor([nbits - (int(start_bit.item()) & 7) if multi else nbits], dtype=torch.int64, device=device)
+    if multi:
         all_reduce(ok, op=dist.ReduceOp.MIN)
         all_reduce(tot_bits)
     round_trip_all = bool(ok.item())
@@ -476,8 +485,8 @@ def main():
                        "sharding": ("contiguous byte ranges, histogram all-reduce (%s, %s)" %
                                     ("RCCL over xGMI" if args.backend == "nccl" else "gloo staged through host memory: REHEARSAL, not RCCL",
                                      "512 KiB" if args.order == 1 else ("128 MiB" if args.o2_exchange != "scatter" or 65536 % world else
-                                                                        "order 2: reduce-scatter of the counts, 65536 / N trees per rank, all-gather of the per-context arrays"))) if world > 1 else "single GPU",
-                       "backend": (dist.get_backend() if world > 1 else None), "ranks": (dist.get_world_size() if world > 1 else 1)},
+                                                                        "order 2: reduce-scatter of the counts, 65536 / N trees per rank, all-gather of the per-context arrays"))) if multi else "single GPU",
+                       "backend": (dist.get_backend() if multi else None), "ranks": (dist.get_world_size() if multi else 1)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_ratio": round(traffic / kernels[dom][0], 3) if traffic else None,
@@ -523,7 +532,7 @@ def main():
             out["cpu_baseline"]["gpu_histogram_equals_cpu_histogram_on_sample"] = bool(
                 np.array_equal(codec.counts.cpu().numpy().astype(np.uint64), mh_oracle.histogram_o1(sample)))
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
     if not round_trip_all:
         sys.exit(2)
