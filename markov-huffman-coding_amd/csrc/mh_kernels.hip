@@ -2524,13 +2524,22 @@ __device__ __forceinline__ LaneIn load_raw2(const uint8_t *__restrict__ data, ui
 constexpr int H2_THREADS = 1024;
 constexpr uint32_t H2_SLOTS = 16384;
 constexpr uint32_t H2_EMPTY = 0xFFFFFFFFu;
-constexpr int H2_LDS_BYTES = int(H2_SLOTS) * 8 + 16;
+constexpr int H2_LDS_BYTES = int(H2_SLOTS) * 8 + 64 * 4 + 16;     // tags, counters + one dummy word per lane, the claim counter
 constexpr uint32_t H2_PROBES = 8, H2_PROBES_FULL = 2, H2_FULL = H2_SLOTS * 3 / 4;
 
+// the two slots a key may own without probing: 14 bits each of one 32-bit product
+__device__ __forceinline__ void hist2_slots(uint32_t key, uint32_t &s1, uint32_t &s2) {
+    const uint32_t h = key * 0x9E3779B1u;
+    s1 = h >> 18;
+    s2 = (h >> 4) & (H2_SLOTS - 1u);
+}
+// the whole story for one key: its first slot, its second, then linear probing behind the first, then memory
 __device__ __forceinline__ void hist2_add(uint32_t *tag, uint32_t *cnt, uint32_t *used, unsigned long long *counts, uint32_t key,
                                           uint32_t probes) {
-    uint32_t slot = (key * 0x9E3779B1u) >> 18;                   // 14 bits
-    for (uint32_t p = 0; p < probes; ++p, slot = (slot + 1u) & (H2_SLOTS - 1u)) {
+    uint32_t s1, s2;
+    hist2_slots(key, s1, s2);
+    uint32_t slot = s1;
+    for (uint32_t p = 0; p < probes + 1u; ++p) {
         // a plain read first: once its tag is set (tags never change) a key costs one read, which the LDS broadcasts
         // to all the lanes that ask for the same slot, and one add — not a compare-and-swap that serialises them
         uint32_t t = __hip_atomic_load(&tag[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -2539,6 +2548,7 @@ __device__ __forceinline__ void hist2_add(uint32_t *tag, uint32_t *cnt, uint32_t
             if (t == H2_EMPTY) { atomicAdd(used, 1u); t = key; }
         }
         if (t == key) { atomicAdd(&cnt[slot], 1u); return; }
+        slot = p == 0 ? s2 : ((p == 1 ? s1 : slot) + 1u) & (H2_SLOTS - 1u);
     }
     atomicAdd(&counts[key], 1ull);
 }
@@ -2547,8 +2557,8 @@ __global__ __launch_bounds__(H2_THREADS) void hist_o2_kernel(const uint8_t *__re
                                                              unsigned long long *counts) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *tag = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *cnt = tag + H2_SLOTS;
-    uint32_t *used = cnt + H2_SLOTS;                             // slots claimed so far
+    uint32_t *cnt = tag + H2_SLOTS;                              // (+ 64 dummy words behind the slots)
+    uint32_t *used = cnt + H2_SLOTS + 64;                        // slots claimed so far
     for (uint32_t i = threadIdx.x; i < H2_SLOTS; i += H2_THREADS) { tag[i] = H2_EMPTY; cnt[i] = 0; }
     if (threadIdx.x == 0) *used = 0;
     __syncthreads();
@@ -2556,22 +2566,54 @@ __global__ __launch_bounds__(H2_THREADS) void hist_o2_kernel(const uint8_t *__re
     const uint4 *vdata = reinterpret_cast<const uint4 *>(data);
     // whole waves stay in the loop together (the neighbour's bytes come by shuffle)
     const uint64_t nvec_up = (nvec + 63) & ~uint64_t(63);
-    for (uint64_t v = uint64_t(blockIdx.x) * H2_THREADS + threadIdx.x; v < nvec_up; v += uint64_t(gridDim.x) * H2_THREADS) {
+    const uint64_t vstep = uint64_t(gridDim.x) * H2_THREADS;
+    const uint32_t dummy = H2_SLOTS + (threadIdx.x & 63u);       // where a lane's add goes when the slot it read is not its key's
+    uint64_t v = uint64_t(blockIdx.x) * H2_THREADS + threadIdx.x;
+    uint4 ahead = v < nvec ? vdata[v] : make_uint4(0, 0, 0, 0);
+    for (; v < nvec_up; v += vstep) {
         const bool live = v < nvec;
-        const uint4 x4 = live ? vdata[v] : make_uint4(0, 0, 0, 0);
+        const uint4 x4 = ahead;
+        if (v + vstep < nvec) ahead = vdata[v + vstep];
         const uint32_t up = __shfl_up(x4.w >> 16, 1);
         uint32_t ctx = ((up & 255u) << 8) | (up >> 8);
         if ((threadIdx.x & 63u) == 0) ctx = live ? ctx_before(data, n, v << 4, ctx0) : ctx0;
         if (!live) continue;
-        const uint32_t probes = *used < H2_FULL ? H2_PROBES : H2_PROBES_FULL;
+        const uint32_t ctx_in = ctx;
         const uint32_t x[4] = {x4.x, x4.y, x4.z, x4.w};
+        // The usual case without a branch: all sixteen tags are read at once, a key that finds its own tag adds to its slot,
+        // any other adds to a dummy word of the lane.  (The counters said what the symbol-by-symbol form below was waiting
+        // for: 30 scalar instructions and 8.5 branches per symbol, the exec-mask bookkeeping of sixteen divergent probe
+        // loops in a row, with the LDS 25 % and the vector ALU 29 % busy.)  Keys that miss — every key once per workgroup,
+        // and what the table cannot hold — go through hist2_add afterwards.
+        uint32_t key[16], sa[16], sb[16], ta[16], tb[16];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int j = 0; j < 16; ++j) {
+            key[j] = (ctx << 8) | ((x[j >> 2] >> (8 * (j & 3))) & 255u);
+            ctx = key[j] & 0xFFFFu;
+            hist2_slots(key[j], sa[j], sb[j]);
+            ta[j] = __hip_atomic_load(&tag[sa[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            tb[j] = __hip_atomic_load(&tag[sb[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        uint32_t missed = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t key = (ctx << 8) | ((x[k] >> (8 * j)) & 255u);
-                hist2_add(tag, cnt, used, counts, key, probes);
-                ctx = key & 0xFFFFu;
+        for (int j = 0; j < 16; ++j) {
+            const bool ha = ta[j] == key[j], hb = tb[j] == key[j];
+            atomicAdd(&cnt[ha ? sa[j] : hb ? sb[j] : dummy], 1u);
+            missed |= (ha || hb) ? 0u : (1u << j);
+        }
+        if (missed) {                                            // (divergent, rare once the table is warm)
+            const uint32_t probes = *used < H2_FULL ? H2_PROBES : H2_PROBES_FULL;
+            // every lane takes ITS next missed symbol per trip: as many trips as the worst lane has misses, not sixteen
+            const uint64_t xlo = uint64_t(x4.x) | uint64_t(x4.y) << 32, xhi = uint64_t(x4.z) | uint64_t(x4.w) << 32;
+            while (missed) {
+                const uint32_t j = uint32_t(__builtin_ctz(missed));
+                missed &= missed - 1u;
+                // bytes j - 2, j - 1, j of the lane's stream: the incoming context supplies what lies before byte 0
+                const uint32_t b0 = uint32_t(((j < 8u ? xlo : xhi) >> (8u * (j & 7u))) & 255u);
+                const uint32_t j1 = j - 1u, j2 = j - 2u;
+                const uint32_t b1 = j >= 1u ? uint32_t(((j1 < 8u ? xlo : xhi) >> (8u * (j1 & 7u))) & 255u) : (ctx_in & 255u);
+                const uint32_t b2 = j >= 2u ? uint32_t(((j2 < 8u ? xlo : xhi) >> (8u * (j2 & 7u))) & 255u) : j == 1u ? (ctx_in & 255u) : (ctx_in >> 8);
+                hist2_add(tag, cnt, used, counts, (b2 << 16) | (b1 << 8) | b0, probes);
             }
         }
     }

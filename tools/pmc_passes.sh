@@ -13,6 +13,7 @@ while read -r line; do
   [ -z "$line" ] && continue
   i=$((i+1))
   [ -n "${PMC_MAX_PASSES:-}" ] && [ $i -gt $PMC_MAX_PASSES ] && break
+  [ -n "${PMC_ONLY:-}" ] && ! echo " $PMC_ONLY " | grep -q " $i " && continue   # PMC_ONLY="1 2 6": just those passes
   timeout -k 10 240 rocprofv3 --pmc $line --kernel-trace --output-format csv -d $OUT/p$i -- python3 $R/tools/prof_run.py "$@" > $OUT/p$i.log 2>&1
   echo "pass $i rc=$? : $line" >> $OUT/passes.txt
 done <<'PASSES'

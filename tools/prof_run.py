@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=1 << 30)
 ap.add_argument("--kind", default="zipf")
 ap.add_argument("--reps", type=int, default=1)
+ap.add_argument("--order", type=int, default=1, choices=[1, 2])
 a = ap.parse_args()
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
@@ -24,11 +25,12 @@ mhc = entry.load_package()
 if bench.CHUNK == 0:
     bench.CHUNK = 1024 if a.size >= (2 << 30) else 256
 data = bench.generate(a.kind, a.size, {"zipf": 2, "uniform": 3, "text": 1}[a.kind], 0, dev)
-codec = bench.Codec(mhc, a.size, dev)
+codec = bench.Codec(mhc, a.size, dev, order=a.order)
+prev0 = 0x20 if a.order == 1 else 0x2020
 for _ in range(a.reps):
-    codec.histogram(data, 0x20)
+    codec.histogram(data, prev0)
     model = codec.build_model()
-    codec.encode(model, data, 0x20)
+    codec.encode(model, data, prev0)
     codec.decode(model)
 torch.cuda.synchronize()
 assert torch.equal(codec.decoded, data)
