@@ -124,6 +124,40 @@ struct RegHeap {
             put_dyn(l, pos >> (L - l), wlo, whi, wit);
         }
     }
+    // [r3] the same with an early exit: most entries come to rest one or two levels above where they were appended, and the
+    // flat form reads and rewrites the whole root path every time.  One comparison chain, no write until the resting level is
+    // known; then only the levels that change are written (switch on the number of moves: every case writes a fixed set).
+    template <int L>
+    __device__ __forceinline__ void swim_short(uint32_t pos, uint32_t lo, uint32_t hi, uint32_t it) {
+        uint32_t alo[L + 1], ahi[L + 1], ait[L + 1];
+        uint32_t moves = 0;
+#pragma unroll
+        for (int l = L - 1; l >= 0; --l) {
+            get_dyn(l, pos >> (L - l), alo[l], ahi[l], ait[l]);
+            if (!lt(lo, hi, alo[l], ahi[l])) break;              // parent <= key: the entry rests at level l + 1
+            ++moves;
+        }
+        // parents at levels L-1 .. L-moves move down one level each; the new entry goes to level L - moves
+#pragma unroll
+        for (int m = 0; m < L; ++m) {
+            if (uint32_t(m) < moves) put_dyn(L - m, pos >> m, alo[L - 1 - m], ahi[L - 1 - m], ait[L - 1 - m]);
+        }
+        put_any_level<L>(L - moves, pos >> moves, lo, hi, it);
+    }
+    template <int L>
+    __device__ __forceinline__ void put_any_level(uint32_t level, uint32_t pos, uint32_t lo, uint32_t hi, uint32_t it) {
+        switch (level) {
+            case 0: put<0>(pos, lo, hi, it); break;
+            case 1: if (L >= 1) put<1>(pos, lo, hi, it); break;
+            case 2: if (L >= 2) put<2>(pos, lo, hi, it); break;
+            case 3: if (L >= 3) put<3>(pos, lo, hi, it); break;
+            case 4: if (L >= 4) put<4>(pos, lo, hi, it); break;
+            case 5: if (L >= 5) put<5>(pos, lo, hi, it); break;
+            case 6: if (L >= 6) put<6>(pos, lo, hi, it); break;
+            case 7: if (L >= 7) put<7>(pos, lo, hi, it); break;
+            default: if (L >= 8) put<8>(pos, lo, hi, it); break;
+        }
+    }
     // level known at compile time through the unrolled loops above: these forward to get<>/put<>
     __device__ __forceinline__ void get_dyn(int l, uint32_t pos, uint32_t &lo, uint32_t &hi, uint32_t &it) const {
         switch (l) {
@@ -144,15 +178,15 @@ struct RegHeap {
         const uint32_t level = 31u - uint32_t(__builtin_clz(i + 1u));
         const uint32_t pos = i + 1u - (1u << level);
         switch (level) {
-            case 0: swim_flat<0>(pos, lo, hi, it); break;
-            case 1: swim_flat<1>(pos, lo, hi, it); break;
-            case 2: swim_flat<2>(pos, lo, hi, it); break;
-            case 3: swim_flat<3>(pos, lo, hi, it); break;
-            case 4: swim_flat<4>(pos, lo, hi, it); break;
-            case 5: swim_flat<5>(pos, lo, hi, it); break;
-            case 6: swim_flat<6>(pos, lo, hi, it); break;
-            case 7: swim_flat<7>(pos, lo, hi, it); break;
-            default: swim_flat<8>(pos, lo, hi, it); break;
+            case 0: swim_short<0>(pos, lo, hi, it); break;
+            case 1: swim_short<1>(pos, lo, hi, it); break;
+            case 2: swim_short<2>(pos, lo, hi, it); break;
+            case 3: swim_short<3>(pos, lo, hi, it); break;
+            case 4: swim_short<4>(pos, lo, hi, it); break;
+            case 5: swim_short<5>(pos, lo, hi, it); break;
+            case 6: swim_short<6>(pos, lo, hi, it); break;
+            case 7: swim_short<7>(pos, lo, hi, it); break;
+            default: swim_short<8>(pos, lo, hi, it); break;
         }
     }
     // src/min_pq.tpp:38-52: the hole at the root takes the smaller child — the right one only when STRICTLY
