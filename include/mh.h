@@ -399,10 +399,11 @@ int mh_dev_index_path(const void *d_ws, void *stream);
  * histogram of the input, one read), 3 the same with its escape variant launched too (model with codes over 12
  * bits), 2 the length pass + emit pair (inputs under 4 MiB without a histogram; order-2 models whose live contexts
  * do not fit the LDS image, or MH_ENCODE2_PATH=two_pass), 4 the one-pass order-2 encoder (enc_chain_kernel: every
- * symbol looked up once, start bits by a chained scan over groups of wave-tiles).  Synchronises.
- * The one-pass encoder needs all its workgroups on the device at once; on a device that another process keeps busy it
- * gives up after about a second of waiting and the workspace's status is MH_ERR_TIMEOUT (nothing valid was written):
- * mh_encode* retry with the pair by themselves, a caller of mh_dev_encode* runs again with MH_ENCODE2_PATH=two_pass. */
+ * symbol looked up once, start bits by a chained scan over groups of wave-tiles that are handed out by a ticket counter,
+ * so a wait is only ever for a workgroup that is running).  Synchronises.
+ * Every wait of the one-pass encoder is bounded; should one run out all the same, the workspace's status is
+ * MH_ERR_TIMEOUT (nothing valid was written): mh_encode* retry with the pair by themselves, a caller of mh_dev_encode*
+ * runs again with MH_ENCODE2_PATH=two_pass. */
 int mh_dev_encode_path(const void *d_ws, void *stream);
 /* Synchronises `stream` and returns the device-side status word of a workspace (MH_OK, MH_ERR_CORRUPT,
  * MH_ERR_TIMEOUT, MH_ERR_CAPACITY). */

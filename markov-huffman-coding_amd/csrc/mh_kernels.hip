@@ -842,14 +842,12 @@ __global__ __launch_bounds__(E_THREADS) void enc_emit_kernel(EmitParams p) {
 // loops over the sub-steps stay rolled), and the start bits come from a chained scan in the manner of Merrill &
 // Garland's decoupled look-back: a state word per GROUP of 16 wave-tiles (one round of one workgroup) is empty, then
 // AGGREGATE | the group's bits, then PREFIX | bits up to and including it; a look-back adds aggregates down to the
-// nearest prefix.  Groups are dealt round-robin over a grid of at most one workgroup per CU, all of which are resident
-// at once (1024 threads and > 64 KiB of LDS each), so every group a look-back can wait for belongs to a workgroup that
-// is running; the wait is bounded anyway (CH_SPIN_MAX polls, then MHK_STATUS_TIMEOUT, a bogus prefix so that nobody
-// else hangs, and the wave leaves).  The launcher keeps to the length pass + emit pair when a CU mask is set in the
-// environment, the one case in which fewer CUs than the device reports would be there for the grid.
-// (A ticket counter handing the groups out in order costs a same-address atomic and two barriers per round: 6.8 ms
-// for 4 GiB of text against 5.65; four rounds per ticket ran the launch in sequence, 938 ms — the first tiles of a
-// ticket wait for the aggregates of the previous ticket's LAST round.)
+// nearest prefix.  Groups are handed out in order through a ticket counter, one round of one workgroup at a time, so
+// every group a look-back can wait for has been taken by a workgroup that is running; the wait is bounded anyway
+// (CH_SPIN_MAX polls, then MHK_STATUS_TIMEOUT, a bogus prefix so that nobody else hangs, and the wave leaves).
+// (Measured on the way, 4 GiB of text: four rounds per ticket ran the launch in sequence, 938 ms — the first tiles of a
+// ticket wait for the aggregates of the previous ticket's LAST round; a state word per wave-tile instead of per group
+// 6.2-6.8 ms; this 5.6 ms.)
 // No dword of the output has two writers, so nothing needs zeroing and no global atomic is spent on seams: the dword
 // that holds a tile's last bits is written by THAT tile, which encodes the next few symbols of the input itself to
 // fill it (at most 31 bits, codes have at least one bit), and a tile never writes the part of its first dword that
@@ -862,6 +860,7 @@ struct ChainParams {
     unsigned long long *nbits;
     int *status;
     uint32_t probe;
+    uint32_t *sync;                          // the ticket counter (zeroed)
 };
 constexpr unsigned long long CH_AGG = 1ull << 62, CH_PFX = 2ull << 62, CH_VAL = (1ull << 62) - 1ull;
 constexpr uint32_t CH_SPIN_MAX = 1u << 20;                   // polls of one wait (~ a second) before giving up
@@ -916,7 +915,7 @@ __device__ __forceinline__ void o2_code_of(const EmitParams &p, const unsigned c
 __global__ __launch_bounds__(E_THREADS) void enc_chain_kernel(ChainParams cp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned long long s_tile[2][E_WAVES], s_base[2];
-    __shared__ uint32_t s_done[2], s_tag[2], s_bad[2];
+    __shared__ uint32_t s_done[2], s_tag[2], s_bad[2], s_ticket;
     const EmitParams &p = cp.e;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t tab_bytes = (p.o2hot_bytes + 15u) & ~15u;
@@ -929,15 +928,18 @@ __global__ __launch_bounds__(E_THREADS) void enc_chain_kernel(ChainParams cp) {
     const uint32_t S = 1u << p.chunk_shift;
     const uint64_t cap_bits = cp.cap * 8;
     const uint64_t carry = cp.start_bit ? (*cp.start_bit & 7ull) : 0ull;
+    // ---- the groups are handed out in order by a ticket counter: every group a look-back can wait for has been taken by a
+    // workgroup that is RUNNING, whatever else holds CUs of the device.  (Dealing them round-robin over a grid assumed to be
+    // resident all at once is no faster — 5.60 against 5.58 ms per 4 GiB — and two ranks rehearsing on one card deadlocked
+    // each other that way until the bounded waits ran out.)
+    if (threadIdx.x == 0) s_ticket = atomicAdd(cp.sync, 1u);
     __syncthreads();
-    const uint64_t stride = uint64_t(gridDim.x) * E_WAVES;
-    uint64_t wt = uint64_t(blockIdx.x) * E_WAVES + wave;      // neighbouring tiles run side by side
+    uint64_t group = s_ticket;
+    uint64_t wt = group * E_WAVES + wave;                      // neighbouring tiles run side by side
     LaneIn ahead = load_raw2(p.data, p.n, wt * E_WT + lane * E_VEC, p.prev0);   // (past the end: zeros, nothing read)
 #pragma unroll 1
-    for (uint32_t round = 0; wt - wave < p.nwt; wt += stride, ++round) {       // (every wave of the workgroup takes part in every group)
-        const uint64_t wt_next = wt + stride;
+    for (uint32_t round = 0; wt - wave < p.nwt; ++round) {     // (every wave of the workgroup takes part in every group)
         const uint32_t par = round & 1u;
-        const uint64_t group = uint64_t(round) * gridDim.x + blockIdx.x;
         struct Held { uint64_t g[4]; uint32_t gl, pb; };      // gl: the four group lengths, a byte each (escape sub-step: the lane's bits)
         Held h0{}, h1{}, h2{}, h3{};
         uint32_t escmask = 0;
@@ -1026,7 +1028,7 @@ __global__ __launch_bounds__(E_THREADS) void enc_chain_kernel(ChainParams cp) {
                 if (group != 0) {
                     if (lane == 0) __hip_atomic_store(&cp.state[group], CH_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (cp.probe == 2u) bad = true;                            // (test hook: as if the wait had run out)
-                    else if (cp.probe) base = group * 320000ull;
+                    else if (cp.probe == 1u) base = group * 320000ull;
                     else bad = !chain_lookback(cp.state, group, lane, base);  // (group 0's prefix carries the start offset)
                 }
                 if (lane == 0) {
@@ -1057,16 +1059,22 @@ __global__ __launch_bounds__(E_THREADS) void enc_chain_kernel(ChainParams cp) {
             emit = !(waited_out || end > cap_bits);            // (wave-uniform) else nothing of this tile is written
         }
         if (waited_out) break;                                 // (the others of the workgroup run into their own bound)
-        ahead = load_raw2(p.data, p.n, wt_next * E_WT + lane * E_VEC, p.prev0);   // the next round's first vectors (past the end: zeros)
+        const uint64_t wt_now = wt;
+        __syncthreads();                                       // (everybody has read the ticket before it is replaced)
+        if (threadIdx.x == 0) s_ticket = atomicAdd(cp.sync, 1u);
+        __syncthreads();
+        group = s_ticket;                                      // the next group: whichever is next in line
+        wt = group * E_WAVES + wave;
+        ahead = load_raw2(p.data, p.n, wt * E_WT + lane * E_VEC, p.prev0);   // the next round's first vectors (past the end: zeros)
         if (emit) {
             // ---- emit from the registers
             uint64_t gbase = s >> 5;                             // output dword under image word 0
             uint32_t cur = uint32_t(s & 31u);                    // image bit where the next code goes
             uint64_t abs_bits = s;
-            uint32_t seam0 = (cur != 0 && wt != 0) ? SEAM_DROP : SEAM_NONE;   // the tile before this one writes that dword
+            uint32_t seam0 = (cur != 0 && wt_now != 0) ? SEAM_DROP : SEAM_NONE;   // the tile before this one writes that dword
 #pragma unroll 1
             for (int k = 0; k < E_SUBSTEPS; ++k) {
-                const uint64_t off = wt * E_WT + uint64_t(k) * E_SUB + lane * E_VEC;
+                const uint64_t off = wt_now * E_WT + uint64_t(k) * E_SUB + lane * E_VEC;
                 const uint32_t nvalid = off + E_VEC <= p.n ? uint32_t(E_VEC) : off < p.n ? uint32_t(p.n - off) : 0u;
                 uint32_t sub_bits;
                 if ((escmask >> k) & 1u) {
@@ -1098,7 +1106,7 @@ __global__ __launch_bounds__(E_THREADS) void enc_chain_kernel(ChainParams cp) {
             }
             // ---- the tile's last, partial dword
             if (cur != 0 && seam0 == SEAM_NONE) {               // this tile's to write: filled up with the first bits of what follows
-                const uint64_t next = (wt + 1) * uint64_t(E_WT);   // (a ragged tile is the last one: nothing follows)
+                const uint64_t next = (wt_now + 1) * uint64_t(E_WT);   // (a ragged tile is the last one: nothing follows)
                 const uint64_t pos = next + lane;
                 const bool valid = lane < 32u && pos < p.n;
                 uint32_t l = 0;
@@ -2998,9 +3006,7 @@ hipError_t launch_payload_bits(const unsigned long long *d_counts, const uint8_t
 // MH_ENCODE2_PATH=two_pass: order 2 through the length pass + emit pair also when the hot image is there (A/B runs, tests)
 static bool encode2_two_pass() {
     const char *v = getenv("MH_ENCODE2_PATH");
-    if (v && !strcmp(v, "two_pass")) return true;
-    // a CU mask leaves fewer CUs than the device reports: the chained scan's grid might not be resident all at once
-    return getenv("HSA_CU_MASK") || getenv("ROC_GLOBAL_CU_MASK") || getenv("HSA_CU_MASK_SKIP_INIT");
+    return v && !strcmp(v, "two_pass");
 }
 
 hipError_t launch_encode(const EncodeArgs &a, void *d_ws, hipStream_t st) {
@@ -3029,7 +3035,7 @@ hipError_t launch_encode(const EncodeArgs &a, void *d_ws, hipStream_t st) {
     uint64_t want = (L.nwt + E_WAVES - 1) / E_WAVES;
     int grid = int(want > uint64_t(2 * cu_count()) ? uint64_t(2 * cu_count()) : want);
     const bool hot2 = a.order == 2 && a.o2hot && a.o2hot_bytes && a.o2hot_bytes <= uint32_t(LEN_LDS_BYTES);
-    if (hot2 && !a.no_chain && !encode2_two_pass()) {                       // one pass: enc_chain_kernel (all its workgroups resident at once)
+    if (hot2 && !a.no_chain && !encode2_two_pass()) {                       // one pass: enc_chain_kernel
         e = once_per_device(&DeviceState::chain_ready, [] { return allow_lds(reinterpret_cast<const void *>(enc_chain_kernel), EMIT_LDS_BYTES); });
         if (e != hipSuccess) return e;
         const uint64_t groups = (L.nwt + E_WAVES - 1) / E_WAVES;
@@ -3046,6 +3052,7 @@ hipError_t launch_encode(const EncodeArgs &a, void *d_ws, hipStream_t st) {
         cp.status = status;
         const char *probe = getenv("MH_CHAIN_PROBE");                        // diagnostics: "timeout" = report MHK_STATUS_TIMEOUT as if a
         cp.probe = !probe ? 0u : !strcmp(probe, "timeout") ? 2u : 1u;        // wait had run out; anything else = no look-back, output wrong
+        cp.sync = reinterpret_cast<uint32_t *>(ws + 32);                     // (zeroed with the status block above)
         const int cgrid = int(groups > uint64_t(cu_count()) ? uint64_t(cu_count()) : groups);
         hipLaunchKernelGGL(enc_chain_kernel, dim3(cgrid), dim3(E_THREADS), ((a.o2hot_bytes + 15u) & ~15u) + E_WAVES * E_STAGE_WORDS * 4, st, cp);
         return hipGetLastError();

@@ -163,3 +163,4 @@ def test_chain_encoder_giving_up_is_reported_and_the_host_path_retries_parity_un
         del os.environ["MH_CHAIN_PROBE"]
     ref, ref_bits = oracle.Model.from_table(text_model.table_bytes()).compress(data.tobytes())
     assert (nbits, blob) == (ref_bits, ref)
+

@@ -213,7 +213,7 @@ def test_order2_config5_size_properties_parity_unpinned(mhc):
 
 # ------------------------------------------------------------------ the model build shared by two ranks (reduce-scatter path)
 
-def _o2_rank(rank, world, port, data, q):
+def _o2_rank(rank, world, port, data, q, exchange):
     import os, sys, importlib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
@@ -233,24 +233,25 @@ def _o2_rank(rank, world, port, data, q):
         ctx0 = 0x2020 if lo == 0 else (data[lo - 2] << 8 | data[lo - 1])
         counts = torch.zeros(1 << 24, dtype=torch.int64, device="cuda")
         assert lib.mh_dev_histogram_o2(shard.data_ptr(), hi - lo, ctx0, counts.data_ptr(), None) == 0
-        model = sharded.order2_model(mhc, counts, None, exchange="scatter")
+        model = sharded.order2_model(mhc, counts, None, exchange=exchange)
         q.put((rank, model.table_bytes(), bytes(model.image(1)), model.max_code_len))
     finally:
         dist.destroy_process_group()
 
 
-def test_order2_model_shared_by_two_ranks_parity_unpinned(mhc, oracle):
-    """SURVEY.md 8e's order-2 exchange with the shipped code, two gloo ranks on the one card: local histograms,
-    reduce-scatter (staged: gloo), each rank builds the trees of ITS half of the contexts, the per-context arrays are
-    all-gathered in place, mh_dev_model2_finish — both ranks end with the table file and the code lengths the oracle
-    derives from the whole input."""
+@pytest.mark.parametrize("exchange", ["scatter", "compact", "allreduce"])
+def test_order2_model_shared_by_two_ranks_parity_unpinned(mhc, oracle, exchange):
+    """SURVEY.md 8e's order-2 exchange with the shipped code, two gloo ranks on the one card: local histograms, then
+    scatter: reduce-scatter (staged: gloo), each rank builds the trees of ITS half of the contexts, the per-context arrays
+    are all-gathered in place, mh_dev_model2_finish; compact: only the rows of the live contexts are summed; allreduce: all
+    128 MiB — both ranks end with the table file and the code lengths the oracle derives from the whole input."""
     import socket
     import torch.multiprocessing as mp
     data = text_like((2 << 20) + 77, 21)
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_o2_rank, args=(r, 2, port, data, q)) for r in range(2)]
+    procs = [ctx.Process(target=_o2_rank, args=(r, 2, port, data, q, exchange)) for r in range(2)]
     for p in procs:
         p.start()
     got = sorted(q.get(timeout=600) for _ in range(2))

@@ -139,3 +139,63 @@ def test_shard_bounds_cover_and_align():
             assert b[0][0] == 0 and b[-1][1] == n
             assert all(x[1] == y[0] for x, y in zip(b, b[1:]))
             assert all(lo % 16 == 0 for lo, _ in b)
+
+
+# ------------------------------------------------------------------ order 2: only the live contexts' rows travel
+
+def _compact_worker(rank, world, port, shards, dense_above, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import __graft_entry__ as entry
+        entry.load_package()
+        import importlib
+        sharded = importlib.import_module("mhc_amd.sharded")
+        data, ctx0 = shards[rank]
+        # the shard's own order-2 counts, its first symbols in the context of the two bytes before the shard
+        full = np.frombuffer(bytes([ctx0 >> 8, ctx0 & 255]) + data, dtype=np.uint8).astype(np.int64)
+        keys = (full[:-2] << 16) | (full[1:-1] << 8) | full[2:]
+        counts = torch.from_numpy(np.bincount(keys, minlength=1 << 24).astype(np.int64))
+        nlive = sharded.merged_histogram_o2_compact(counts, dense_above=dense_above)
+        q.put((rank, nlive, counts.numpy().tobytes()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,kind,dense_above", [(2, "text", 0.25), (3, "text", 0.25), (2, "flat", 0.25), (2, "text", 0.0), (2, "empty", 0.25)])
+def test_order2_compact_merge_equals_the_histogram_of_the_whole_input_parity_unpinned(oracle, world, kind, dense_above):
+    """merged_histogram_o2_compact over gloo ranks on the CPU: the counts every rank ends with are the order-2 histogram of
+    the whole input, whether the compact path ran (text: a few hundred live contexts), the dense fallback (flat bytes, or a
+    threshold of zero), or nothing was live at all."""
+    rng = np.random.default_rng(world)
+    if kind == "text":
+        words = [b"alpha", b"beta", b"gamma", b"delta", b"epsilon", b"zeta"]
+        data = b" ".join(words[int(i)] for i in rng.integers(0, len(words), size=6000))
+    elif kind == "flat":
+        data = rng.integers(0, 256, size=40000, dtype=np.uint8).tobytes()
+    else:
+        data = b""
+    cuts = [len(data) * r // world // 16 * 16 for r in range(world)] + [len(data)]
+    shards = []
+    for r in range(world):
+        lo, hi = cuts[r], cuts[r + 1]
+        ctx0 = 0x2020 if lo == 0 else (data[lo - 2] << 8 | data[lo - 1])
+        shards.append((data[lo:hi], ctx0))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_compact_worker, args=(r, world, port, shards, dense_above, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=60) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = oracle.histogram_o2(data).astype(np.int64)
+    live = int((want.reshape(65536, 256) != 0).any(axis=1).sum())
+    for rank, nlive, raw in out:
+        assert np.array_equal(np.frombuffer(raw, dtype=np.int64), want), rank
+        assert nlive == live
