@@ -2163,7 +2163,6 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecParams p) {
 // Huffman streams re-synchronise after a few symbols, so a handful of passes converge; a pass that
 // recomputes nothing proves the fixed point (= the true decode).  Then a prefix sum of the symbol
 // counts and one more pass emit the regular chunk index.
-constexpr uint64_t ST_POS = 0x00FFFFFFFFFFFFFFull;
 __device__ __forceinline__ uint64_t st_pack(uint32_t prev, uint64_t pos) { return (uint64_t(prev) << 56) | pos; }
 // a state = context | bit position, packed like an index entry: order 1 context << 56, order 2 (two bytes) << 48
 __device__ __forceinline__ uint32_t st_shift(const IdxParams &p) { return p.order == 2 ? 48u : 56u; }

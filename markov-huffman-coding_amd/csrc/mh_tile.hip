@@ -143,7 +143,6 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
     if (nw == 0) { nw = 1; region = free_bytes & ~15u; }
     if (nw > uint32_t(T_WAVES)) nw = T_WAVES;
     const uint32_t H = HC ? uint32_t(HC) : p.H;
-    const uint32_t S = 1u << p.chunk_shift;
     const uint64_t nsub = (p.n + T_SUB - 1) >> T_SUB_SHIFT;
     constexpr uint32_t TSYM = uint32_t(K) * T_TILE;               // symbols per wave piece
     // ---- what the tiles do not cover: the chunks behind the last full piece (block 0, wave 0)
