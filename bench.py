@@ -449,7 +449,9 @@ def main():
         }
         dom = max(kernels, key=lambda k: kernels[k][1])
         if args.order == 2:
-            kernels = {k.replace("hist_o1", "hist_o2").replace("enc_region_kernel", "enc2_emit_kernel").replace("decode_kernel", "decode2_kernel"): v
+            # which encoder ran is on record in the workspace (mh_dev_encode_path): 4 the one-pass enc_chain_kernel, else the pair
+            enc2 = "enc_chain_kernel" if codec.lib.mh_dev_encode_path(codec.enc_ws.data_ptr(), codec.stream()) == 4 else "enc_emit_kernel<2>"
+            kernels = {k.replace("hist_o1", "hist_o2").replace("enc_region_kernel", enc2).replace("decode_kernel", "decode2_kernel"): v
                        for k, v in kernels.items()}
             dom = max(kernels, key=lambda k: kernels[k][1])
         # counter-derived figures of the dominant kernel come from the committed --pmc summaries (profiles/): HBM
