@@ -162,7 +162,9 @@ struct OutputView {
     void start_populate() {
 #ifdef MADV_POPULATE_WRITE
         if (!map || size < (size_t(64) << 20)) return;
-        const size_t threads = 4, step = size_t(32) << 20;
+        size_t threads = 4;                                   // MH_POPULATE_THREADS: measured 4 / 8 / 16 in profiles/r03/README.md
+        if (const char* e = getenv("MH_POPULATE_THREADS")) { const long v = atol(e); if (v >= 1 && v <= 64) threads = size_t(v); }
+        const size_t step = size_t(32) << 20;
         const size_t part = ((size / threads) + step - 1) / step * step;
         for (size_t t = 0; t < threads; ++t) {
             const size_t lo = t * part, hi = std::min(size, lo + part);
