@@ -441,7 +441,8 @@ def main():
         total_bytes = float(total)
         gbps = total_bytes / (elapsed / K) / 1e9
         # algorithmic bytes per launch: hist 1, encode 1 + r, decode r + 1 per input byte
-        dec_name = "decode_tile_kernel" if codec.use_fine else "decode_kernel"
+        # which decoder ran is on record in the workspace (mh_dev_decode_path): 1 the tile decoder, 2 the chunk decoder
+        dec_name = "decode_tile_kernel" if codec.lib.mh_dev_decode_path(codec.dec_ws.data_ptr(), codec.stream()) == 1 else "decode_kernel"
         kernels = {
             "hist_o1_kernel": (1.0 * n, ms["hist"]),
             "enc_region_kernel": ((1.0 + r) * n, ms["encode"]),

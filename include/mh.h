@@ -405,6 +405,9 @@ int mh_dev_index_path(const void *d_ws, void *stream);
  * MH_ERR_TIMEOUT (nothing valid was written): mh_encode* retry with the pair by themselves, a caller of mh_dev_encode*
  * runs again with MH_ENCODE2_PATH=two_pass. */
 int mh_dev_encode_path(const void *d_ws, void *stream);
+/* Diagnostic: which decoder the last mh_dev_decode* call on this workspace ran — 1 the tile decoder (fine index given, 8 MiB
+ * or more, average code shorter than the tile tables' first level), 2 the chunk decoder.  Synchronises. */
+int mh_dev_decode_path(const void *d_ws, void *stream);
 /* Synchronises `stream` and returns the device-side status word of a workspace (MH_OK, MH_ERR_CORRUPT,
  * MH_ERR_TIMEOUT, MH_ERR_CAPACITY). */
 int mh_dev_status(const void *d_ws, void *stream);

@@ -1321,9 +1321,11 @@ static int dev_decode(const mh_model *m, const uint8_t *d_payload, uint64_t nbit
             t.P = m->o2_p; t.H = m->o2_h; t.nsec = m->o2_nsec;
         }
         HIP_TRY(mhk::launch_decode_tile(t, p, d_ws, static_cast<hipStream_t>(stream)));
+        HIP_TRY(mhk::launch_set_word(reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(d_ws) + 40), mhk::DEC_PATH_TILE, static_cast<hipStream_t>(stream)));
         return MH_OK;
     }
     HIP_TRY(mhk::launch_decode(p, d_ws, static_cast<hipStream_t>(stream)));
+    HIP_TRY(mhk::launch_set_word(reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(d_ws) + 40), mhk::DEC_PATH_CHUNK, static_cast<hipStream_t>(stream)));
     return MH_OK;
 }
 
@@ -1383,6 +1385,14 @@ int mh_dev_build_index_fine(const mh_model *m, const uint8_t *d_payload, uint64_
 
 int mh_dev_index_path(const void *d_ws, void *stream);
 int mh_dev_encode_path(const void *d_ws, void *stream) { return mh_dev_index_path(d_ws, stream); }   // same word of the status block
+
+int mh_dev_decode_path(const void *d_ws, void *stream) {
+    if (!d_ws) return MH_ERR_ARG;
+    uint32_t v = 0;
+    HIP_TRY(hipMemcpyAsync(&v, static_cast<const unsigned char *>(d_ws) + 40, sizeof v, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return int(v);
+}
 
 int mh_dev_index_path(const void *d_ws, void *stream) {
     if (!d_ws) return MH_ERR_ARG;

@@ -171,6 +171,9 @@ struct IdxParams {
     uint64_t fine_cap;            // entries available at `fine`
 };
 // which encoder a launch_encode* call used (its workspace's status block, bytes 8..11)
+// which decoder ran (status block of the decode workspace, bytes 40..43; mh_dev_decode_path)
+enum { DEC_PATH_NONE = 0, DEC_PATH_TILE = 1, DEC_PATH_CHUNK = 2 };
+hipError_t launch_set_word(uint32_t *d_word, uint32_t v, hipStream_t st);
 enum { ENC_PATH_NONE = 0, ENC_PATH_REGIONS = 1, ENC_PATH_LENGTH_PASS = 2, ENC_PATH_REGIONS_ESCAPES = 3, ENC_PATH_CHAIN = 4 };
 // how launch_build_index arrived at the index (status block bytes 8..11)
 enum { IDX_PATH_NONE = 0, IDX_PATH_SEGMENTS = 1, IDX_PATH_GROUP_MAPS = 2, IDX_PATH_STATE_MAPS = 3, IDX_PATH_WALK = 4 };

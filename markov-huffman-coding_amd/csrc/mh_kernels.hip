@@ -66,6 +66,10 @@ __device__ __forceinline__ void slots16(const uint4 &x4, uint32_t pb, uint32_t (
 }
 
 __global__ void set_word_kernel(uint32_t *p, uint32_t v) { *p = v; }
+hipError_t launch_set_word(uint32_t *d_word, uint32_t v, hipStream_t st) {
+    hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(1), 0, st, d_word, v);
+    return hipGetLastError();
+}
 
 // ------------------------------------------------------------------------------------------------
 // histogram, order 1

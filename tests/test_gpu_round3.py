@@ -211,3 +211,32 @@ def test_stream_without_an_index_decodes_through_the_tile_decoder(mhc, oracle):
     j = np.arange(0, data.size, 64)
     want = ((prev[j] << 24) | (pos[j] & 0xFFFFFF)).astype(np.uint32)
     assert np.array_equal(d_fine.download(np.uint32)[:want.size], want)
+
+
+@pytest.mark.parametrize("kind,forced,want", [("zipf", None, 1), ("uniform", None, 2), ("zipf", "chunk", 2), ("text", "tile", 1)])
+def test_decode_path_word_says_which_decoder_ran(mhc, kind, forced, want):
+    """mh_dev_decode_path: the library picks the tile decoder from 8 MiB on when the average code is shorter than the tile
+    tables' first level (uniform bytes: 8-bit codes, the chunk decoder), MH_DECODE_PATH overrides."""
+    import torch
+    import bench
+    bench.CHUNK = 256
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    n = 16 << 20
+    data = bench.generate(kind, n, {"zipf": 2, "uniform": 3, "text": 1}[kind], 0, dev)
+    codec = bench.Codec(mhc, n, dev)
+    codec.histogram(data, 0x20)
+    model = codec.build_model()
+    codec.encode(model, data, 0x20)
+    codec.nbits_hint = int(codec.nbits[0].item())            # (the choice by code length needs the payload length on the host)
+    if forced:
+        os.environ["MH_DECODE_PATH"] = forced
+    try:
+        codec.decode(model)
+        torch.cuda.synchronize()
+    finally:
+        if forced:
+            del os.environ["MH_DECODE_PATH"]
+    assert codec.lib.mh_dev_status(codec.dec_ws.data_ptr(), codec.stream()) == 0
+    assert codec.lib.mh_dev_decode_path(codec.dec_ws.data_ptr(), codec.stream()) == want
+    assert torch.equal(codec.decoded, data)
