@@ -132,86 +132,13 @@ def generate(kind, n, seed, first_byte, device):
     return out
 
 
-class Codec:
-    """Thin holder of device buffers + the C-ABI calls of one rank.  Everything a step needs is allocated
-    here, once: the timed step allocates nothing and waits for the device exactly once (the 16 KiB of table
-    sizes the host needs to pick the decode-table layout)."""
-
-    def __init__(self, mhc, n, device, order=1):
-        self.mhc, self.lib, self.n, self.device, self.order = mhc, mhc.lib(), n, device, order
-        self.counts = torch.zeros(65536 if order == 1 else 1 << 24, dtype=torch.int64, device=device)
-        self.cap = n + (64 << 20)
-        self.payload = torch.empty(self.cap, dtype=torch.uint8, device=device)
-        self.decoded = torch.empty(n, dtype=torch.uint8, device=device)
-        self.nidx = (n + CHUNK - 1) // CHUNK
-        self.index = torch.empty(max(self.nidx, 1), dtype=torch.int64, device=device)
-        self.nbits = torch.zeros(2, dtype=torch.int64, device=device)
-        # device-only fine index (one uint32 per 64 symbols): what lets a wave decode 64 adjacent pieces from one
-        # contiguous piece of the payload (mh_dev_encode_fine / mh_dev_decode_fine); MH_BENCH_NO_FINE=1: without it
-        self.use_fine = not os.environ.get("MH_BENCH_NO_FINE") and not (order == 1 and os.environ.get("MH_BENCH_TWO_PASS_ENCODE"))
-        self.fine_symbols = int(os.environ.get("MH_FINE_SYMBOLS", "64"))     # (an experimental library build may use 32)
-        self.fine = torch.empty(max((n + self.fine_symbols - 1) // self.fine_symbols, 1), dtype=torch.int32, device=device) if self.use_fine else None
-        self.hist_ws_bytes = int(self.lib.mh_dev_histogram_workspace(n))
-        self.hist_ws = torch.empty(self.hist_ws_bytes, dtype=torch.uint8, device=device)
-        self.enc_ws_bytes = self.lib.mh_dev_encode_workspace(n)
-        self.enc_ws = torch.empty(self.enc_ws_bytes + 64, dtype=torch.uint8, device=device)
-        self.dec_ws_bytes = int(self.lib.mh_dev_decode_workspace(0, n, CHUNK))
-        self.dec_ws = torch.empty(self.dec_ws_bytes, dtype=torch.uint8, device=device)
-        self.model_ws_bytes = int(self.lib.mh_dev_model_workspace(1))
-        self.model_ws = torch.empty(self.model_ws_bytes, dtype=torch.uint8, device=device)
-        self.nbits_hint = 0          # last known payload length: steers the decode variant choice only
-
-    def check(self, rc, what):
-        if rc != 0:
-            raise self.mhc.MhError(rc, what)
-
-    def stream(self):
-        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-
-    def histogram(self, data, prev0, n=None):
-        if self.order == 2:         # extension (parity unpinned): 65536 two-byte contexts, counts in HBM
-            self.check(self.lib.mh_dev_histogram_o2(data.data_ptr(), self.n if n is None else n, prev0,     # prev0: 16-bit context
-                                                    self.counts.data_ptr(), self.stream()), "hist2")
-            return
-        self.check(self.lib.mh_dev_histogram_o1(data.data_ptr(), self.n if n is None else n, prev0, self.counts.data_ptr(),
-                                                self.hist_ws.data_ptr(), self.hist_ws_bytes, self.stream()), "hist")
-
-    def build_model(self):
-        """Tables built on the device into the preallocated workspace: no allocation, one stream sync."""
-        if self.order == 2:         # 65536 trees; this build allocates its (data-dependent) tables itself
-            return self.mhc.Model.from_device_counts(self.counts.data_ptr(), 2, self.stream())
-        return self.mhc.Model.from_device_counts_ws(self.counts.data_ptr(), 1, self.model_ws.data_ptr(), self.model_ws_bytes,
-                                                    self.stream())
-
-    def payload_bits(self, model, counts, out):
-        self.check(self.lib.mh_dev_payload_bits(model.handle, counts.data_ptr(), out.data_ptr(), self.stream()), "payload_bits")
-
-    def encode(self, model, data, prev0, start_bit=None):
-        """start_bit: device int64 tensor holding this shard's global start bit (the payload is emitted
-        pre-shifted by its low 3 bits so that shards concatenate with one OR-merged seam byte), or None."""
-        if self.order == 1 and not os.environ.get("MH_BENCH_TWO_PASS_ENCODE"):
-            # the histogram of this very buffer is in hist_ws: the encoder prices its regions from it (no length pass)
-            self.check(self.lib.mh_dev_encode_fine(model.handle, data.data_ptr(), self.n, prev0,
-                                                   start_bit.data_ptr() if start_bit is not None else None,
-                                                   self.payload.data_ptr(), self.cap,
-                                                   self.nbits.data_ptr(), self.index.data_ptr(), CHUNK,
-                                                   self.fine.data_ptr() if self.use_fine else None,
-                                                   self.hist_ws.data_ptr(), self.hist_ws_bytes,
-                                                   self.enc_ws.data_ptr(), self.enc_ws_bytes, self.stream()), "encode")
-            return
-        self.check(self.lib.mh_dev_encode_ctx_fine(model.handle, data.data_ptr(), self.n, prev0,
-                                                   start_bit.data_ptr() if start_bit is not None else None,
-                                                   self.payload.data_ptr(), self.cap,
-                                                   self.nbits.data_ptr(), self.index.data_ptr(), CHUNK,
-                                                   self.fine.data_ptr() if self.use_fine else None, self.enc_ws.data_ptr(),
-                                                   self.enc_ws_bytes, self.stream()), "encode")
-
-    def decode(self, model):
-        """The payload length stays on the device (self.nbits[0], written by the encoder)."""
-        self.check(self.lib.mh_dev_decode_fine(model.handle, self.payload.data_ptr(), self.nbits_hint, self.nbits.data_ptr(),
-                                               self.decoded.data_ptr(), self.n, self.index.data_ptr(), CHUNK,
-                                               self.fine.data_ptr() if self.use_fine else None, self.dec_ws.data_ptr(),
-                                               self.dec_ws_bytes, self.stream()), "decode")
+def Codec(mhc, n, device, order=1):
+    """One rank's device buffers + C-ABI calls: sharded.HipBackend with this module's chunk size (tools/ and tests use it)."""
+    import importlib
+    sharded = importlib.import_module("mhc_amd.sharded")
+    return sharded.HipBackend(mhc, n, device, order=order, chunk_symbols=CHUNK or 1024,
+                              use_fine=not os.environ.get("MH_BENCH_NO_FINE"),
+                              two_pass_encode=bool(os.environ.get("MH_BENCH_TWO_PASS_ENCODE")))
 
 
 def cpu_baseline(mhc, table_bytes, sample, gpu_payload_prefix_check):
@@ -256,6 +183,26 @@ def cpu_baseline(mhc, table_bytes, sample, gpu_payload_prefix_check):
     }
 
 
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` without a launcher: this process starts `python -m torch.distributed.run` with N ranks
+    of this very command as a CHILD, relays what the ranks print and returns the child's exit code.  It runs before
+    anything here touches a GPU (importing torch does not), and nothing is exec'ed."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in child.stdout:                         # rank 0's JSON line (and anything else the ranks say)
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return child.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -279,11 +226,13 @@ def main():
                     help="gloo (collectives staged through host memory) is only for rehearsing the N>1 path on one GPU")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))                   # parent of N ranks: never touches a GPU
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node N" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if "MH_BENCH_DEVICE" in os.environ:          # rehearsal: several ranks on one card
         local = int(os.environ["MH_BENCH_DEVICE"])
     torch.cuda.set_device(local)
@@ -302,23 +251,6 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group("gloo")
-    staged = multi and args.backend == "gloo"
-
-    def all_reduce(t, op=dist.ReduceOp.SUM):
-        if staged:
-            c = t.cpu()
-            dist.all_reduce(c, op=op)
-            t.copy_(c)
-        else:
-            dist.all_reduce(t, op=op)
-
-    def all_gather(out, t):
-        if staged:
-            co, ct = out.cpu(), t.cpu()
-            dist.all_gather_into_tensor(co, ct)
-            out.copy_(co)
-        else:
-            dist.all_gather_into_tensor(out, t)
 
     mhc = entry.load_package()
     mhc.lib()                      # fails loudly if libmhc.so is missing: there is no fallback path
@@ -332,10 +264,8 @@ def main():
         args.total_size = 16 << 30
     if args.total_size is not None:
         mode, total = "strong", args.total_size
-        unit = 16                                  # shards start on 16-byte boundaries (device loads are 16-byte vectors)
-        units = (total + unit - 1) // unit
-        first = min(total, (units * rank // world) * unit)
-        n = min(total, (units * (rank + 1) // world) * unit) - first
+        first, hi = sharded.shard_bounds(total, world)[rank]     # shards start on 16-byte boundaries (device loads are 16-byte vectors)
+        n = hi - first
     else:
         mode = "weak"
         n = args.size if args.size is not None else ((8 << 30) if args.config == 4 else (16 << 30))
@@ -351,55 +281,38 @@ def main():
     if multi:
         k = args.order
         last = torch.zeros(world * k, dtype=torch.uint8, device=device)
-        all_gather(last, data[-k:].clone())
+        sharded.all_gather_flat(last, data[-k:].clone())
         if rank > 0:
             tail = last[(rank - 1) * k:rank * k].tolist()
             prev0 = tail[0] if k == 1 else (tail[0] << 8 | tail[1])
-    codec = Codec(mhc, n, device, args.order)
-    all_bits = torch.zeros(world, dtype=torch.int64, device=device)
-    my_bits = torch.zeros(1, dtype=torch.int64, device=device)
-    start_bit = torch.zeros(1, dtype=torch.int64, device=device)
-    local_counts = torch.zeros(65536 if args.order == 1 else 1 << 24, dtype=torch.int64, device=device)
+    # the rank's buffers and C-ABI calls (sharded.HipBackend); the step below is sharded.compress_step — the shipped
+    # orchestration, the one the world-2 tests drive — followed by the decode of what it left in HBM
+    codec = sharded.HipBackend(mhc, n, device, order=args.order, chunk_symbols=CHUNK, o2_exchange=args.o2_exchange,
+                               use_fine=not os.environ.get("MH_BENCH_NO_FINE"),
+                               two_pass_encode=bool(os.environ.get("MH_BENCH_TWO_PASS_ENCODE")))
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
     stage_ms = {"hist": 0.0, "allreduce": 0.0, "tree": 0.0, "encode": 0.0, "decode": 0.0}
     model = None
+    last_step = {}
 
     def step(record):
-        nonlocal model
-        e = [ev() for _ in range(6)]
-        e[0].record()
-        codec.histogram(data, prev0)
-        e[1].record()
-        o2_shared = multi and args.order == 2 and args.o2_exchange == "scatter" and 65536 % world == 0
-        if multi:
-            local_counts.copy_(codec.counts)          # the shard's own histogram fixes its payload length
-            if args.order == 2 and args.o2_exchange == "compact":
-                sharded.merged_histogram_o2_compact(codec.counts)   # only the live contexts' rows travel (text: a few MiB of 128)
-            elif not o2_shared:
-                all_reduce(codec.counts)              # the one collective: 512 KiB sum over xGMI (order 2: 128 MiB)
-        e[2].record()
-        if o2_shared:                                 # reduce-scatter, 65536 / N trees per rank, all-gather of the per-context arrays
-            model = sharded.order2_model(mhc, codec.counts, codec.stream(), exchange="scatter")
-        else:
-            model = codec.build_model()               # the step's one host wait (16 KiB of table sizes)
-        e[3].record()
-        if multi:
-            # placement before encoding: shard bits = local histogram . code lengths, all-gather,
-            # exclusive sum -> global start bit; the shard is emitted pre-shifted by start % 8
-            codec.payload_bits(model, local_counts, my_bits)
-            all_gather(all_bits, my_bits)
-            torch.sum(all_bits[:rank], dim=0, keepdim=True, out=start_bit)
-            codec.encode(model, data, prev0, start_bit)
-        else:
-            codec.encode(model, data, prev0)
-        e[4].record()
+        nonlocal model, last_step
+        marks = [ev()]
+        marks[0].record()
+
+        def mark(name):
+            e = ev()
+            e.record()
+            marks.append(e)
+        last_step = sharded.compress_step(codec, data, prev0, distributed=multi, mark=mark)   # hist, allreduce, tree, encode
+        model = last_step["model"]
         codec.decode(model)                           # reads the payload length where the encoder left it (HBM)
-        e[5].record()
+        mark("decode")
         torch.cuda.synchronize()
         if record:
-            for k, (a, b) in zip(stage_ms, [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5)]):
-                stage_ms[k] += e[a].elapsed_time(e[b])
+            for i, k in enumerate(stage_ms):
+                stage_ms[k] += marks[i].elapsed_time(marks[i + 1])
 
     for _ in range(args.warmup):
         step(False)
@@ -414,6 +327,14 @@ def main():
     if multi:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    def all_reduce(t, op=dist.ReduceOp.SUM):       # (after the timed region: timing and verdicts of the ranks)
+        if t.is_cuda and dist.get_backend() != "nccl":
+            c = t.cpu()
+            dist.all_reduce(c, op=op)
+            t.copy_(c)
+        else:
+            dist.all_reduce(t, op=op)
+
     if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         all_reduce(t, op=dist.ReduceOp.MAX)
@@ -421,14 +342,14 @@ def main():
 
     # ---- correctness of what was timed (outside the timed region)
     nbits = int(codec.nbits[0].item())
-    rc = codec.lib.mh_dev_status(codec.enc_ws.data_ptr(), codec.stream())
-    rc2 = codec.lib.mh_dev_status(codec.dec_ws.data_ptr(), codec.stream())
-    rc3 = codec.lib.mh_dev_status(codec.hist_ws.data_ptr(), codec.stream()) if args.order == 1 else 0   # counts add up to n
-    round_trip = bool(rc == 0 and rc2 == 0 and rc3 == 0 and torch.equal(codec.decoded, data))
+    rc, rc2, rc3 = codec.statuses()                  # encoder, decoder, histogram (its counts add up to n)
+    enc_path, dec_path = codec.paths()
+    round_trip = bool(rc == 0 and rc2 == 0 and rc3 == 0 and torch.equal(codec.decoded[:n], data))
+    start_low = (int(last_step["start_bit"].item()) & 7) if multi else 0
     if multi:     # the shard ended where its histogram said it would: the ranks' payloads tile the global stream
-        round_trip = round_trip and nbits == (int(start_bit.item()) & 7) + int(my_bits.item())
+        round_trip = round_trip and nbits == start_low + int(last_step["my_bits"].item())
     ok = torch.tensor([1 if round_trip else 0], device=device)
-    tot_bits = torch.tensor([nbits - (int(start_bit.item()) & 7) if multi else nbits], dtype=torch.int64, device=device)
+    tot_bits = torch.tensor([nbits - start_low], dtype=torch.int64, device=device)
     if multi:
         all_reduce(ok, op=dist.ReduceOp.MIN)
         all_reduce(tot_bits)
@@ -442,7 +363,7 @@ def main():
         gbps = total_bytes / (elapsed / K) / 1e9
         # algorithmic bytes per launch: hist 1, encode 1 + r, decode r + 1 per input byte
         # which decoder ran is on record in the workspace (mh_dev_decode_path): 1 the tile decoder, 2 the chunk decoder
-        dec_name = "decode_tile_kernel" if codec.lib.mh_dev_decode_path(codec.dec_ws.data_ptr(), codec.stream()) == 1 else "decode_kernel"
+        dec_name = "decode_tile_kernel" if dec_path == 1 else "decode_kernel"
         kernels = {
             "hist_o1_kernel": (1.0 * n, ms["hist"]),
             "enc_region_kernel": ((1.0 + r) * n, ms["encode"]),
@@ -451,7 +372,7 @@ def main():
         dom = max(kernels, key=lambda k: kernels[k][1])
         if args.order == 2:
             # which encoder ran is on record in the workspace (mh_dev_encode_path): 4 the one-pass enc_chain_kernel, else the pair
-            enc2 = "enc_chain_kernel" if codec.lib.mh_dev_encode_path(codec.enc_ws.data_ptr(), codec.stream()) == 4 else "enc_emit_kernel<2>"
+            enc2 = "enc_chain_kernel" if enc_path == 4 else "enc_emit_kernel<2>"
             kernels = {k.replace("hist_o1", "hist_o2").replace("enc_region_kernel", enc2).replace("decode_kernel", "decode2_kernel"): v
                        for k, v in kernels.items()}
             dom = max(kernels, key=lambda k: kernels[k][1])

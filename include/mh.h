@@ -61,6 +61,12 @@ int mh_last_hip_error(void);
 /* Diagnostic: how the calling thread's last mh_decode / mh_decode_to WITHOUT an index rebuilt it (codes of
  * mh_dev_index_path below). */
 int mh_last_index_path(void);
+/* Diagnostic: how many segments of the calling thread's last mh_encode* call the one-pass order-2 encoder gave up on
+ * (MH_ERR_TIMEOUT: its bounded waits ran out, e.g. on a device shared with a long-running kernel) and that were encoded
+ * again with the two-pass pair — the bytes are the same, the time is not, so the retry is counted, never silent.
+ * 0 in normal operation.  mh_total_encode_retries: the same over all threads since the library was loaded. */
+int mh_last_encode_retries(void);
+uint64_t mh_total_encode_retries(void);
 /* Number of usable devices; 0 when there is none (never an error). */
 int mh_device_count(void);
 /* Device used by the calling thread's subsequent mh_* / mh_dev_* calls (hipSetDevice). */

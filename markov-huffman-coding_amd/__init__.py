@@ -27,7 +27,7 @@ INDEX2_BIT_MASK = 0x0000FFFFFFFFFFFF      # order-2 models: two context bytes in
 
 # every symbol include/mh.h declares (checked by tests/test_abi.py)
 EXPORTS = [
-    "mh_strerror", "mh_last_hip_error", "mh_last_index_path", "mh_device_count", "mh_set_device",
+    "mh_strerror", "mh_last_hip_error", "mh_last_index_path", "mh_last_encode_retries", "mh_total_encode_retries", "mh_device_count", "mh_set_device",
     "mh_dev_malloc", "mh_dev_free", "mh_dev_upload", "mh_dev_download",
     "mh_model_from_counts", "mh_dev_model_from_counts", "mh_dev_model_workspace", "mh_dev_model_from_counts_ws",
     "mh_model_from_table_bits", "mh_model_write_table",
@@ -65,6 +65,7 @@ def lib():
         pi, pu64, psz = C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_size_t)
         l.mh_strerror.restype = C.c_char_p
         l.mh_strerror.argtypes = [i32]
+        l.mh_total_encode_retries.restype = u64
         l.mh_dev_malloc.argtypes = [C.POINTER(vp), sz]
         l.mh_dev_free.argtypes = [vp]
         l.mh_dev_upload.argtypes = [vp, vp, sz]

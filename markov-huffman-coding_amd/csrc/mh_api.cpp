@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -66,6 +67,8 @@ struct mh_model {
 namespace {
 
 thread_local int g_last_hip = 0;
+thread_local int g_encode_retries = 0;    // segments of the calling thread's last mh_encode* that the one-pass order-2 encoder gave up on
+std::atomic<uint64_t> g_encode_retries_total{0};   // ... of all threads since the library was loaded
 thread_local int g_last_index_path = 0;   // how the calling thread's last index-free mh_decode* built its index (mh_last_index_path)
 
 int hip_fail(hipError_t e) {
@@ -240,7 +243,9 @@ struct PhaseClock {
         fprintf(stderr, "[mh-timing] %s.upload %zu bytes %.4f s %.2f GB/s\n", call, up_bytes, upload, upload > 0 ? up_bytes / upload / 1e9 : 0.0);
         fprintf(stderr, "[mh-timing] %s.device %zu bytes %.4f s %.2f GB/s\n", call, n, device, device > 0 ? n / device / 1e9 : 0.0);
         fprintf(stderr, "[mh-timing] %s.download %zu bytes %.4f s %.2f GB/s\n", call, down_bytes, download, download > 0 ? down_bytes / download / 1e9 : 0.0);
+        if (retries) fprintf(stderr, "[mh-timing] %s.retries %d (one-pass encoder timed out: segments encoded again with the two-pass pair)\n", call, retries);
     }
+    int retries = 0;
 };
 thread_local PhaseClock *g_phase = nullptr;
 
@@ -399,6 +404,8 @@ const char *mh_strerror(int status) {
 
 int mh_last_hip_error(void) { return g_last_hip; }
 int mh_last_index_path(void) { return g_last_index_path; }
+int mh_last_encode_retries(void) { return g_encode_retries; }
+uint64_t mh_total_encode_retries(void) { return g_encode_retries_total.load(std::memory_order_relaxed); }
 
 int mh_device_count(void) {
     int n = 0;
@@ -1551,6 +1558,7 @@ int mh_encode(const mh_model *m, const uint8_t *data, size_t n, uint8_t prev0, u
     if (index && chunk_shift_of(chunk_symbols) < 0) return MH_ERR_ARG;
     if (!have_device()) return MH_ERR_NO_DEVICE;
     if (m->max_len > mh::MAX_CODE_BITS) return MH_ERR_CODE_TOO_LONG;
+    g_encode_retries = 0;
     hipStream_t st = nullptr;
     PhaseClock clock;
     struct Scope { PhaseClock *c; size_t n; Scope(PhaseClock *cc, size_t nn) : c(cc), n(nn) { g_phase = c; } ~Scope() { c->report("encode", n); g_phase = nullptr; } } scope(&clock, n);
@@ -1595,6 +1603,9 @@ int mh_encode(const mh_model *m, const uint8_t *data, size_t n, uint8_t prev0, u
         if (rc != MH_OK) return rc;
         rc = mh_dev_status(d_ws.p, st);
         if (rc == MH_ERR_TIMEOUT && !t_no_chain) {               // (see t_no_chain)
+            ++g_encode_retries;                                  // never silent: mh_last_encode_retries(), MH_TIMING line
+            clock.retries = g_encode_retries;
+            g_encode_retries_total.fetch_add(1, std::memory_order_relaxed);
             t_no_chain = true;
             rc = dev_encode_ctx(m, d_seg, len, c0, d_start.as<uint64_t>(), d_out.as<uint8_t>(), dcap,
                                 d_nbits.as<uint64_t>(), index ? d_index.as<uint64_t>() : nullptr, chunk_symbols, d_ws.p, wsb, st, nullptr);

@@ -1032,7 +1032,9 @@ __global__ __launch_bounds__(E_THREADS) void enc_chain_kernel(ChainParams cp) {
                 if (group != 0) {
                     if (lane == 0) __hip_atomic_store(&cp.state[group], CH_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (cp.probe == 2u) bad = true;                            // (test hook: as if the wait had run out)
+#ifdef MH_EXP_PROBES                                                           /* diagnostic builds only: no look-back, output wrong */
                     else if (cp.probe == 1u) base = group * 320000ull;
+#endif
                     else bad = !chain_lookback(cp.state, group, lane, base);  // (group 0's prefix carries the start offset)
                 }
                 if (lane == 0) {
@@ -1046,10 +1048,22 @@ __global__ __launch_bounds__(E_THREADS) void enc_chain_kernel(ChainParams cp) {
                     __hip_atomic_store(&s_tag[par], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
+            // The group's last arrival always publishes s_tag (its own look-back is bounded), so this wait ends; its bound is a
+            // second line of defence only, longer than the look-back's (shorter sleeps, hence the factor), and a wave that does
+            // run out of it says so: its tile stays unwritten, and nobody may take the payload for valid.
             uint32_t spins = 0;
+            const bool follower_hook = cp.probe == 3u && group != 0 && arrived != uint32_t(E_WAVES) - 1u;   // (test hook)
             while (__hip_atomic_load(&s_tag[par], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != tag) {
-                if (++spins > CH_SPIN_MAX) { waited_out = true; break; }
+                if (++spins > CH_SPIN_MAX * 8u || follower_hook) {
+                    waited_out = true;
+                    if (lane == 0) atomicExch(cp.status, MHK_STATUS_TIMEOUT);
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(1);
+            }
+            if (follower_hook && !waited_out) {                    // (the tag was already there: the hook still reports)
+                waited_out = true;
+                if (lane == 0) atomicExch(cp.status, MHK_STATUS_TIMEOUT);
             }
             uint64_t mine = lane < wave ? s_tile[par][lane] : 0ull;          // the tiles of the group before this wave's
 #pragma unroll
@@ -3053,8 +3067,13 @@ hipError_t launch_encode(const EncodeArgs &a, void *d_ws, hipStream_t st) {
         cp.cap = a.cap & ~uint64_t(3);                                       // whole dwords are stored
         cp.nbits = a.nbits;
         cp.status = status;
-        const char *probe = getenv("MH_CHAIN_PROBE");                        // diagnostics: "timeout" = report MHK_STATUS_TIMEOUT as if a
-        cp.probe = !probe ? 0u : !strcmp(probe, "timeout") ? 2u : 1u;        // wait had run out; anything else = no look-back, output wrong
+        // test hooks (they never change a byte of a stream: the encoder reports MHK_STATUS_TIMEOUT and the caller retries with the
+        // two-pass pair): "timeout" = as if the leader's look-back had run out, "timeout_follower" = as if a follower's wait had
+        const char *probe = getenv("MH_CHAIN_PROBE");
+        cp.probe = !probe ? 0u : !strcmp(probe, "timeout") ? 2u : !strcmp(probe, "timeout_follower") ? 3u : 0u;
+#ifdef MH_EXP_PROBES
+        if (probe && !strcmp(probe, "nolookback")) cp.probe = 1u;             // diagnostic builds only: output wrong
+#endif
         cp.sync = reinterpret_cast<uint32_t *>(ws + 32);                     // (zeroed with the status block above)
         const int cgrid = int(groups > uint64_t(cu_count()) ? uint64_t(cu_count()) : groups);
         hipLaunchKernelGGL(enc_chain_kernel, dim3(cgrid), dim3(E_THREADS), ((a.o2hot_bytes + 15u) & ~15u) + E_WAVES * E_STAGE_WORDS * 4, st, cp);

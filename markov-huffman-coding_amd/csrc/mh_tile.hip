@@ -308,7 +308,14 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
                         e2[k] = uint32_t(__builtin_amdgcn_raw_buffer_load_b32(sec_rsrc, int(idx2), 0, 0));
                     } else {
                         const uint32_t idx2 = (e[k] << (H + 1)) | ((win[k] >> (P - 1)) & ((2u << H) - 2u));   // byte offset of the entry
+#if defined(MH_TILE_PROBE_NOGATHER)                 /* diagnostic build: no second level at all (output wrong) */
+                        e2[k] = idx2 & 0u;
+#elif defined(MH_TILE_EXECMASK)                     /* only the lanes whose entry is an inner node issue the gather */
+                        e2[k] = 0u;
+                        if (!(e[k] & DEC16_LEAF)) e2[k] = uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(sec_rsrc, int(idx2), 0, 0)));
+#else
                         e2[k] = uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(sec_rsrc, int(idx2), 0, 0)));
+#endif
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -393,7 +400,9 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
             const unsigned long long t4 = tile_stamp();
             seg[0] += t1 - t0; seg[1] += t2 - t1; seg[2] += t3 - t2; seg[3] += t4 - t3;
         }
+#ifdef MH_EXP_PROBES
         if (p.probe) continue;
+#endif
         if (__any(unresolved)) {                                  // rare: all chunks of this piece again, with the walk
             const uint64_t c0 = (t * TSYM) >> p.chunk_shift;
             for (uint32_t c = lane; c < chunks_per_tile * K; c += 64) p.redo[1u + atomicAdd(p.redo, 1u)] = uint32_t(c0 + c);
@@ -474,11 +483,12 @@ hipError_t launch_decode_tile(TileParams p, const DecParams &legacy, void *d_ws,
         void (*k2)(TileParams) = decode_tile_kernel<2, 6, 0, 2, 0, 0, 1>;
         return launch_tile_with<2, 1>(k2, p, legacy, d_ws, st);
     }
-    // timing probe (MH_TILE_PROBE=1): the second-level table has zero records, so every gather is answered by the
-    // bounds check — the instruction stream and the waits stay, the trips to L2 go (results are wrong)
+#ifdef MH_EXP_PROBES
+    // Diagnostic builds only (make exp EXPFLAGS=-DMH_EXP_PROBES): the shipped library has none of these switches.
+    // MH_TILE_PROBE=1: the second-level table has zero records, so every gather is answered by the bounds check — the
+    // instruction stream and the waits stay, the trips to L2 go (results are wrong)
     if (const char *pr = getenv("MH_TILE_PROBE")) { p.probe = uint32_t(atoi(pr)); if (p.probe & 1) p.nsec = 0; }
-    // tiles per wave: 2 by default; MH_TILE_K (1, 2) for A/B runs
-    const char *e = getenv("MH_TILE_K");
+    const char *e = getenv("MH_TILE_K");                          // tiles per wave
     const int k = e ? atoi(e) : 2;
     const char *eo = getenv("MH_TILE_OUT");
     const int o = eo ? atoi(eo) : 2;
@@ -490,9 +500,12 @@ hipError_t launch_decode_tile(TileParams p, const DecParams &legacy, void *d_ws,
             return launch_tile_with<2>(ks, p, legacy, d_ws, st);
         }
     }
-    const char *ew = getenv("MH_TILE_WIN");                       // 1: the register-window variant (measured level with the LDS window)
-    if (ew && atoi(ew) == 1) return launch_tile_k<2, 2, 1>(p, legacy, d_ws, st);
+    const char *ew = getenv("MH_TILE_WIN");                       // 1: the register-window variant
+    if (ew && atoi(ew) == 1) return k == 4 ? launch_tile_k<4, 2, 1>(p, legacy, d_ws, st) : k == 3 ? launch_tile_k<3, 2, 1>(p, legacy, d_ws, st) : launch_tile_k<2, 2, 1>(p, legacy, d_ws, st);
     return k == 1 ? launch_tile_k<1, 2>(p, legacy, d_ws, st) : k == 4 ? launch_tile_k<4, 2>(p, legacy, d_ws, st) : k == 3 ? launch_tile_k<3, 2>(p, legacy, d_ws, st) : launch_tile_k<2, 2>(p, legacy, d_ws, st);
+#else
+    return launch_tile_k<2, 2>(p, legacy, d_ws, st);             // two tiles per wave, output through LDS, window from LDS
+#endif
 }
 
 }  // namespace mhk

@@ -13,6 +13,7 @@ This module holds only the orchestration.  The per-shard compute comes from a `b
 tests inject their own backend to exercise the collective logic with gloo on CPU.
 """
 import ctypes
+import os
 
 import torch
 import torch.distributed as dist
@@ -159,32 +160,84 @@ def order2_model(mhc, local_counts, stream=None, group=None, exchange="scatter")
     return model
 
 
-def global_bit_offsets(local_nbits, group=None):
-    """All-gather of the shard payload lengths -> (this rank's global start bit, total bits, all lengths)."""
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    mine = torch.tensor([int(local_nbits)], dtype=torch.int64, device=_dev(group))
-    allv = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(allv, mine, group=group)
-    lens = [int(v.item()) for v in allv]
-    return sum(lens[:rank]), sum(lens), lens
+def _staged(t, group):
+    """True when a collective on tensor `t` has to go through host memory (gloo rehearsals with the shards on a GPU)."""
+    return t.is_cuda and dist.get_backend(group) != "nccl"
+
+
+def all_gather_flat(out, t, group=None):
+    """all_gather_into_tensor where the tensors lie (RCCL), or through host copies (gloo)."""
+    if _staged(t, group):
+        co, ct = out.cpu(), t.cpu()
+        dist.all_gather_into_tensor(co, ct, group=group)
+        out.copy_(co)
+    elif t.is_cuda:
+        dist.all_gather_into_tensor(out, t, group=group)
+    else:                                                        # gloo on CPU tensors: the list form
+        parts = list(out.view(dist.get_world_size(group), -1).unbind(0))
+        dist.all_gather(parts, t.view(-1), group=group)
+    return out
+
+
+def global_start_bit(my_bits, all_bits=None, start_bit=None, group=None):
+    """All-gather of the shard payload lengths (one int64 per rank) and an exclusive sum: this rank's global start bit.
+    Everything stays where `my_bits` lies (no host wait with RCCL).  Returns (start_bit[1], all_bits[world])."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if all_bits is None:
+        all_bits = torch.zeros(world, dtype=torch.int64, device=my_bits.device)
+    if start_bit is None:
+        start_bit = torch.zeros(1, dtype=torch.int64, device=my_bits.device)
+    all_gather_flat(all_bits, my_bits, group)
+    torch.sum(all_bits[:rank], dim=0, keepdim=True, out=start_bit)
+    return start_bit, all_bits
+
+
+def compress_step(backend, shard, prev0, group=None, distributed=None, mark=None):
+    """THE orchestration of one rank's part of a sharded compress — what `bench.py --gpus N` times, what
+    `compress_shard` returns to callers, what the world-2/3 tests drive (gloo on CPU with an oracle-backed double, gloo
+    and the HIP backend on one card):
+        histogram of the shard (context of its first byte = the byte before it, src/main.cpp:32-37)
+        -> sum over ranks (the ONE collective on the data path: 512 KiB of counts)
+        -> the same model on every rank (integer-only tree build, src/huffman.cpp:131-164)
+        -> shard payload bits = local histogram . code lengths -> all-gather -> exclusive sum = global start bit
+        -> encode, pre-shifted by start bit % 8 so that the shards' payloads concatenate with one OR-merged seam byte.
+    `backend` supplies the per-shard compute (HipBackend below; tests inject doubles): histogram, merge, build_model,
+    payload_bits, encode.  `distributed` None = whenever a process group is up.  `mark(name)` is called after each stage
+    (bench.py records an event there).  Nothing here waits for the device.
+    Returns dict(model, local, my_bits, start_bit, all_bits, encoded)."""
+    mark = mark or (lambda name: None)
+    if distributed is None:
+        distributed = dist.is_available() and dist.is_initialized()
+    local = backend.histogram(shard, prev0)                    # int64 counts where the backend computes
+    mark("hist")
+    merged = local
+    if distributed:
+        merged = backend.merge(local, group)                   # a second buffer: the shard's own counts fix its payload length
+    mark("allreduce")
+    model = backend.build_model(merged)
+    mark("tree")
+    my_bits = start_bit = all_bits = None
+    if distributed:
+        my_bits = backend.payload_bits(model, local)           # known before encoding: placement first
+        start_bit, all_bits = global_start_bit(my_bits, getattr(backend, "all_bits", None), getattr(backend, "start_bit", None), group)
+    encoded = backend.encode(model, shard, prev0, start_bit)
+    mark("encode")
+    return {"model": model, "local": local, "my_bits": my_bits, "start_bit": start_bit, "all_bits": all_bits, "encoded": encoded}
 
 
 def compress_shard(backend, shard, last_byte, group=None):
-    """One rank's part of a sharded compress.  Returns dict(model, payload, nbits, index, prev0,
+    """One rank's part of a sharded compress, results on the host.  Returns dict(model, payload, nbits, index, prev0,
     start_bit, total_bits): `payload` holds the shard's codes from bit (start_bit % 8) of its first
     byte on (zero bits before), `nbits` counts the shard's own payload bits."""
     n = backend.length(shard)
     prev0 = exchange_prev0(last_byte, n > 0, group)
-    local = backend.histogram(shard, prev0)
-    merged = merged_histogram(local.clone(), group)
-    model = backend.build_model(merged)
-    nbits = backend.payload_bits(model, local)               # known before encoding: placement first
-    start, total, _ = global_bit_offsets(nbits, group)
-    payload, end_bits, index = backend.encode(model, shard, prev0, start)
+    r = compress_step(backend, shard, prev0, group, distributed=True)
+    nbits, start = int(r["my_bits"].item()), int(r["start_bit"].item())
+    total = int(r["all_bits"].sum().item())
+    payload, end_bits, index = backend.finish(r["encoded"])
     if end_bits != (start & 7) + nbits:
         raise RuntimeError("shard payload is %d bits, its histogram predicted %d" % (end_bits - (start & 7), nbits))
-    return {"model": model, "payload": payload, "nbits": nbits, "index": index, "prev0": prev0,
+    return {"model": r["model"], "payload": payload, "nbits": nbits, "index": index, "prev0": prev0,
             "start_bit": start, "total_bits": total}
 
 
@@ -204,12 +257,48 @@ def stitch(parts, total_bits):
 
 
 class HipBackend:
-    """Per-shard compute on the rank's MI355X through the C ABI (device pointers, current stream)."""
+    """Per-shard compute on the rank's MI355X through the C ABI (device pointers, torch's current stream), for shards of
+    at most `n` bytes.  Every buffer a step needs is allocated here, once: a step allocates nothing and waits for the
+    device exactly once (the 16 KiB of table sizes the model build needs to pick the decode-table layout).
+    The fast flow: the histogram runs in region mode and leaves the regions' pair counts in its
+    workspace, the encoder prices its regions from them (no length pass) and writes the device-only fine index beside
+    the payload, the tile decoder decodes from it."""
 
-    def __init__(self, mhc, chunk_symbols=1024):
-        self.mhc, self.lib, self.chunk = mhc, mhc.lib(), chunk_symbols
+    def __init__(self, mhc, n, device=None, order=1, chunk_symbols=1024, o2_exchange="compact", use_fine=True, two_pass_encode=False):
+        self.mhc, self.lib, self.n, self.order, self.chunk = mhc, mhc.lib(), int(n), order, int(chunk_symbols)
         if mhc.device_count() < 1:
             raise mhc.MhError(mhc.MH_ERR_NO_DEVICE, "HipBackend")
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.o2_exchange = o2_exchange
+        self.two_pass_encode = two_pass_encode
+        dev, n = self.device, self.n
+        ncounts = 65536 if order == 1 else 1 << 24
+        self.counts = torch.zeros(ncounts, dtype=torch.int64, device=dev)        # the shard's own histogram
+        self.merged = None                                                       # the all-reduced one (allocated at first merge)
+        self.cap = n + (64 << 20) if n >= (1 << 20) else n * 8 + 4096            # (tiny shards: codes of up to 64 bits)
+        self.payload = torch.empty(self.cap, dtype=torch.uint8, device=dev)
+        self.decoded = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
+        self.nidx = (n + self.chunk - 1) // self.chunk
+        self.index = torch.empty(max(self.nidx, 1), dtype=torch.int64, device=dev)
+        self.nbits = torch.zeros(2, dtype=torch.int64, device=dev)
+        # device-only fine index (one uint32 per 64 symbols): what lets a wave decode 64 adjacent pieces from one
+        # contiguous piece of the payload (mh_dev_encode_fine / mh_dev_decode_fine)
+        self.use_fine = bool(use_fine) and not (order == 1 and two_pass_encode)
+        self.fine_symbols = int(os.environ.get("MH_FINE_SYMBOLS", "64"))        # (an experimental library build may use 32)
+        self.fine = torch.empty(max((n + self.fine_symbols - 1) // self.fine_symbols, 1), dtype=torch.int32, device=dev) if self.use_fine else None
+        self.hist_ws_bytes = int(self.lib.mh_dev_histogram_workspace(n))
+        self.hist_ws = torch.empty(max(self.hist_ws_bytes, 64), dtype=torch.uint8, device=dev)
+        self.enc_ws_bytes = int(self.lib.mh_dev_encode_workspace(n))
+        self.enc_ws = torch.empty(self.enc_ws_bytes + 64, dtype=torch.uint8, device=dev)
+        self.dec_ws_bytes = int(self.lib.mh_dev_decode_workspace(0, n, self.chunk))
+        self.dec_ws = torch.empty(max(self.dec_ws_bytes, 64), dtype=torch.uint8, device=dev)
+        self.model_ws_bytes = int(self.lib.mh_dev_model_workspace(1))
+        self.model_ws = torch.empty(self.model_ws_bytes, dtype=torch.uint8, device=dev)
+        self.my_bits = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.start_bit = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.all_bits = None                                                     # (global_start_bit allocates it: world entries)
+        self.nbits_hint = 0          # last known payload length: steers the decode variant choice only
+        self.n_now = n               # bytes of the shard the buffers currently describe
 
     @staticmethod
     def _stream():
@@ -219,47 +308,91 @@ class HipBackend:
         if rc != 0:
             raise self.mhc.MhError(rc, what)
 
+    stream, check = _stream, _check                            # (names the tools under tools/ use)
+
     def length(self, shard):
         return shard.numel()
 
-    def histogram(self, shard, prev0):
-        counts = torch.zeros(65536, dtype=torch.int64, device=shard.device)
-        wsb = int(self.lib.mh_dev_histogram_workspace(shard.numel()))
-        ws = torch.empty(wsb, dtype=torch.uint8, device=shard.device)
-        self._check(self.lib.mh_dev_histogram_o1(shard.data_ptr(), shard.numel(), prev0, counts.data_ptr(), ws.data_ptr(), wsb,
-                                                 self._stream()), "mh_dev_histogram_o1")
-        return counts
+    # ---- the five calls compress_step makes -------------------------------------------------------------------
+    def histogram(self, shard, prev0, n=None):
+        n = shard.numel() if n is None else n
+        if n > self.n:
+            raise ValueError("shard of %d bytes, buffers for %d" % (n, self.n))
+        self.n_now = n
+        if self.order == 2:         # extension (parity unpinned): 65536 two-byte contexts, counts in HBM; prev0: 16-bit context
+            self._check(self.lib.mh_dev_histogram_o2(shard.data_ptr(), n, prev0, self.counts.data_ptr(), self._stream()), "mh_dev_histogram_o2")
+        else:                       # region mode: the regions' own pair counts stay in hist_ws for the encoder
+            self._check(self.lib.mh_dev_histogram_o1(shard.data_ptr(), n, prev0, self.counts.data_ptr(),
+                                                     self.hist_ws.data_ptr(), self.hist_ws_bytes, self._stream()), "mh_dev_histogram_o1")
+        return self.counts
 
-    def build_model(self, counts):
-        return self.mhc.Model.from_device_counts(counts.data_ptr(), 1, self._stream())
+    def merge(self, local, group=None):
+        if self.merged is None:
+            self.merged = torch.empty_like(local)
+        self.merged.copy_(local)
+        if self.order == 2 and self.o2_exchange == "compact":
+            merged_histogram_o2_compact(self.merged, group)   # only the live contexts' rows travel (text: a few MiB of 128)
+        elif self.order == 2 and self.o2_exchange == "scatter" and 65536 % dist.get_world_size(group) == 0:
+            pass                                              # build_model reduce-scatters the counts itself
+        else:
+            merged_histogram(self.merged, group)              # the one collective: 512 KiB sum over xGMI (order 2: 128 MiB)
+        return self.merged
 
-    def payload_bits(self, model, counts):
-        out = torch.zeros(1, dtype=torch.int64, device=counts.device)
-        self._check(self.lib.mh_dev_payload_bits(model.handle, counts.data_ptr(), out.data_ptr(), self._stream()),
-                    "mh_dev_payload_bits")
-        return int(out.item())
+    def build_model(self, counts=None):
+        """Tables built on the device into the preallocated workspace: no allocation, one stream sync."""
+        counts = self.counts if counts is None else counts
+        if self.order == 2:
+            if counts is self.merged and self.o2_exchange == "scatter" and 65536 % dist.get_world_size() == 0:
+                return order2_model(self.mhc, counts, self._stream(), exchange="scatter")
+            return self.mhc.Model.from_device_counts(counts.data_ptr(), 2, self._stream())   # (allocates its data-dependent tables)
+        return self.mhc.Model.from_device_counts_ws(counts.data_ptr(), 1, self.model_ws.data_ptr(), self.model_ws_bytes, self._stream())
 
-    def encode(self, model, shard, prev0, start_bit=0):
-        n = shard.numel()
-        cap = self.lib.mh_encode_bound(model.handle, n) + 16
-        payload = torch.empty(cap, dtype=torch.uint8, device=shard.device)
-        nbits = torch.zeros(1, dtype=torch.int64, device=shard.device)
-        start = torch.tensor([int(start_bit)], dtype=torch.int64, device=shard.device)
-        index = torch.empty(max((n + self.chunk - 1) // self.chunk, 1), dtype=torch.int64, device=shard.device)
-        wsb = self.lib.mh_dev_encode_workspace(n)
-        ws = torch.empty(wsb + 64, dtype=torch.uint8, device=shard.device)
-        self._check(self.lib.mh_dev_encode_at(model.handle, shard.data_ptr(), n, prev0, start.data_ptr(), payload.data_ptr(), cap,
-                                              nbits.data_ptr(), index.data_ptr(), self.chunk, ws.data_ptr(), wsb,
-                                              self._stream()), "mh_dev_encode_at")
-        self._check(self.lib.mh_dev_status(ws.data_ptr(), self._stream()), "encode status")
-        nb = int(nbits.item())
-        return payload[:(nb + 7) // 8], nb, index[:(n + self.chunk - 1) // self.chunk]
+    def payload_bits(self, model, counts, out=None):
+        out = self.my_bits if out is None else out
+        self._check(self.lib.mh_dev_payload_bits(model.handle, counts.data_ptr(), out.data_ptr(), self._stream()), "mh_dev_payload_bits")
+        return out
 
-    def decode(self, model, payload, nbits, index, n):
-        out = torch.empty(max(n, 1), dtype=torch.uint8, device=payload.device)
-        wsb = int(self.lib.mh_dev_decode_workspace(nbits, n, self.chunk))
-        ws = torch.empty(wsb, dtype=torch.uint8, device=payload.device)
-        self._check(self.lib.mh_dev_decode(model.handle, payload.data_ptr(), nbits, out.data_ptr(), n, index.data_ptr(),
-                                           self.chunk, ws.data_ptr(), wsb, self._stream()), "mh_dev_decode")
-        self._check(self.lib.mh_dev_status(ws.data_ptr(), self._stream()), "decode status")
-        return out[:n]
+    def encode(self, model, shard, prev0, start_bit=None):
+        """start_bit: device int64 tensor holding this shard's global start bit (the payload is emitted pre-shifted by
+        its low 3 bits), or None.  Payload, its bit count (nbits[0]), the chunk index and the fine index stay on the device."""
+        n = self.n_now
+        sb = start_bit.data_ptr() if start_bit is not None else None
+        fine = self.fine.data_ptr() if self.use_fine else None
+        if self.order == 1 and not self.two_pass_encode:
+            # the histogram of this very buffer is in hist_ws: the encoder prices its regions from it (no length pass)
+            self._check(self.lib.mh_dev_encode_fine(model.handle, shard.data_ptr(), n, prev0, sb, self.payload.data_ptr(), self.cap,
+                                                    self.nbits.data_ptr(), self.index.data_ptr(), self.chunk, fine,
+                                                    self.hist_ws.data_ptr(), self.hist_ws_bytes,
+                                                    self.enc_ws.data_ptr(), self.enc_ws_bytes, self._stream()), "mh_dev_encode_fine")
+        else:
+            self._check(self.lib.mh_dev_encode_ctx_fine(model.handle, shard.data_ptr(), n, prev0, sb, self.payload.data_ptr(), self.cap,
+                                                        self.nbits.data_ptr(), self.index.data_ptr(), self.chunk, fine,
+                                                        self.enc_ws.data_ptr(), self.enc_ws_bytes, self._stream()), "mh_dev_encode_ctx_fine")
+        return self
+
+    # ---- beside the orchestration --------------------------------------------------------------------------------
+    def decode(self, model):
+        """Decodes what encode() left (payload, indices; the payload length stays on the device) into self.decoded."""
+        self._check(self.lib.mh_dev_decode_fine(model.handle, self.payload.data_ptr(), self.nbits_hint, self.nbits.data_ptr(),
+                                                self.decoded.data_ptr(), self.n_now, self.index.data_ptr(), self.chunk,
+                                                self.fine.data_ptr() if self.use_fine else None, self.dec_ws.data_ptr(),
+                                                self.dec_ws_bytes, self._stream()), "mh_dev_decode_fine")
+        return self.decoded[:self.n_now]
+
+    def finish(self, encoded):
+        """Host view of an encode: (payload tensor, bits in it counted from bit 0 of its first byte, chunk index)."""
+        self._check(self.lib.mh_dev_status(self.enc_ws.data_ptr(), self._stream()), "encode status")
+        nb = int(self.nbits[0].item())
+        self.nbits_hint = nb
+        return self.payload[:(nb + 7) // 8], nb, self.index[:(self.n_now + self.chunk - 1) // self.chunk]
+
+    def statuses(self):
+        """(encode, decode, histogram) status words of the last step (0 = fine); synchronises."""
+        st = self._stream()
+        return (self.lib.mh_dev_status(self.enc_ws.data_ptr(), st), self.lib.mh_dev_status(self.dec_ws.data_ptr(), st),
+                self.lib.mh_dev_status(self.hist_ws.data_ptr(), st) if self.order == 1 else 0)
+
+    def paths(self):
+        """(encoder, decoder) that ran last on this backend's workspaces (codes of mh_dev_encode_path / mh_dev_decode_path)."""
+        st = self._stream()
+        return (self.lib.mh_dev_encode_path(self.enc_ws.data_ptr(), st), self.lib.mh_dev_decode_path(self.dec_ws.data_ptr(), st))

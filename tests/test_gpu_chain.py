@@ -150,17 +150,26 @@ def test_chain_encoder_one_bit_codes_parity_unpinned(mhc, oracle):
     assert (a[1], a[2][:(a[1] + 7) // 8].tobytes()) == (ref_bits, ref[1:])
 
 
-def test_chain_encoder_giving_up_is_reported_and_the_host_path_retries_parity_unpinned(mhc, oracle, text_model):
-    """The one-pass encoder's waits are bounded; when one runs out (forced here) the workspace says MH_ERR_TIMEOUT, and
-    mh_encode*, which synchronises anyway, runs the two-pass pair instead."""
+@pytest.mark.parametrize("hook", ["timeout", "timeout_follower"])
+def test_chain_encoder_giving_up_is_reported_and_the_host_path_retries_parity_unpinned(mhc, oracle, text_model, hook):
+    """The one-pass encoder's waits are bounded; when one runs out (forced here: the leader's look-back, or a follower's wait
+    for the leader — ADVICE r03: that wave's tile stays unwritten, so it must report too) the workspace says
+    MH_ERR_TIMEOUT, and mh_encode*, which synchronises anyway, runs the two-pass pair instead — and counts it
+    (mh_last_encode_retries: 1 under the forced timeout, 0 otherwise)."""
     data = text_like(4096 * 40 + 5, 21)
-    os.environ["MH_CHAIN_PROBE"] = "timeout"
+    lib = mhc.lib()
+    ref, ref_bits = oracle.Model.from_table(text_model.table_bytes()).compress(data.tobytes())
+    blob, nbits, idx = text_model.compress(data.tobytes(), chunk_symbols=256)
+    assert (nbits, blob) == (ref_bits, ref) and lib.mh_last_encode_retries() == 0
+    total0 = lib.mh_total_encode_retries()
+    os.environ["MH_CHAIN_PROBE"] = hook
     try:
         rc, _, _, _, _, path = encode(mhc, text_model, data)
         assert rc == mhc.MH_ERR_TIMEOUT and path == ENC_CHAIN
         blob, nbits, idx = text_model.compress(data.tobytes(), chunk_symbols=256)
+        assert lib.mh_last_encode_retries() == 1 and lib.mh_total_encode_retries() == total0 + 1
     finally:
         del os.environ["MH_CHAIN_PROBE"]
-    ref, ref_bits = oracle.Model.from_table(text_model.table_bytes()).compress(data.tobytes())
     assert (nbits, blob) == (ref_bits, ref)
-
+    blob, nbits, idx = text_model.compress(data.tobytes(), chunk_symbols=256)
+    assert (nbits, blob) == (ref_bits, ref) and lib.mh_last_encode_retries() == 0

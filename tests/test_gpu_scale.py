@@ -179,21 +179,23 @@ def _hip_rank(rank, world, port, data, q):
         sharded = importlib.import_module("mhc_amd.sharded")
         lo, hi = sharded.shard_bounds(len(data), world)[rank]
         shard = torch.frombuffer(bytearray(data[lo:hi] + bytes(16)), dtype=torch.uint8)[:hi - lo].cuda()
-        be = sharded.HipBackend(mhc, chunk_symbols=256)
-        res = sharded.compress_shard(be, shard, data[hi - 1] if hi > lo else 0)
-        back = be.decode(res["model"], res["payload"], (res["start_bit"] & 7) + res["nbits"], res["index"], hi - lo)
+        be = sharded.HipBackend(mhc, hi - lo, chunk_symbols=256)
+        res = sharded.compress_shard(be, shard, data[hi - 1] if hi > lo else 0)     # compress_step: what bench.py times
+        back = be.decode(res["model"])
+        assert be.statuses() == (0, 0, 0)
         q.put((rank, lo, hi, res["prev0"], res["start_bit"], res["total_bits"], res["nbits"], res["model"].table_bytes(),
-               res["payload"].cpu().numpy().tobytes(), back.cpu().numpy().tobytes()))
+               res["payload"].cpu().numpy().tobytes(), back.cpu().numpy().tobytes(), be.paths()))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [3_000_000 + 5, 40_000])
+@pytest.mark.parametrize("n", [20_000_000 + 5, 40_000])
 def test_hip_backend_two_ranks_stitch_to_the_reference_stream(mhc, oracle, n):
-    """SURVEY.md 8(e) with the shipped code: two gloo ranks on the one device drive
-    sharded.compress_shard(HipBackend) — local histograms, the all-reduce, identical models, the bit-offset
-    all-gather, pre-shifted shard payloads — and sharded.stitch() of what they return IS the stream the
-    reference writes for the whole input; every shard also decodes from its own buffer."""
+    """SURVEY.md 8(e) with the shipped code: two gloo ranks on the one device drive sharded.compress_shard(HipBackend),
+    i.e. sharded.compress_step — the orchestration `bench.py --gpus N` times: region-mode local histograms, the
+    all-reduce, identical models, the bit-offset all-gather, pre-shifted shard payloads from the region encoder —
+    and sharded.stitch() of what they return IS the stream the reference writes for the whole input; every shard
+    also decodes from its own buffers with the tile decoder.  Which kernels ran is asserted by path code."""
     import importlib
     import torch.multiprocessing as mp
     rng = np.random.default_rng(n)
@@ -220,6 +222,10 @@ def test_hip_backend_two_ranks_stitch_to_the_reference_stream(mhc, oracle, n):
     assert sharded.stitch([(g[4], g[8]) for g in got], ref_bits) == ref[1:]
     for g in got:
         assert g[9] == data[g[1]:g[2]]
+        if n >= 16 << 20:                                   # shards of 8 MiB and more: the fast flow, by path code
+            assert g[10] == (1, 1), g[10]                   # region encoder (priced from the histogram), tile decoder
+        else:
+            assert g[10][0] in (1, 2) and g[10][1] == 2, g[10]   # small shards: the chunk decoder (under 8 MiB)
 
 
 # ------------------------------------------------------------------ histogram counter overflow, many times per workgroup

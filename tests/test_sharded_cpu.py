@@ -32,13 +32,19 @@ class OracleBackend:
     def build_model(self, counts):
         return self.o.Model.from_counts(counts.numpy().astype(np.uint64), 1)
 
+    def merge(self, local, group=None):
+        import importlib
+        sharded = importlib.import_module("mhc_amd.sharded")
+        return sharded.merged_histogram(local.clone(), group)
+
     def payload_bits(self, model, counts):
         lens, _ = model.codes()
-        return int((counts.numpy().astype(np.int64) * np.asarray(lens, dtype=np.int64)).sum())
+        return torch.tensor([int((counts.numpy().astype(np.int64) * np.asarray(lens, dtype=np.int64)).sum())], dtype=torch.int64)
 
-    def encode(self, model, shard, prev0, start_bit=0):
+    def encode(self, model, shard, prev0, start_bit=None):
         # the oracle's compress starts at context ' '; emulate an arbitrary first context by
         # prepending that byte and dropping its code afterwards
+        start_bit = 0 if start_bit is None else int(start_bit.item())
         lens, _ = model.codes()
         if prev0 == 0x20:
             blob, nbits = model.compress(shard)
@@ -50,6 +56,9 @@ class OracleBackend:
         lead = np.zeros(start_bit & 7, dtype=np.uint8)            # pre-shifted like mh_dev_encode_at
         shifted = np.concatenate([lead, bits])
         return np.packbits(shifted).tobytes(), len(shifted), None
+
+    def finish(self, encoded):
+        return encoded
 
 
 def _free_port():
@@ -199,3 +208,42 @@ def test_order2_compact_merge_equals_the_histogram_of_the_whole_input_parity_unp
     for rank, nlive, raw in out:
         assert np.array_equal(np.frombuffer(raw, dtype=np.int64), want), rank
         assert nlive == live
+
+
+def test_bench_self_launch_starts_the_ranks_as_a_child_and_relays_them(tmp_path):
+    """`python bench.py --gpus 2` without a launcher: bench.self_launch builds a torch.distributed.run command of this very
+    script (127.0.0.1, a free port, N ranks) as a CHILD process and relays its output and exit code.  No GPU here: the
+    child is replaced by a stand-in that prints what it was started with."""
+    import importlib.util
+    import json
+    import subprocess
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    class FakeChild:
+        def __init__(self, cmd, env=None, stdout=None, text=None):
+            seen["cmd"], seen["env"] = cmd, env
+            self.stdout = iter(['{"metric": "x", "n_gpus": 2}\n'])
+
+        def wait(self):
+            return 7
+
+    real = subprocess.Popen
+    subprocess.Popen = FakeChild
+    old_argv = sys.argv
+    sys.argv = ["bench.py", "--gpus", "2", "--size", "1048576", "--backend", "gloo"]
+    try:
+        rc = bench.self_launch(2)
+    finally:
+        subprocess.Popen = real
+        sys.argv = old_argv
+    assert rc == 7                                             # the child's exit code comes back
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "2"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "2", "--size", "1048576", "--backend", "gloo"]
+    assert os.path.samefile(cmd[-7], os.path.join(ROOT, "bench.py"))
+    assert seen["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
