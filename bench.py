@@ -183,6 +183,44 @@ def cpu_baseline(mhc, table_bytes, sample, gpu_payload_prefix_check):
     }
 
 
+def index_free_decode(mhc, codec, model, data, nbits, prev0, reps=2):
+    """The real drop-in decode: the reference's `.cm` carries no index (src/coding.cpp:35-59), so the
+    payload the bench just wrote is decoded again with NO index handed in — mh_dev_build_index_fine rebuilds chunk index and
+    fine index from the bits alone, mh_dev_decode_fine decodes from them.  Outside the timed loop, like cpu_baseline;
+    HIP events on the launch stream.  (The index builder waits for the device between its batches of passes.)"""
+    lib, n, dev = codec.lib, codec.n_now, codec.device
+    wsb = int(lib.mh_dev_build_index_workspace(nbits))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    index = torch.zeros(nbits // codec.chunk + 2, dtype=torch.int64, device=dev)   # sized as a caller that does not know n must
+    fine_cap = nbits // 64 + 2
+    fine = torch.zeros(fine_cap, dtype=torch.int32, device=dev)
+    nsym = torch.zeros(1, dtype=torch.int64, device=dev)
+    codec.decoded.zero_()
+    t_idx = t_dec = 0.0
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    for rep in range(reps + 1):
+        e = [ev() for _ in range(3)]
+        e[0].record()
+        codec.check(lib.mh_dev_build_index_fine(model.handle, codec.payload.data_ptr(), nbits, prev0, index.data_ptr(), index.numel(), codec.chunk,
+                                                fine.data_ptr(), fine_cap, nsym.data_ptr(), ws.data_ptr(), wsb, codec.stream()), "mh_dev_build_index_fine")
+        e[1].record()
+        codec.check(lib.mh_dev_decode_fine(model.handle, codec.payload.data_ptr(), nbits, None, codec.decoded.data_ptr(), n, index.data_ptr(), codec.chunk,
+                                           fine.data_ptr(), codec.dec_ws.data_ptr(), codec.dec_ws_bytes, codec.stream()), "mh_dev_decode_fine")
+        e[2].record()
+        torch.cuda.synchronize()
+        if rep:                                        # (the first repetition warms up)
+            t_idx += e[0].elapsed_time(e[1])
+            t_dec += e[1].elapsed_time(e[2])
+    t_idx, t_dec = t_idx / reps, t_dec / reps
+    ok = (int(nsym.item()) == n and lib.mh_dev_status(ws.data_ptr(), codec.stream()) == 0 and lib.mh_dev_status(codec.dec_ws.data_ptr(), codec.stream()) == 0
+          and torch.equal(codec.decoded[:n], data) and torch.equal(index[:codec.nidx], codec.index[:codec.nidx]))
+    return {"index_build_ms": round(t_idx, 3), "decode_ms": round(t_dec, 3), "total_ms": round(t_idx + t_dec, 3),
+            "GBps": round(n / ((t_idx + t_dec) * 1e-3) / 1e9, 2) if t_idx + t_dec > 0 else None,
+            "index_path": int(lib.mh_dev_index_path(ws.data_ptr(), codec.stream())),       # 5 = tiles (fast path), 1 = segment iteration, ...
+            "decode_path": int(lib.mh_dev_decode_path(codec.dec_ws.data_ptr(), codec.stream())),
+            "index_workspace_bytes": wsb, "bit_exact": bool(ok)}
+
+
 def self_launch(n_gpus):
     """`python bench.py --gpus N` without a launcher: this process starts `python -m torch.distributed.run` with N ranks
     of this very command as a CHILD, relays what the ranks print and returns the child's exit code.  It runs before
@@ -197,9 +235,10 @@ def self_launch(n_gpus):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    for line in child.stdout:                         # rank 0's JSON line (and anything else the ranks say)
-        sys.stdout.write(line)
-        sys.stdout.flush()
+    for line in child.stdout:                         # rank 0's JSON line to stdout; whatever else the ranks say (gloo's
+        dst = sys.stdout if line.lstrip().startswith("{") else sys.stderr     # connection chatter) to stderr
+        dst.write(line)
+        dst.flush()
     return child.wait()
 
 
@@ -439,6 +478,8 @@ def main():
         if args.order == 2:
             out["order"] = 2
             out["parity"] = "unpinned: the reference has no order 2; checked against the generalised oracle in tests/test_gpu_order2.py"
+        if world == 1 and args.order == 1 and not os.environ.get("MH_BENCH_NO_INDEX_FREE"):
+            out["decode_index_free"] = index_free_decode(mhc, codec, model, data, nbits, prev0)
         if world == 1 and not args.no_cpu_baseline and args.order == 1:
             sample_n = min(args.cpu_sample, n) & ~(CHUNK - 1)
             sample = data[:sample_n].cpu().numpy().tobytes()

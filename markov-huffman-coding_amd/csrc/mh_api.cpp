@@ -1375,6 +1375,9 @@ static int dev_build_index(const mh_model *m, const uint8_t *d_payload, uint64_t
     p.max_len = uint32_t(m->max_len > 0 ? m->max_len : 1);
     p.fine = m->type == 2 ? nullptr : d_fine;
     p.fine_cap = fine_cap;
+    if (m->type != 2 && m->tile_p) {                         // the tile decoder's tables: the index builder's fast path
+        p.tprim = m->d_tprim; p.tsec = m->d_tsec; p.tP = uint32_t(m->tile_p); p.tH = uint32_t(m->tile_h); p.tnsec = m->tile_nsec;
+    }
     HIP_TRY(mhk::launch_build_index(p, d_ws, static_cast<hipStream_t>(stream)));
     return MH_OK;
 }
@@ -1714,8 +1717,13 @@ int mh_decode_to(const mh_model *m, const uint8_t *payload, uint64_t nbits, uint
     // the fill pass of the index builder also writes the fine index (one uint32 per 64 symbols): the stream then
     // decodes with the tile decoder although it came without any index
     DevBuf d_fine;
-    const uint64_t fine_cap = m->type == 2 ? 0 : nbits / MH_FINE_SYMBOLS + 2;
-    if (fine_cap) HIP_TRY(d_fine.alloc(size_t(fine_cap) * 4));
+    // (nbits / 64 entries = half the payload's size again: a bound for 1-bit codes.  The fine index only buys speed, so a
+    // card that cannot spare it decodes with the chunk decoder instead of failing — ADVICE r03)
+    uint64_t fine_cap = m->type == 2 ? 0 : nbits / MH_FINE_SYMBOLS + 2;
+    if (fine_cap && d_fine.alloc(size_t(fine_cap) * 4) != hipSuccess) {
+        (void)hipGetLastError();
+        fine_cap = 0;
+    }
     {
         DevBuf d_iws;
         const size_t iws = mh_dev_build_index_workspace(nbits);

@@ -169,14 +169,27 @@ struct IdxParams {
     uint64_t nseg;
     uint32_t *fine;               // optional: fine index entries written by the fill passes (see TileParams)
     uint64_t fine_cap;            // entries available at `fine`
+    // the fast path (mh_tile.hip, index_tile_kernel): the tile decoder's tables and, from the workspace, one compact
+    // record per IX_SEG_BITS-bit segment — state = context << 8 | bits past the segment boundary
+    const uint16_t *tprim, *tsec; // null: no tile tables, the fast path is not taken
+    uint32_t tP, tH, tnsec;
+    uint16_t *e16, *s16, *c16;    // end state, the state the segment was entered with, symbols that start in it
+    uint32_t *tile_cnt;           // symbols per tile of 64 segments
+    unsigned long long *tile_base;
+    uint64_t nseg5, ntile5;
 };
+// segments of the fast index path: 512 bits each, 64 of them (one per lane) a tile = 4 KiB of payload; a lane that does
+// not know its start state warms up over the IX_WARM_BITS in front of its segment
+constexpr uint32_t IX_SEG_BITS = 512, IX_TILE_BITS = 64 * IX_SEG_BITS, IX_WARM_BITS = 256;
+constexpr uint16_t IX_INVALID = 0xFFFF;
+hipError_t launch_index_tile(const IdxParams &p, int mode, hipStream_t st);   // mode 0: states and counts, 1: the index entries
 // which encoder a launch_encode* call used (its workspace's status block, bytes 8..11)
 // which decoder ran (status block of the decode workspace, bytes 40..43; mh_dev_decode_path)
 enum { DEC_PATH_NONE = 0, DEC_PATH_TILE = 1, DEC_PATH_CHUNK = 2 };
 hipError_t launch_set_word(uint32_t *d_word, uint32_t v, hipStream_t st);
 enum { ENC_PATH_NONE = 0, ENC_PATH_REGIONS = 1, ENC_PATH_LENGTH_PASS = 2, ENC_PATH_REGIONS_ESCAPES = 3, ENC_PATH_CHAIN = 4 };
 // how launch_build_index arrived at the index (status block bytes 8..11)
-enum { IDX_PATH_NONE = 0, IDX_PATH_SEGMENTS = 1, IDX_PATH_GROUP_MAPS = 2, IDX_PATH_STATE_MAPS = 3, IDX_PATH_WALK = 4 };
+enum { IDX_PATH_NONE = 0, IDX_PATH_SEGMENTS = 1, IDX_PATH_GROUP_MAPS = 2, IDX_PATH_STATE_MAPS = 3, IDX_PATH_WALK = 4, IDX_PATH_TILES = 5 };
 
 // ---- device tree build (mh_tree.hip)
 constexpr int TB_NODE_STRIDE = 520;   // >= 513 nodes per context

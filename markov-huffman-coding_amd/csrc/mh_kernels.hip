@@ -2282,6 +2282,42 @@ __global__ __launch_bounds__(256) void index_fill_kernel(IdxParams p) {
         atomicExch(p.status, MHK_STATUS_CORRUPT);
 }
 
+// ---- the fast path's bookkeeping (mh_tile.hip, index_tile_kernel) ------------------------------------------------------
+// One thread per 512-bit segment: a segment whose entry state (s16) is not the end state of the segment in front is decoded
+// again from that state, with the general tables from memory — after the warm-up pass these are a handful; a pass that
+// finds nothing to do proves the fixed point.
+__global__ __launch_bounds__(256) void index_tile_repair_kernel(IdxParams p, uint32_t iter) {
+    if (iter && p.changed[iter - 1] == 0) return;
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= p.nseg5) return;
+    const uint32_t pe = i ? uint32_t(__hip_atomic_load(&p.e16[i - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : (p.prev0 << 8);
+    const uint32_t s = p.s16[i];
+    if (s == pe && s != IX_INVALID) return;
+    const uint64_t seg_end = (i + 1) * IX_SEG_BITS < p.nbits ? (i + 1) * IX_SEG_BITS : p.nbits;
+    const uint64_t start = st_make(p, pe >> 8, i * IX_SEG_BITS + (pe & 255u));
+    const BitSrc src{p.payload, p.payload_bytes >> 2, p.payload_bytes};
+    const DecTables tabs{p.sec, p.tree, p.P, p.direct, p.H};
+    uint32_t count;
+    bool bad;
+    uint64_t end = walk_segment(p, tabs, src, start, seg_end, count, bad, [](uint32_t, uint32_t, uint64_t) {});
+    if (bad) end = st_make(p, st_ctx(p, end), seg_end);                // (the fill pass reports it if the state was the true one)
+    const uint64_t over = st_pos(p, end) - seg_end;
+    __hip_atomic_store(&p.e16[i], uint16_t((st_ctx(p, end) << 8) | uint32_t(over > 254 ? 254 : over)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    p.c16[i] = uint16_t(count);
+    p.s16[i] = uint16_t(pe == IX_INVALID ? 0xFFFEu : pe);              // (an end state is never IX_INVALID: its overshoot is under 255)
+    atomicAdd(&p.changed[iter], 1u);
+}
+
+// symbols per tile of 64 segments (the input of the prefix sum)
+__global__ __launch_bounds__(256) void index_tile_count_kernel(IdxParams p) {
+    const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t >= p.ntile5) return;
+    uint32_t sum = 0;
+    const uint64_t s0 = t * 64u;
+    for (uint32_t j = 0; j < 64u && s0 + j < p.nseg5; ++j) sum += p.c16[s0 + j];
+    p.tile_cnt[t] = sum;
+}
+
 // ---- streams the segment iteration cannot synchronise: fixed-length codes with context-dependent assignment
 // Two decodes that start in different contexts only ever agree again if they happen to produce the same symbol;
 // with few symbols they may never (ABCABC...: every context has one successor; 0/1 data whose two contexts map
@@ -3289,7 +3325,8 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
 constexpr uint32_t IDX_SEG_BITS = 4096;
 constexpr uint32_t IDX_SEG_BITS_MIN = IDX_SEG_BITS - 64;       // smallest segment any gcd <= 64 gives (workspace sizing)
 constexpr uint32_t IDX_MAX_PASSES = 96;
-struct IdxWs { size_t off_changed, off_end, off_used, off_count, off_start, off_blk, total; uint64_t nseg, nblk; };
+struct IdxWs { size_t off_changed, off_end, off_used, off_count, off_start, off_blk, total; uint64_t nseg, nblk;
+               size_t off_e16, off_s16, off_c16, off_tcnt, off_tbase, off_tblk; uint64_t nseg5, ntile5, ntblk; };
 static IdxWs idx_ws_layout(uint64_t nbits) {
     IdxWs w;
     w.nseg = (nbits + IDX_SEG_BITS_MIN - 1) / IDX_SEG_BITS_MIN;  // capacity; the launch uses the model's segment length
@@ -3302,6 +3339,18 @@ static IdxWs idx_ws_layout(uint64_t nbits) {
     w.off_start = up(w.off_count + size_t(w.nseg) * 4);
     w.off_blk = up(w.off_start + size_t(w.nseg) * 8);
     w.total = up(w.off_blk + size_t(w.nblk + 1) * 8);
+    // the fast path (index_tile_kernel): 6 bytes per 512-bit segment + 12 per tile, in the same space (one path runs at a time)
+    w.nseg5 = (nbits + IX_SEG_BITS - 1) / IX_SEG_BITS;
+    w.ntile5 = (w.nseg5 + 63) / 64;
+    w.ntblk = (w.ntile5 + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    w.off_e16 = w.off_end;
+    w.off_s16 = up(w.off_e16 + size_t(w.nseg5) * 2);
+    w.off_c16 = up(w.off_s16 + size_t(w.nseg5) * 2);
+    w.off_tcnt = up(w.off_c16 + size_t(w.nseg5) * 2);
+    w.off_tbase = up(w.off_tcnt + size_t(w.ntile5) * 4);
+    w.off_tblk = up(w.off_tbase + size_t(w.ntile5) * 8);
+    const size_t total5 = up(w.off_tblk + size_t(w.ntblk + 1) * 8);
+    if (total5 > w.total) w.total = total5;
     return w;
 }
 size_t build_index_workspace_bytes(uint64_t nbits) { return idx_ws_layout(nbits).total; }
@@ -3332,6 +3381,44 @@ hipError_t launch_build_index(IdxParams p, void *d_ws, hipStream_t st) {
     e = once_per_device(&DeviceState::index_ready, [] { return allow_lds(reinterpret_cast<const void *>(build_index_kernel<1>), 131072); });
     if (e != hipSuccess) return e;
     if (p.P > 8) return hipErrorInvalidValue;
+    // ---- the fast path: order 1, every code within the tile decoder's two table levels, no code-length lattice (g == 1),
+    // a stream worth a launch of 256 workgroups.  Given up (and the segment iteration below started from scratch) when more
+    // than an eighth of the segments did not synchronise within their warm-up, or the repairs do not die out.
+    if (p.order != 2 && p.tprim && p.tP == 7 && p.max_len <= p.tP + p.tH && g == 1 && p.nbits >= (1ull << 20) && !getenv("MH_INDEX_NO_TILES")) {
+        IdxParams q = p;
+        q.e16 = reinterpret_cast<uint16_t *>(ws + L.off_e16);
+        q.s16 = reinterpret_cast<uint16_t *>(ws + L.off_s16);
+        q.c16 = reinterpret_cast<uint16_t *>(ws + L.off_c16);
+        q.tile_cnt = reinterpret_cast<uint32_t *>(ws + L.off_tcnt);
+        q.tile_base = reinterpret_cast<unsigned long long *>(ws + L.off_tbase);
+        q.nseg5 = L.nseg5; q.ntile5 = L.ntile5;
+        e = launch_index_tile(q, 0, st);
+        if (e != hipSuccess) return e;
+        const unsigned rgrid = unsigned((q.nseg5 + 255) / 256);
+        bool ok = false;
+        for (uint32_t it = 0; it < 32u && !ok;) {
+            const uint32_t batch_end = it + 2u;
+            for (; it < batch_end; ++it) hipLaunchKernelGGL(index_tile_repair_kernel, dim3(rgrid), dim3(256), 0, st, q, it);
+            unsigned int ch[2] = {1, 1};
+            e = hipMemcpyAsync(ch, q.changed + (it - 2), 8, hipMemcpyDeviceToHost, st);
+            if (e != hipSuccess) return e;
+            e = hipStreamSynchronize(st);
+            if (e != hipSuccess) return e;
+            ok = ch[1] == 0;
+            if (it == 2u && uint64_t(ch[0]) * 8u > q.nseg5) break;       // the warm-up does not synchronise this stream
+        }
+        if (ok) {
+            note_index_path(ws, IDX_PATH_TILES, st);
+            unsigned long long *tblk = reinterpret_cast<unsigned long long *>(ws + L.off_tblk);
+            hipLaunchKernelGGL(index_tile_count_kernel, dim3(unsigned((q.ntile5 + 255) / 256)), dim3(256), 0, st, q);
+            hipLaunchKernelGGL(scan_local_kernel, dim3(unsigned(L.ntblk)), dim3(SCAN_THREADS), 0, st, q.tile_cnt, q.ntile5, q.tile_base, tblk);
+            hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, tblk, L.ntblk, static_cast<const unsigned long long *>(nullptr));
+            hipLaunchKernelGGL(index_scan_add_kernel, dim3(unsigned(L.ntblk)), dim3(SCAN_THREADS), 0, st, q.tile_base, tblk, q.ntile5, L.ntblk, q.n_symbols);
+            return launch_index_tile(q, 1, st);
+        }
+        e = hipMemsetAsync(ws, 0, L.off_end, st);                     // (status and the pass counters: the iteration starts clean)
+        if (e != hipSuccess) return e;
+    }
     const unsigned grid = unsigned((p.nseg + 255) / 256);
     const uint64_t nblk = (p.nseg + SCAN_BLOCK - 1) / SCAN_BLOCK;
     // One instance of the iteration = a first pass from guessed starts + passes that chase the changes.

@@ -416,6 +416,173 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
     }
 }
 
+// ---- index builder, fast path (the reference's streams carry no index, src/coding.cpp:35-59) ---------
+// The segment iteration of mh_kernels.hip gives a lane 4096 bits of payload 512 bytes from its neighbour's and gathers both
+// table levels from L2: three such passes cost ten times the decode they prepare.  Here a WAVE takes 64 ADJACENT segments of
+// IX_SEG_BITS bits — one contiguous 4 KiB of payload, staged through LDS exactly as the tile decoder stages its pieces —
+// with the tile decoder's first level in LDS:
+//   mode 0  a lane that does not know its start state begins IX_WARM_BITS in front of its segment in context ' ' (Huffman
+//           streams re-synchronise within a few symbols), notes the state it ENTERS its segment with (s16), decodes to the
+//           segment's end and leaves the end state (e16) and the number of symbols that start in the segment (c16).
+//           Segment 0 starts exact.  If s16[i] == e16[i - 1] for every i, every state is the true one (induction from
+//           segment 0); the few segments whose warm-up did not synchronise are decoded again from e16[i - 1] by
+//           index_tile_repair_kernel until nothing changes — the same fixed point as the segment iteration's.
+//   mode 1  true start states and symbol numbers (a prefix sum of c16) known: the lanes decode once more and write the
+//           chunk index entry / fine index entry of every symbol whose number is a multiple of chunk_symbols / 64.
+// Both modes cost a decode without output; no second payload pass through L2-gathered first levels.
+constexpr uint32_t IX_TILE_BYTES = IX_TILE_BITS / 8;
+constexpr uint32_t IX_WARM_BYTES = IX_WARM_BITS / 8;
+constexpr uint32_t IX_STAGE_BYTES = IX_TILE_BYTES + IX_WARM_BYTES + 32u;   // + what a code past the end and a window read may touch
+constexpr uint32_t IX_REGION = IX_STAGE_BYTES + 16u;
+static_assert(IX_WARM_BYTES % 16 == 0 && IX_STAGE_BYTES % 16 == 0, "16-byte staging loads");
+
+template <int MODE, int PC>
+__global__ __launch_bounds__(T_THREADS) void index_tile_kernel(IdxParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr uint32_t P = PC, PRIM_BYTES = (256u << P) * 2u;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (uint32_t i = tid; i < PRIM_BYTES / 16u; i += T_THREADS)
+        reinterpret_cast<uint4 *>(smem)[i] = reinterpret_cast<const uint4 *>(p.tprim)[i];
+    __syncthreads();
+    constexpr uint32_t NW = (uint32_t(T_LDS_BYTES) - PRIM_BYTES) / IX_REGION < uint32_t(T_WAVES) ? (uint32_t(T_LDS_BYTES) - PRIM_BYTES) / IX_REGION : uint32_t(T_WAVES);
+    if (wave >= NW) return;                                       // no barrier below this line
+    if (lds_addr_of(smem) != 0u) {                                // the first-level table is addressed from LDS address 0
+        if (tid == 0) atomicExch(p.status, MHK_STATUS_CORRUPT);
+        return;
+    }
+    unsigned char *reg = smem + PRIM_BYTES + wave * IX_REGION;
+    const uint32_t reg_bit0 = lds_addr_of(reg) * 8u;
+    const uint32_t H = p.tH;
+    const __amdgpu_buffer_rsrc_t sec_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.tsec), 0, p.tnsec ? int((p.tnsec + 8u) * 2u) : 0, 0x00020000);
+    const uint64_t vec_total = (p.payload_bytes + 15u) >> 4;     // (the payload is readable up to the next 64-byte boundary: mh.h)
+    const uint64_t cmask = (1ull << p.chunk_shift) - 1ull;
+
+    for (uint64_t t = uint64_t(blockIdx.x) * NW + wave; t < p.ntile5; t += uint64_t(gridDim.x) * NW) {
+        // ---- stage [tile start - warm-up, tile end + slack): bits reversed inside every byte, as the tile decoder does
+        const uint64_t sb = t ? t * IX_TILE_BYTES - IX_WARM_BYTES : 0ull;      // first staged payload byte (16-byte aligned)
+        {
+            const uint4 *src = reinterpret_cast<const uint4 *>(p.payload + sb);
+            const uint64_t left = vec_total - (sb >> 4);
+            const uint32_t nvec = left < IX_STAGE_BYTES / 16u ? uint32_t(left) : IX_STAGE_BYTES / 16u;
+            for (uint32_t i = lane; i < IX_REGION / 16u; i += 64u) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (i < nvec) {
+                    v = src[i];
+                    v.x = __builtin_bswap32(__builtin_bitreverse32(v.x));
+                    v.y = __builtin_bswap32(__builtin_bitreverse32(v.y));
+                    v.z = __builtin_bswap32(__builtin_bitreverse32(v.z));
+                    v.w = __builtin_bswap32(__builtin_bitreverse32(v.w));
+                }
+                *reinterpret_cast<uint4 *>(reg + i * 16u) = v;
+            }
+        }
+        // LDS operations of one wave execute in order: the reads below see the writes above
+        const uint64_t seg = t * 64u + lane;
+        const uint64_t b0 = seg * IX_SEG_BITS;
+        const bool active = b0 < p.nbits;
+        const uint64_t e0 = b0 + IX_SEG_BITS < p.nbits ? b0 + IX_SEG_BITS : p.nbits;
+        const uint32_t qb0 = reg_bit0 + uint32_t(b0 - sb * 8u), qe0 = reg_bit0 + uint32_t((active ? e0 : b0) - sb * 8u);
+        uint32_t q, ctx, k = 0;
+        bool crossed = false, done = !active, bad = false;
+        uint32_t S = IX_INVALID, E = IX_INVALID;
+        uint64_t base = 0;
+        uint32_t want_e = 0, want_c = 0;
+        if (MODE == 0) {
+            const bool exact = seg == 0;
+            ctx = exact ? p.prev0 : 0x20u;
+            q = exact ? qb0 : qb0 - IX_WARM_BITS;                 // (seg >= 1: the warm-up lies inside the staged piece)
+        } else {
+            // true start state: the end state of the segment in front (segment 0: the stream's start)
+            uint32_t pe = p.prev0 << 8;
+            if (active && seg) pe = p.e16[seg - 1];
+            ctx = pe >> 8;
+            q = qb0 + (pe & 255u);
+            want_e = active ? p.e16[seg] : 0u;
+            want_c = active ? p.c16[seg] : 0u;
+            uint32_t inc = want_c;                                // exclusive prefix of the lanes' symbol counts
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if (lane >= uint32_t(d)) inc += o; }
+            base = p.tile_base[t] + (inc - want_c);
+            crossed = true;
+        }
+        bool overflow = false;
+#pragma unroll 1
+        for (uint32_t it = 0; it < IX_SEG_BITS + IX_WARM_BITS + 64u; ++it) {      // (a symbol takes at least one bit)
+            if (!done) {
+                if (!crossed && q >= qb0) { crossed = true; S = (ctx << 8) | (q - qb0); }
+                if (crossed && q >= qe0) { done = true; E = (ctx << 8) | (q - qe0); }
+            }
+            if (!__any(!done)) break;
+            if (MODE == 1 && !done) {
+                const uint64_t g = base + k;
+                const uint64_t pos = sb * 8u + (q - reg_bit0);
+                if ((g & cmask) == 0) {
+                    const uint64_t ci = g >> p.chunk_shift;
+                    if (ci < p.index_cap) p.index[ci] = (uint64_t(ctx) << 56) | pos; else overflow = true;
+                }
+                if (p.fine && (g & ((1u << T_SUB_SHIFT) - 1u)) == 0 && (g >> T_SUB_SHIFT) < p.fine_cap)
+                    p.fine[g >> T_SUB_SHIFT] = (ctx << 24) | (uint32_t(pos) & FINE_POS_MASK);
+            }
+            const lds_u32 *wp = lds_ptr<uint32_t>((q >> 3) & ~3u);
+            const uint32_t win = __builtin_amdgcn_alignbit(wp[1], wp[0], q);
+            const uint32_t e = *lds_ptr<uint16_t>(((win << 1) & ((2u << P) - 2u)) | (ctx << (P + 1)));
+            const uint32_t idx2 = (e << (H + 1)) | ((win >> (P - 1)) & ((2u << H) - 2u));
+            const uint32_t e2 = uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(sec_rsrc, int(idx2), 0, 0)));
+            const uint32_t ef = e > e2 ? e : e2;
+            uint32_t len = __builtin_amdgcn_ubfe(ef, 8, 5);
+            if (!(ef & DEC16_LEAF) || len == 0) {                 // an empty context's null entry (a guess may run into one)
+                len = 1;
+                bad = bad || crossed;
+            } else {
+                ctx = ef & 255u;
+            }
+            if (!done) {
+                q += len;
+                k += crossed ? 1u : 0u;
+            }
+        }
+        if (MODE == 0) {
+            if (active) {
+                p.s16[seg] = uint16_t(bad || !done ? IX_INVALID : S);
+                p.e16[seg] = uint16_t(E);
+                p.c16[seg] = uint16_t(k);
+            }
+        } else {
+            if (overflow) atomicExch(p.status, MHK_STATUS_CAPACITY);
+            // with true start states a null entry, an end state or a count that differs from the converged ones, or a stream
+            // that does not end exactly at nbits (src/coding.cpp:124,158) means the stream does not belong to this table
+            const bool last = active && e0 == p.nbits;
+            if (active && (bad || !done || E != want_e || k != want_c || (last && (E & 255u) != 0u))) atomicExch(p.status, MHK_STATUS_CORRUPT);
+        }
+    }
+}
+
+hipError_t launch_index_tile(const IdxParams &p, int mode, hipStream_t st) {
+    if (p.tP != 7 || !p.tprim || p.order == 2) return hipErrorInvalidValue;
+    void (*kern)(IdxParams) = mode == 0 ? index_tile_kernel<0, 7> : index_tile_kernel<1, 7>;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    {
+        static std::mutex mu;
+        static std::vector<std::pair<const void *, int>> done;
+        std::lock_guard<std::mutex> lock(mu);
+        const std::pair<const void *, int> key(reinterpret_cast<const void *>(kern), dev);
+        if (std::find(done.begin(), done.end(), key) == done.end()) {
+            e = hipFuncSetAttribute(key.first, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
+            if (e != hipSuccess) return e;
+            done.push_back(key);
+        }
+    }
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    const uint64_t want = (p.ntile5 + T_WAVES - 1) / T_WAVES;
+    const unsigned grid = unsigned(want < 1 ? 1 : (want > uint64_t(cus) ? uint64_t(cus) : want));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(T_THREADS), T_LDS_BYTES, st, p);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------
 
 size_t decode_tile_workspace_extra() { return 64; }

@@ -223,7 +223,9 @@ def test_hip_backend_two_ranks_stitch_to_the_reference_stream(mhc, oracle, n):
     for g in got:
         assert g[9] == data[g[1]:g[2]]
         if n >= 16 << 20:                                   # shards of 8 MiB and more: the fast flow, by path code
-            assert g[10] == (1, 1), g[10]                   # region encoder (priced from the histogram), tile decoder
+            # region encoder priced from the histogram (3: its escape variant ran too — 20 MB of Zipf has codes over 12 bits
+            # in its rare contexts), tile decoder
+            assert g[10] in ((1, 1), (3, 1)), g[10]
         else:
             assert g[10][0] in (1, 2) and g[10][1] == 2, g[10]   # small shards: the chunk decoder (under 8 MiB)
 
