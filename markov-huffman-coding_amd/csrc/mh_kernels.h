@@ -177,12 +177,14 @@ struct IdxParams {
     uint32_t *tile_cnt;           // symbols per tile of 64 segments
     unsigned long long *tile_base;
     uint64_t nseg5, ntile5;
+    uint32_t warm_bits;           // mode 0: bits in front of its segment a lane starts at (<= IX_WARM_BITS_MAX)
+    uint32_t iter;                // mode 2: the pass counter the repaired segments are added to
 };
 // segments of the fast index path: 512 bits each, 64 of them (one per lane) a tile = 4 KiB of payload; a lane that does
-// not know its start state warms up over the IX_WARM_BITS in front of its segment
-constexpr uint32_t IX_SEG_BITS = 512, IX_TILE_BITS = 64 * IX_SEG_BITS, IX_WARM_BITS = 256;
+// not know its start state warms up over the bits in front of its segment (IdxParams::warm_bits)
+constexpr uint32_t IX_SEG_BITS = 512, IX_TILE_BITS = 64 * IX_SEG_BITS, IX_WARM_BITS_MAX = 512;
 constexpr uint16_t IX_INVALID = 0xFFFF;
-hipError_t launch_index_tile(const IdxParams &p, int mode, hipStream_t st);   // mode 0: states and counts, 1: the index entries
+hipError_t launch_index_tile(const IdxParams &p, int mode, hipStream_t st);   // mode 0: states and counts, 1: the index entries, 2: repairs
 // which encoder a launch_encode* call used (its workspace's status block, bytes 8..11)
 // which decoder ran (status block of the decode workspace, bytes 40..43; mh_dev_decode_path)
 enum { DEC_PATH_NONE = 0, DEC_PATH_TILE = 1, DEC_PATH_CHUNK = 2 };

@@ -2287,7 +2287,6 @@ __global__ __launch_bounds__(256) void index_fill_kernel(IdxParams p) {
 // again from that state, with the general tables from memory — after the warm-up pass these are a handful; a pass that
 // finds nothing to do proves the fixed point.
 __global__ __launch_bounds__(256) void index_tile_repair_kernel(IdxParams p, uint32_t iter) {
-    if (iter && p.changed[iter - 1] == 0) return;
     const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= p.nseg5) return;
     const uint32_t pe = i ? uint32_t(__hip_atomic_load(&p.e16[i - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : (p.prev0 << 8);
@@ -3392,20 +3391,34 @@ hipError_t launch_build_index(IdxParams p, void *d_ws, hipStream_t st) {
         q.tile_cnt = reinterpret_cast<uint32_t *>(ws + L.off_tcnt);
         q.tile_base = reinterpret_cast<unsigned long long *>(ws + L.off_tbase);
         q.nseg5 = L.nseg5; q.ntile5 = L.ntile5;
+        // The warm-up is short (streams of an iid-like source re-synchronise within a few symbols: 16 GiB of Zipf leaves one
+        // segment in 10^5 for the repairs), and what it misses is repaired by passes that only touch the tiles in need: text, whose
+        // decode depends on the context at every step, needs one or two such passes.
+        q.warm_bits = 128;
+        if (const char *wv = getenv("MH_INDEX_WARM_BITS")) { const int v = atoi(wv); if (v >= 16 && v <= int(IX_WARM_BITS_MAX)) q.warm_bits = uint32_t(v); }
         e = launch_index_tile(q, 0, st);
         if (e != hipSuccess) return e;
         const unsigned rgrid = unsigned((q.nseg5 + 255) / 256);
         bool ok = false;
-        for (uint32_t it = 0; it < 32u && !ok;) {
-            const uint32_t batch_end = it + 2u;
-            for (; it < batch_end; ++it) hipLaunchKernelGGL(index_tile_repair_kernel, dim3(rgrid), dim3(256), 0, st, q, it);
-            unsigned int ch[2] = {1, 1};
-            e = hipMemcpyAsync(ch, q.changed + (it - 2), 8, hipMemcpyDeviceToHost, st);
+        unsigned int prev_dirty = ~0u;
+        for (uint32_t it = 0; it < 32u && !ok; ++it) {
+            // many segments to repair: by tiles (the fast kernel skips tiles in order); a handful: one thread each
+            if (prev_dirty > 4096u) {
+                q.iter = it;
+                e = launch_index_tile(q, 2, st);
+                if (e != hipSuccess) return e;
+            } else {
+                hipLaunchKernelGGL(index_tile_repair_kernel, dim3(rgrid), dim3(256), 0, st, q, it);
+            }
+            unsigned int dirty = 1;
+            e = hipMemcpyAsync(&dirty, q.changed + it, 4, hipMemcpyDeviceToHost, st);
             if (e != hipSuccess) return e;
             e = hipStreamSynchronize(st);
             if (e != hipSuccess) return e;
-            ok = ch[1] == 0;
-            if (it == 2u && uint64_t(ch[0]) * 8u > q.nseg5) break;       // the warm-up does not synchronise this stream
+            ok = dirty == 0;
+            // repairs that do not die out (fewer than a quarter fewer per pass): the stream does not synchronise this way
+            if (it >= 2u && dirty > 4096u && uint64_t(dirty) * 4u > uint64_t(prev_dirty) * 3u) break;
+            prev_dirty = dirty;
         }
         if (ok) {
             note_index_path(ws, IDX_PATH_TILES, st);

@@ -425,16 +425,18 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
 //           streams re-synchronise within a few symbols), notes the state it ENTERS its segment with (s16), decodes to the
 //           segment's end and leaves the end state (e16) and the number of symbols that start in the segment (c16).
 //           Segment 0 starts exact.  If s16[i] == e16[i - 1] for every i, every state is the true one (induction from
-//           segment 0); the few segments whose warm-up did not synchronise are decoded again from e16[i - 1] by
-//           index_tile_repair_kernel until nothing changes — the same fixed point as the segment iteration's.
+//           segment 0); segments whose warm-up did not synchronise are decoded again from e16[i - 1] — mode 2, the same
+//           kernel over the tiles that hold such a segment (a wave whose 64 segments are all in order skips its tile), or
+//           index_tile_repair_kernel (one thread per segment, general tables) once only a handful are left — until a
+//           pass finds nothing to do: the same fixed point as the segment iteration's.
 //   mode 1  true start states and symbol numbers (a prefix sum of c16) known: the lanes decode once more and write the
 //           chunk index entry / fine index entry of every symbol whose number is a multiple of chunk_symbols / 64.
 // Both modes cost a decode without output; no second payload pass through L2-gathered first levels.
 constexpr uint32_t IX_TILE_BYTES = IX_TILE_BITS / 8;
-constexpr uint32_t IX_WARM_BYTES = IX_WARM_BITS / 8;
-constexpr uint32_t IX_STAGE_BYTES = IX_TILE_BYTES + IX_WARM_BYTES + 32u;   // + what a code past the end and a window read may touch
+constexpr uint32_t IX_STAGE_LEAD = IX_WARM_BITS_MAX / 8;                    // bytes staged in front of the tile: the longest warm-up
+constexpr uint32_t IX_STAGE_BYTES = IX_TILE_BYTES + IX_STAGE_LEAD + 32u;   // + what a code past the end and a window read may touch
 constexpr uint32_t IX_REGION = IX_STAGE_BYTES + 16u;
-static_assert(IX_WARM_BYTES % 16 == 0 && IX_STAGE_BYTES % 16 == 0, "16-byte staging loads");
+static_assert(IX_STAGE_LEAD % 16 == 0 && IX_STAGE_BYTES % 16 == 0, "16-byte staging loads");
 
 template <int MODE, int PC>
 __global__ __launch_bounds__(T_THREADS) void index_tile_kernel(IdxParams p) {
@@ -459,8 +461,25 @@ __global__ __launch_bounds__(T_THREADS) void index_tile_kernel(IdxParams p) {
     const uint64_t cmask = (1ull << p.chunk_shift) - 1ull;
 
     for (uint64_t t = uint64_t(blockIdx.x) * NW + wave; t < p.ntile5; t += uint64_t(gridDim.x) * NW) {
+        const uint64_t sb = t ? t * IX_TILE_BYTES - IX_STAGE_LEAD : 0ull;      // first staged payload byte (16-byte aligned)
+        const uint64_t seg = t * 64u + lane;
+        const uint64_t b0 = seg * IX_SEG_BITS;
+        const bool active = b0 < p.nbits;
+        const uint64_t e0 = b0 + IX_SEG_BITS < p.nbits ? b0 + IX_SEG_BITS : p.nbits;
+        const uint32_t qb0 = reg_bit0 + uint32_t(b0 - sb * 8u), qe0 = reg_bit0 + uint32_t((active ? e0 : b0) - sb * 8u);
+        uint32_t pe2 = 0;
+        bool dirty = false;
+        if (MODE == 2) {
+            // a segment is in order when it was entered in the state its predecessor ended in; a tile of such segments is skipped
+            pe2 = p.prev0 << 8;
+            if (active && seg) pe2 = __hip_atomic_load(&p.e16[seg - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t s = active ? uint32_t(p.s16[seg]) : pe2;
+            dirty = active && (s != pe2 || s == IX_INVALID);
+            const unsigned long long dm = __ballot(dirty);
+            if (dm == 0ull) continue;
+            if (lane == 0) atomicAdd(&p.changed[p.iter], uint32_t(__popcll(dm)));
+        }
         // ---- stage [tile start - warm-up, tile end + slack): bits reversed inside every byte, as the tile decoder does
-        const uint64_t sb = t ? t * IX_TILE_BYTES - IX_WARM_BYTES : 0ull;      // first staged payload byte (16-byte aligned)
         {
             const uint4 *src = reinterpret_cast<const uint4 *>(p.payload + sb);
             const uint64_t left = vec_total - (sb >> 4);
@@ -478,20 +497,20 @@ __global__ __launch_bounds__(T_THREADS) void index_tile_kernel(IdxParams p) {
             }
         }
         // LDS operations of one wave execute in order: the reads below see the writes above
-        const uint64_t seg = t * 64u + lane;
-        const uint64_t b0 = seg * IX_SEG_BITS;
-        const bool active = b0 < p.nbits;
-        const uint64_t e0 = b0 + IX_SEG_BITS < p.nbits ? b0 + IX_SEG_BITS : p.nbits;
-        const uint32_t qb0 = reg_bit0 + uint32_t(b0 - sb * 8u), qe0 = reg_bit0 + uint32_t((active ? e0 : b0) - sb * 8u);
         uint32_t q, ctx, k = 0;
         bool crossed = false, done = !active, bad = false;
         uint32_t S = IX_INVALID, E = IX_INVALID;
         uint64_t base = 0;
-        uint32_t want_e = 0, want_c = 0;
-        if (MODE == 0) {
+        uint32_t want_e = 0, want_c = 0, next_entry = 0;
+        if (MODE == 2) {
+            ctx = pe2 >> 8;
+            q = qb0 + (pe2 & 255u);
+            crossed = true;
+            done = !dirty;
+        } else if (MODE == 0) {
             const bool exact = seg == 0;
             ctx = exact ? p.prev0 : 0x20u;
-            q = exact ? qb0 : qb0 - IX_WARM_BITS;                 // (seg >= 1: the warm-up lies inside the staged piece)
+            q = exact ? qb0 : qb0 - p.warm_bits;                  // (seg >= 1: the warm-up lies inside the staged piece)
         } else {
             // true start state: the end state of the segment in front (segment 0: the stream's start)
             uint32_t pe = p.prev0 << 8;
@@ -504,25 +523,26 @@ __global__ __launch_bounds__(T_THREADS) void index_tile_kernel(IdxParams p) {
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if (lane >= uint32_t(d)) inc += o; }
             base = p.tile_base[t] + (inc - want_c);
+            next_entry = (0u - uint32_t(base)) & ((1u << T_SUB_SHIFT) - 1u);
             crossed = true;
         }
         bool overflow = false;
 #pragma unroll 1
-        for (uint32_t it = 0; it < IX_SEG_BITS + IX_WARM_BITS + 64u; ++it) {      // (a symbol takes at least one bit)
+        for (uint32_t it = 0; it < IX_SEG_BITS + IX_WARM_BITS_MAX + 64u; ++it) {  // (a symbol takes at least one bit)
             if (!done) {
                 if (!crossed && q >= qb0) { crossed = true; S = (ctx << 8) | (q - qb0); }
                 if (crossed && q >= qe0) { done = true; E = (ctx << 8) | (q - qe0); }
             }
             if (!__any(!done)) break;
-            if (MODE == 1 && !done) {
+            if (MODE == 1 && !done && k == next_entry) {          // symbol number base + k is a multiple of 64 (chunks are multiples of 64 symbols)
+                next_entry += 1u << T_SUB_SHIFT;
                 const uint64_t g = base + k;
                 const uint64_t pos = sb * 8u + (q - reg_bit0);
                 if ((g & cmask) == 0) {
                     const uint64_t ci = g >> p.chunk_shift;
                     if (ci < p.index_cap) p.index[ci] = (uint64_t(ctx) << 56) | pos; else overflow = true;
                 }
-                if (p.fine && (g & ((1u << T_SUB_SHIFT) - 1u)) == 0 && (g >> T_SUB_SHIFT) < p.fine_cap)
-                    p.fine[g >> T_SUB_SHIFT] = (ctx << 24) | (uint32_t(pos) & FINE_POS_MASK);
+                if (p.fine && (g >> T_SUB_SHIFT) < p.fine_cap) p.fine[g >> T_SUB_SHIFT] = (ctx << 24) | (uint32_t(pos) & FINE_POS_MASK);
             }
             const lds_u32 *wp = lds_ptr<uint32_t>((q >> 3) & ~3u);
             const uint32_t win = __builtin_amdgcn_alignbit(wp[1], wp[0], q);
@@ -548,6 +568,14 @@ __global__ __launch_bounds__(T_THREADS) void index_tile_kernel(IdxParams p) {
                 p.e16[seg] = uint16_t(E);
                 p.c16[seg] = uint16_t(k);
             }
+        } else if (MODE == 2) {
+            if (dirty) {
+                // (a state that runs into a null entry is parked at the segment's end: if it was the true one the fill pass says so)
+                if (bad || !done) E = (ctx << 8);
+                __hip_atomic_store(&p.e16[seg], uint16_t(E), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                p.c16[seg] = uint16_t(k);
+                p.s16[seg] = uint16_t(pe2 == IX_INVALID ? 0xFFFEu : pe2);
+            }
         } else {
             if (overflow) atomicExch(p.status, MHK_STATUS_CAPACITY);
             // with true start states a null entry, an end state or a count that differs from the converged ones, or a stream
@@ -560,7 +588,8 @@ __global__ __launch_bounds__(T_THREADS) void index_tile_kernel(IdxParams p) {
 
 hipError_t launch_index_tile(const IdxParams &p, int mode, hipStream_t st) {
     if (p.tP != 7 || !p.tprim || p.order == 2) return hipErrorInvalidValue;
-    void (*kern)(IdxParams) = mode == 0 ? index_tile_kernel<0, 7> : index_tile_kernel<1, 7>;
+    if (mode == 0 && (p.warm_bits == 0 || p.warm_bits > IX_WARM_BITS_MAX)) return hipErrorInvalidValue;
+    void (*kern)(IdxParams) = mode == 0 ? index_tile_kernel<0, 7> : mode == 1 ? index_tile_kernel<1, 7> : index_tile_kernel<2, 7>;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;

@@ -190,7 +190,7 @@ def test_stream_without_an_index_decodes_through_the_tile_decoder(mhc, oracle):
         out = m.decompress(blob)
     finally:
         del os.environ["MH_DECODE_PATH"]
-    assert mhc.lib().mh_last_index_path() == 1
+    assert mhc.lib().mh_last_index_path() == 5              # the index builder's fast path (tiles of 512-bit segments)
     assert out == data.tobytes()
     # device level: the fine index the builder wrote equals the one the encoder writes
     lib = mhc.lib()

@@ -18,7 +18,7 @@ torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
 mhc = entry.load_package()
 bench.CHUNK = 1024
-data = bench.generate(a.kind, a.size, 2, 0, dev)
+data = bench.generate(a.kind, a.size, {"zipf": 2, "uniform": 3, "text": 1}[a.kind], 0, dev)
 codec = bench.Codec(mhc, a.size, dev)
 codec.histogram(data, 0x20)
 model = codec.build_model()
@@ -35,5 +35,7 @@ for it in range(3):
     rc = lib.mh_dev_build_index(model.handle, codec.payload.data_ptr(), nbits, 0x20, idx2.data_ptr(), idx2.numel(), bench.CHUNK,
                                 nsym.data_ptr(), ws.data_ptr(), ws_bytes, codec.stream())
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print("build_index rc=%d  %.2f ms  (%.1f GB/s of payload)  symbols %d  index equal %s" %
-          (rc, dt * 1e3, nbits / 8 / dt / 1e9, int(nsym.item()), bool(torch.equal(idx2, codec.index))), flush=True)
+    changed = ws[64:64 + 16 * 4].view(torch.int32).tolist()          # the pass counters: segments (re)decoded per pass
+    print("build_index rc=%d  %.2f ms  (%.1f GB/s of payload)  symbols %d  index equal %s  path %d  changed per pass %s" %
+          (rc, dt * 1e3, nbits / 8 / dt / 1e9, int(nsym.item()), bool(torch.equal(idx2, codec.index)),
+           lib.mh_dev_index_path(ws.data_ptr(), codec.stream()), changed), flush=True)
