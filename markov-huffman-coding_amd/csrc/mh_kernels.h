@@ -178,13 +178,15 @@ struct IdxParams {
     unsigned long long *tile_base;
     uint64_t nseg5, ntile5;
     uint32_t warm_bits;           // mode 0: bits in front of its segment a lane starts at (<= IX_WARM_BITS_MAX)
-    uint32_t iter;                // mode 2: the pass counter the repaired segments are added to
+    uint32_t *dirty_list;         // segments to repair (index_tile_dirty_kernel); dirty_cap entries
+    uint32_t dirty_cap;
+    uint32_t iter;                // the pass counter (changed[iter]) the listed segments are counted in
 };
-// segments of the fast index path: 512 bits each, 64 of them (one per lane) a tile = 4 KiB of payload; a lane that does
+// segments of the fast index path: 256 bits each, 128 of them (two per lane) a tile = 4 KiB of payload; a lane that does
 // not know its start state warms up over the bits in front of its segment (IdxParams::warm_bits)
-constexpr uint32_t IX_SEG_BITS = 512, IX_TILE_BITS = 64 * IX_SEG_BITS, IX_WARM_BITS_MAX = 512;
+constexpr uint32_t IX_SEG_BITS = 256, IX_TILE_SEGS = 128, IX_TILE_BITS = IX_TILE_SEGS * IX_SEG_BITS, IX_WARM_BITS_MAX = 512;
 constexpr uint16_t IX_INVALID = 0xFFFF;
-hipError_t launch_index_tile(const IdxParams &p, int mode, hipStream_t st);   // mode 0: states and counts, 1: the index entries, 2: repairs
+hipError_t launch_index_tile(const IdxParams &p, int mode, hipStream_t st);   // mode 0: states and counts, 1: the index entries
 // which encoder a launch_encode* call used (its workspace's status block, bytes 8..11)
 // which decoder ran (status block of the decode workspace, bytes 40..43; mh_dev_decode_path)
 enum { DEC_PATH_NONE = 0, DEC_PATH_TILE = 1, DEC_PATH_CHUNK = 2 };

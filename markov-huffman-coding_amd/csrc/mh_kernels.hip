@@ -2283,38 +2283,69 @@ __global__ __launch_bounds__(256) void index_fill_kernel(IdxParams p) {
 }
 
 // ---- the fast path's bookkeeping (mh_tile.hip, index_tile_kernel) ------------------------------------------------------
-// One thread per 512-bit segment: a segment whose entry state (s16) is not the end state of the segment in front is decoded
-// again from that state, with the general tables from memory — after the warm-up pass these are a handful; a pass that
-// finds nothing to do proves the fixed point.
-__global__ __launch_bounds__(256) void index_tile_repair_kernel(IdxParams p, uint32_t iter) {
-    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= p.nseg5) return;
+// A segment is in order when it was entered in the state its predecessor ended in.  The others are listed (one thread per
+// segment; a wave appends its lanes' numbers with one atomic) ...
+__global__ __launch_bounds__(256) void index_tile_dirty_kernel(IdxParams p) {
+    // every wave owns a strided share of the segments, counts its share first and reserves room for all of it with ONE
+    // atomic (an atomic per 64 segments on one address took 10 ms with one segment in seven to list), then lists it
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave = (uint64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6, nwaves = (uint64_t(gridDim.x) * blockDim.x) >> 6;
+    auto is_dirty = [&](uint64_t i) -> bool {
+        if (i >= p.nseg5) return false;
+        const uint32_t pe = i ? uint32_t(p.e16[i - 1]) : (p.prev0 << 8);
+        const uint32_t s = p.s16[i];
+        return s != pe || s == IX_INVALID;
+    };
+    uint32_t mine = 0;
+    for (uint64_t i0 = wave * 64u; i0 < p.nseg5; i0 += nwaves * 64u) mine += uint32_t(__popcll(__ballot(is_dirty(i0 + lane))));
+    if (mine == 0) return;                                       // (wave-uniform)
+    uint32_t at = 0;
+    if (lane == 0) at = atomicAdd(&p.changed[p.iter], mine);
+    at = uint32_t(__builtin_amdgcn_readfirstlane(int(at)));
+    for (uint64_t i0 = wave * 64u; i0 < p.nseg5; i0 += nwaves * 64u) {
+        const bool d = is_dirty(i0 + lane);
+        const unsigned long long m = __ballot(d);
+        if (d) {
+            const uint32_t slot = at + uint32_t(__popcll(m & ((1ull << lane) - 1ull)));
+            if (slot < p.dirty_cap) p.dirty_list[slot] = uint32_t(i0 + lane);
+        }
+        at += uint32_t(__popcll(m));
+    }
+}
+
+// ... and decoded again from that state with the general tables from memory, one thread per listed segment (after the
+// warm-up pass: one segment in 10^5 for an iid-like source, one in seven for text).  A pass that lists nothing proves the
+// fixed point.
+__global__ __launch_bounds__(256) void index_tile_repair_kernel(IdxParams p, uint32_t count) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    const uint64_t i = p.dirty_list[j];
     const uint32_t pe = i ? uint32_t(__hip_atomic_load(&p.e16[i - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : (p.prev0 << 8);
-    const uint32_t s = p.s16[i];
-    if (s == pe && s != IX_INVALID) return;
     const uint64_t seg_end = (i + 1) * IX_SEG_BITS < p.nbits ? (i + 1) * IX_SEG_BITS : p.nbits;
     const uint64_t start = st_make(p, pe >> 8, i * IX_SEG_BITS + (pe & 255u));
     const BitSrc src{p.payload, p.payload_bytes >> 2, p.payload_bytes};
     const DecTables tabs{p.sec, p.tree, p.P, p.direct, p.H};
-    uint32_t count;
+    uint32_t count_sym;
     bool bad;
-    uint64_t end = walk_segment(p, tabs, src, start, seg_end, count, bad, [](uint32_t, uint32_t, uint64_t) {});
+    uint64_t end = walk_segment(p, tabs, src, start, seg_end, count_sym, bad, [](uint32_t, uint32_t, uint64_t) {});
     if (bad) end = st_make(p, st_ctx(p, end), seg_end);                // (the fill pass reports it if the state was the true one)
     const uint64_t over = st_pos(p, end) - seg_end;
     __hip_atomic_store(&p.e16[i], uint16_t((st_ctx(p, end) << 8) | uint32_t(over > 254 ? 254 : over)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    p.c16[i] = uint16_t(count);
+    p.c16[i] = uint16_t(count_sym);
     p.s16[i] = uint16_t(pe == IX_INVALID ? 0xFFFEu : pe);              // (an end state is never IX_INVALID: its overshoot is under 255)
-    atomicAdd(&p.changed[iter], 1u);
 }
 
-// symbols per tile of 64 segments (the input of the prefix sum)
+// symbols per tile of IX_TILE_SEGS segments (the input of the prefix sum): one wave per tile
 __global__ __launch_bounds__(256) void index_tile_count_kernel(IdxParams p) {
-    const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    const uint64_t t = (uint64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
     if (t >= p.ntile5) return;
     uint32_t sum = 0;
-    const uint64_t s0 = t * 64u;
-    for (uint32_t j = 0; j < 64u && s0 + j < p.nseg5; ++j) sum += p.c16[s0 + j];
-    p.tile_cnt[t] = sum;
+    const uint64_t s0 = t * IX_TILE_SEGS;
+    for (uint32_t j = lane; j < IX_TILE_SEGS; j += 64u) if (s0 + j < p.nseg5) sum += p.c16[s0 + j];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+    if (lane == 0) p.tile_cnt[t] = sum;
 }
 
 // ---- streams the segment iteration cannot synchronise: fixed-length codes with context-dependent assignment
@@ -3325,7 +3356,7 @@ constexpr uint32_t IDX_SEG_BITS = 4096;
 constexpr uint32_t IDX_SEG_BITS_MIN = IDX_SEG_BITS - 64;       // smallest segment any gcd <= 64 gives (workspace sizing)
 constexpr uint32_t IDX_MAX_PASSES = 96;
 struct IdxWs { size_t off_changed, off_end, off_used, off_count, off_start, off_blk, total; uint64_t nseg, nblk;
-               size_t off_e16, off_s16, off_c16, off_tcnt, off_tbase, off_tblk; uint64_t nseg5, ntile5, ntblk; };
+               size_t off_e16, off_s16, off_c16, off_dirty, off_tcnt, off_tbase, off_tblk; uint64_t nseg5, ntile5, ntblk, dirty_cap; };
 static IdxWs idx_ws_layout(uint64_t nbits) {
     IdxWs w;
     w.nseg = (nbits + IDX_SEG_BITS_MIN - 1) / IDX_SEG_BITS_MIN;  // capacity; the launch uses the model's segment length
@@ -3338,14 +3369,17 @@ static IdxWs idx_ws_layout(uint64_t nbits) {
     w.off_start = up(w.off_count + size_t(w.nseg) * 4);
     w.off_blk = up(w.off_start + size_t(w.nseg) * 8);
     w.total = up(w.off_blk + size_t(w.nblk + 1) * 8);
-    // the fast path (index_tile_kernel): 6 bytes per 512-bit segment + 12 per tile, in the same space (one path runs at a time)
+    // the fast path (index_tile_kernel): 6 bytes per 256-bit segment, a list of the segments to repair (a quarter of them at
+    // most: beyond that the stream does not synchronise this way) and 12 bytes per tile, in the same space (one path runs at a time)
     w.nseg5 = (nbits + IX_SEG_BITS - 1) / IX_SEG_BITS;
-    w.ntile5 = (w.nseg5 + 63) / 64;
+    w.ntile5 = (w.nseg5 + IX_TILE_SEGS - 1) / IX_TILE_SEGS;
     w.ntblk = (w.ntile5 + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    w.dirty_cap = w.nseg5 / 4 + 64;
     w.off_e16 = w.off_end;
     w.off_s16 = up(w.off_e16 + size_t(w.nseg5) * 2);
     w.off_c16 = up(w.off_s16 + size_t(w.nseg5) * 2);
-    w.off_tcnt = up(w.off_c16 + size_t(w.nseg5) * 2);
+    w.off_dirty = up(w.off_c16 + size_t(w.nseg5) * 2);
+    w.off_tcnt = up(w.off_dirty + size_t(w.dirty_cap) * 4);
     w.off_tbase = up(w.off_tcnt + size_t(w.ntile5) * 4);
     w.off_tblk = up(w.off_tbase + size_t(w.ntile5) * 8);
     const size_t total5 = up(w.off_tblk + size_t(w.ntblk + 1) * 8);
@@ -3383,7 +3417,7 @@ hipError_t launch_build_index(IdxParams p, void *d_ws, hipStream_t st) {
     // ---- the fast path: order 1, every code within the tile decoder's two table levels, no code-length lattice (g == 1),
     // a stream worth a launch of 256 workgroups.  Given up (and the segment iteration below started from scratch) when more
     // than an eighth of the segments did not synchronise within their warm-up, or the repairs do not die out.
-    if (p.order != 2 && p.tprim && p.tP == 7 && p.max_len <= p.tP + p.tH && g == 1 && p.nbits >= (1ull << 20) && !getenv("MH_INDEX_NO_TILES")) {
+    if (p.order != 2 && p.tprim && p.tP == 7 && p.max_len <= p.tP + p.tH && g == 1 && p.nbits >= (1ull << 20) && L.nseg5 < 0xFFFFFFFFull && !getenv("MH_INDEX_NO_TILES")) {
         IdxParams q = p;
         q.e16 = reinterpret_cast<uint16_t *>(ws + L.off_e16);
         q.s16 = reinterpret_cast<uint16_t *>(ws + L.off_s16);
@@ -3391,39 +3425,43 @@ hipError_t launch_build_index(IdxParams p, void *d_ws, hipStream_t st) {
         q.tile_cnt = reinterpret_cast<uint32_t *>(ws + L.off_tcnt);
         q.tile_base = reinterpret_cast<unsigned long long *>(ws + L.off_tbase);
         q.nseg5 = L.nseg5; q.ntile5 = L.ntile5;
-        // The warm-up is short (streams of an iid-like source re-synchronise within a few symbols: 16 GiB of Zipf leaves one
-        // segment in 10^5 for the repairs), and what it misses is repaired by passes that only touch the tiles in need: text, whose
-        // decode depends on the context at every step, needs one or two such passes.
-        q.warm_bits = 128;
-        if (const char *wv = getenv("MH_INDEX_WARM_BITS")) { const int v = atoi(wv); if (v >= 16 && v <= int(IX_WARM_BITS_MAX)) q.warm_bits = uint32_t(v); }
-        e = launch_index_tile(q, 0, st);
-        if (e != hipSuccess) return e;
-        const unsigned rgrid = unsigned((q.nseg5 + 255) / 256);
+        // The warm-up is short: streams of an iid-like source re-synchronise within a few symbols (4 GiB of Zipf: 256 bits leave
+        // one segment in 10^5 for the repairs), text, whose decode depends on the context at every step, leaves one in seven —
+        // listed and repaired one thread each, which costs a fraction of a pass either way.  More than a quarter to repair:
+        // once more with the longest warm-up; still more: the stream does not synchronise this way.
+        q.dirty_list = reinterpret_cast<uint32_t *>(ws + L.off_dirty);
+        q.dirty_cap = uint32_t(L.dirty_cap < 0xFFFFFFFFull ? L.dirty_cap : 0xFFFFFFFFull);
+        const uint64_t dwant = (q.nseg5 + 255) / 256;
+        const unsigned dgrid = unsigned(dwant < 2048 ? dwant : 2048);
         bool ok = false;
-        unsigned int prev_dirty = ~0u;
-        for (uint32_t it = 0; it < 32u && !ok; ++it) {
-            // many segments to repair: by tiles (the fast kernel skips tiles in order); a handful: one thread each
-            if (prev_dirty > 4096u) {
+        uint32_t it = 0;
+        q.warm_bits = 256;
+        if (const char *wv = getenv("MH_INDEX_WARM_BITS")) { const int v = atoi(wv); if (v >= 16 && v <= int(IX_WARM_BITS_MAX)) q.warm_bits = uint32_t(v); }
+        for (int attempt = 0; attempt < 2 && !ok; ++attempt) {
+            e = launch_index_tile(q, 0, st);
+            if (e != hipSuccess) return e;
+            unsigned int prev_dirty = ~0u;
+            bool hopeless = false;
+            for (const uint32_t it_end = it + 24u; it < it_end && !ok && !hopeless; ++it) {
                 q.iter = it;
-                e = launch_index_tile(q, 2, st);
+                hipLaunchKernelGGL(index_tile_dirty_kernel, dim3(dgrid), dim3(256), 0, st, q);
+                unsigned int dirty = 1;
+                e = hipMemcpyAsync(&dirty, q.changed + it, 4, hipMemcpyDeviceToHost, st);
                 if (e != hipSuccess) return e;
-            } else {
-                hipLaunchKernelGGL(index_tile_repair_kernel, dim3(rgrid), dim3(256), 0, st, q, it);
+                e = hipStreamSynchronize(st);
+                if (e != hipSuccess) return e;
+                ok = dirty == 0;
+                // too many to list, or repairs that do not die out (fewer than a quarter fewer per pass)
+                hopeless = dirty > q.dirty_cap || (dirty > 4096u && prev_dirty != ~0u && uint64_t(dirty) * 4u > uint64_t(prev_dirty) * 3u);
+                prev_dirty = dirty;
+                if (!ok && !hopeless) hipLaunchKernelGGL(index_tile_repair_kernel, dim3((dirty + 255u) / 256u), dim3(256), 0, st, q, dirty);
             }
-            unsigned int dirty = 1;
-            e = hipMemcpyAsync(&dirty, q.changed + it, 4, hipMemcpyDeviceToHost, st);
-            if (e != hipSuccess) return e;
-            e = hipStreamSynchronize(st);
-            if (e != hipSuccess) return e;
-            ok = dirty == 0;
-            // repairs that do not die out (fewer than a quarter fewer per pass): the stream does not synchronise this way
-            if (it >= 2u && dirty > 4096u && uint64_t(dirty) * 4u > uint64_t(prev_dirty) * 3u) break;
-            prev_dirty = dirty;
+            if (!ok && q.warm_bits < IX_WARM_BITS_MAX) q.warm_bits = IX_WARM_BITS_MAX; else break;
         }
         if (ok) {
             note_index_path(ws, IDX_PATH_TILES, st);
             unsigned long long *tblk = reinterpret_cast<unsigned long long *>(ws + L.off_tblk);
-            hipLaunchKernelGGL(index_tile_count_kernel, dim3(unsigned((q.ntile5 + 255) / 256)), dim3(256), 0, st, q);
+            hipLaunchKernelGGL(index_tile_count_kernel, dim3(unsigned((q.ntile5 + 3) / 4)), dim3(256), 0, st, q);
             hipLaunchKernelGGL(scan_local_kernel, dim3(unsigned(L.ntblk)), dim3(SCAN_THREADS), 0, st, q.tile_cnt, q.ntile5, q.tile_base, tblk);
             hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, tblk, L.ntblk, static_cast<const unsigned long long *>(nullptr));
             hipLaunchKernelGGL(index_scan_add_kernel, dim3(unsigned(L.ntblk)), dim3(SCAN_THREADS), 0, st, q.tile_base, tblk, q.ntile5, L.ntblk, q.n_symbols);

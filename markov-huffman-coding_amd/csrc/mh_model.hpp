@@ -86,6 +86,7 @@ class BitWriter;
 // One context = one Huffman table (huffman_table in the reference).
 class ContextCoder {
 public:
+    ContextCoder() { lut_.fill(-1); }  // (a context nobody built has no nodes: its LUT must say so — found by the UBSan fuzz)
     void clear();
     bool empty() const { return root_ < 0; }
     void build_from_counts(const uint64_t *counts256);

@@ -418,30 +418,31 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
 
 // ---- index builder, fast path (the reference's streams carry no index, src/coding.cpp:35-59) ---------
 // The segment iteration of mh_kernels.hip gives a lane 4096 bits of payload 512 bytes from its neighbour's and gathers both
-// table levels from L2: three such passes cost ten times the decode they prepare.  Here a WAVE takes 64 ADJACENT segments of
-// IX_SEG_BITS bits — one contiguous 4 KiB of payload, staged through LDS exactly as the tile decoder stages its pieces —
-// with the tile decoder's first level in LDS:
-//   mode 0  a lane that does not know its start state begins IX_WARM_BITS in front of its segment in context ' ' (Huffman
+// table levels from L2: three such passes cost ten times the decode they prepare.  Here a WAVE takes 128 ADJACENT segments of
+// IX_SEG_BITS bits (two per lane) — one contiguous 4 KiB of payload, staged through LDS exactly as the tile decoder stages
+// its pieces — with the tile decoder's first level in LDS:
+//   mode 0  a lane that does not know its start state begins warm_bits in front of its segment in context ' ' (Huffman
 //           streams re-synchronise within a few symbols), notes the state it ENTERS its segment with (s16), decodes to the
 //           segment's end and leaves the end state (e16) and the number of symbols that start in the segment (c16).
 //           Segment 0 starts exact.  If s16[i] == e16[i - 1] for every i, every state is the true one (induction from
-//           segment 0); segments whose warm-up did not synchronise are decoded again from e16[i - 1] — mode 2, the same
-//           kernel over the tiles that hold such a segment (a wave whose 64 segments are all in order skips its tile), or
-//           index_tile_repair_kernel (one thread per segment, general tables) once only a handful are left — until a
-//           pass finds nothing to do: the same fixed point as the segment iteration's.
+//           segment 0); the segments whose warm-up did not synchronise are listed (index_tile_dirty_kernel) and decoded
+//           again from e16[i - 1] (index_tile_repair_kernel: one thread each, general tables) until a pass lists none:
+//           the same fixed point as the segment iteration's.
 //   mode 1  true start states and symbol numbers (a prefix sum of c16) known: the lanes decode once more and write the
 //           chunk index entry / fine index entry of every symbol whose number is a multiple of chunk_symbols / 64.
-// Both modes cost a decode without output; no second payload pass through L2-gathered first levels.
+// Both modes cost a decode without output; no payload pass through L2-gathered first levels.
 constexpr uint32_t IX_TILE_BYTES = IX_TILE_BITS / 8;
 constexpr uint32_t IX_STAGE_LEAD = IX_WARM_BITS_MAX / 8;                    // bytes staged in front of the tile: the longest warm-up
 constexpr uint32_t IX_STAGE_BYTES = IX_TILE_BYTES + IX_STAGE_LEAD + 32u;   // + what a code past the end and a window read may touch
 constexpr uint32_t IX_REGION = IX_STAGE_BYTES + 16u;
-static_assert(IX_STAGE_LEAD % 16 == 0 && IX_STAGE_BYTES % 16 == 0, "16-byte staging loads");
+static_assert(IX_STAGE_LEAD % 16 == 0 && IX_STAGE_BYTES % 16 == 0 && IX_TILE_BYTES % 16 == 0, "16-byte staging loads");
+static_assert(IX_TILE_SEGS == 128, "two segments per lane");
 
 template <int MODE, int PC>
 __global__ __launch_bounds__(T_THREADS) void index_tile_kernel(IdxParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr uint32_t P = PC, PRIM_BYTES = (256u << P) * 2u;
+    constexpr int K = 2;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     for (uint32_t i = tid; i < PRIM_BYTES / 16u; i += T_THREADS)
         reinterpret_cast<uint4 *>(smem)[i] = reinterpret_cast<const uint4 *>(p.tprim)[i];
@@ -462,23 +463,6 @@ __global__ __launch_bounds__(T_THREADS) void index_tile_kernel(IdxParams p) {
 
     for (uint64_t t = uint64_t(blockIdx.x) * NW + wave; t < p.ntile5; t += uint64_t(gridDim.x) * NW) {
         const uint64_t sb = t ? t * IX_TILE_BYTES - IX_STAGE_LEAD : 0ull;      // first staged payload byte (16-byte aligned)
-        const uint64_t seg = t * 64u + lane;
-        const uint64_t b0 = seg * IX_SEG_BITS;
-        const bool active = b0 < p.nbits;
-        const uint64_t e0 = b0 + IX_SEG_BITS < p.nbits ? b0 + IX_SEG_BITS : p.nbits;
-        const uint32_t qb0 = reg_bit0 + uint32_t(b0 - sb * 8u), qe0 = reg_bit0 + uint32_t((active ? e0 : b0) - sb * 8u);
-        uint32_t pe2 = 0;
-        bool dirty = false;
-        if (MODE == 2) {
-            // a segment is in order when it was entered in the state its predecessor ended in; a tile of such segments is skipped
-            pe2 = p.prev0 << 8;
-            if (active && seg) pe2 = __hip_atomic_load(&p.e16[seg - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t s = active ? uint32_t(p.s16[seg]) : pe2;
-            dirty = active && (s != pe2 || s == IX_INVALID);
-            const unsigned long long dm = __ballot(dirty);
-            if (dm == 0ull) continue;
-            if (lane == 0) atomicAdd(&p.changed[p.iter], uint32_t(__popcll(dm)));
-        }
         // ---- stage [tile start - warm-up, tile end + slack): bits reversed inside every byte, as the tile decoder does
         {
             const uint4 *src = reinterpret_cast<const uint4 *>(p.payload + sb);
@@ -497,99 +481,125 @@ __global__ __launch_bounds__(T_THREADS) void index_tile_kernel(IdxParams p) {
             }
         }
         // LDS operations of one wave execute in order: the reads below see the writes above
-        uint32_t q, ctx, k = 0;
-        bool crossed = false, done = !active, bad = false;
-        uint32_t S = IX_INVALID, E = IX_INVALID;
-        uint64_t base = 0;
-        uint32_t want_e = 0, want_c = 0, next_entry = 0;
-        if (MODE == 2) {
-            ctx = pe2 >> 8;
-            q = qb0 + (pe2 & 255u);
-            crossed = true;
-            done = !dirty;
-        } else if (MODE == 0) {
-            const bool exact = seg == 0;
-            ctx = exact ? p.prev0 : 0x20u;
-            q = exact ? qb0 : qb0 - p.warm_bits;                  // (seg >= 1: the warm-up lies inside the staged piece)
-        } else {
-            // true start state: the end state of the segment in front (segment 0: the stream's start)
-            uint32_t pe = p.prev0 << 8;
-            if (active && seg) pe = p.e16[seg - 1];
-            ctx = pe >> 8;
-            q = qb0 + (pe & 255u);
-            want_e = active ? p.e16[seg] : 0u;
-            want_c = active ? p.c16[seg] : 0u;
-            uint32_t inc = want_c;                                // exclusive prefix of the lanes' symbol counts
+        // lane l takes segments l and l + 64 of the tile: two independent streams per lane hide each other's lookups.
+        // The loop is branch-free: "entered its segment" and "done" are comparisons of the position (a finished stream stands
+        // still), the entry state is caught by a select, everything a lane carries lives in vector registers.
+        uint64_t seg[K], base[K];
+        uint32_t qb0[K], qe0[K], q[K], ctx[K], k[K], S[K], badv[K], want_e[K], want_c[K], next_entry[K];
+        bool active[K], last[K];
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if (lane >= uint32_t(d)) inc += o; }
-            base = p.tile_base[t] + (inc - want_c);
-            next_entry = (0u - uint32_t(base)) & ((1u << T_SUB_SHIFT) - 1u);
-            crossed = true;
+        for (int j = 0; j < K; ++j) {
+            seg[j] = t * IX_TILE_SEGS + uint32_t(j) * 64u + lane;
+            const uint64_t b0 = seg[j] * IX_SEG_BITS;
+            active[j] = b0 < p.nbits;
+            const uint64_t e0 = b0 + IX_SEG_BITS < p.nbits ? b0 + IX_SEG_BITS : p.nbits;
+            last[j] = active[j] && e0 == p.nbits;
+            qb0[j] = reg_bit0 + uint32_t(b0 - sb * 8u);
+            qe0[j] = active[j] ? reg_bit0 + uint32_t(e0 - sb * 8u) : qb0[j];       // (not active: done at once)
+            k[j] = 0; S[j] = IX_INVALID; badv[j] = 0; base[j] = 0; want_e[j] = want_c[j] = next_entry[j] = 0;
+            if (MODE == 0) {
+                const bool exact = seg[j] == 0;
+                ctx[j] = exact ? p.prev0 : 0x20u;
+                const uint32_t room = qb0[j] - reg_bit0;          // (tile 0 has nothing staged in front of it)
+                q[j] = exact || !active[j] ? qb0[j] : qb0[j] - (p.warm_bits < room ? p.warm_bits : room);
+            } else {
+                // true start state: the end state of the segment in front (segment 0: the stream's start)
+                uint32_t pe = p.prev0 << 8;
+                if (active[j] && seg[j]) pe = p.e16[seg[j] - 1];
+                ctx[j] = pe >> 8;
+                q[j] = active[j] ? qb0[j] + (pe & 255u) : qb0[j];
+                want_e[j] = active[j] ? p.e16[seg[j]] : 0u;
+                want_c[j] = active[j] ? p.c16[seg[j]] : 0u;
+            }
         }
-        bool overflow = false;
+        if (MODE == 1) {                                          // symbol numbers: the tile's base + the counts of the segments in front
+            uint64_t run = p.tile_base[t];
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                uint32_t inc = want_c[j];
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if (lane >= uint32_t(d)) inc += o; }
+                base[j] = run + (inc - want_c[j]);
+                next_entry[j] = (0u - uint32_t(base[j])) & ((1u << T_SUB_SHIFT) - 1u);
+                run += __shfl(inc, 63);
+            }
+        }
+        uint32_t overflow = 0;
 #pragma unroll 1
         for (uint32_t it = 0; it < IX_SEG_BITS + IX_WARM_BITS_MAX + 64u; ++it) {  // (a symbol takes at least one bit)
-            if (!done) {
-                if (!crossed && q >= qb0) { crossed = true; S = (ctx << 8) | (q - qb0); }
-                if (crossed && q >= qe0) { done = true; E = (ctx << 8) | (q - qe0); }
-            }
-            if (!__any(!done)) break;
-            if (MODE == 1 && !done && k == next_entry) {          // symbol number base + k is a multiple of 64 (chunks are multiples of 64 symbols)
-                next_entry += 1u << T_SUB_SHIFT;
-                const uint64_t g = base + k;
-                const uint64_t pos = sb * 8u + (q - reg_bit0);
-                if ((g & cmask) == 0) {
-                    const uint64_t ci = g >> p.chunk_shift;
-                    if (ci < p.index_cap) p.index[ci] = (uint64_t(ctx) << 56) | pos; else overflow = true;
+            if (!__any(q[0] < qe0[0] || q[1] < qe0[1])) break;
+            if (MODE == 1) {
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    if (q[j] < qe0[j] && k[j] == next_entry[j]) { // symbol number base + k is a multiple of 64 (chunks are multiples of 64 symbols)
+                        next_entry[j] += 1u << T_SUB_SHIFT;
+                        const uint64_t g = base[j] + k[j];
+                        const uint64_t pos = sb * 8u + (q[j] - reg_bit0);
+                        if ((g & cmask) == 0) {
+                            const uint64_t ci = g >> p.chunk_shift;
+                            if (ci < p.index_cap) p.index[ci] = (uint64_t(ctx[j]) << 56) | pos; else overflow = 1;
+                        }
+                        if (p.fine && (g >> T_SUB_SHIFT) < p.fine_cap) p.fine[g >> T_SUB_SHIFT] = (ctx[j] << 24) | (uint32_t(pos) & FINE_POS_MASK);
+                    }
                 }
-                if (p.fine && (g >> T_SUB_SHIFT) < p.fine_cap) p.fine[g >> T_SUB_SHIFT] = (ctx << 24) | (uint32_t(pos) & FINE_POS_MASK);
             }
-            const lds_u32 *wp = lds_ptr<uint32_t>((q >> 3) & ~3u);
-            const uint32_t win = __builtin_amdgcn_alignbit(wp[1], wp[0], q);
-            const uint32_t e = *lds_ptr<uint16_t>(((win << 1) & ((2u << P) - 2u)) | (ctx << (P + 1)));
-            const uint32_t idx2 = (e << (H + 1)) | ((win >> (P - 1)) & ((2u << H) - 2u));
-            const uint32_t e2 = uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(sec_rsrc, int(idx2), 0, 0)));
-            const uint32_t ef = e > e2 ? e : e2;
-            uint32_t len = __builtin_amdgcn_ubfe(ef, 8, 5);
-            if (!(ef & DEC16_LEAF) || len == 0) {                 // an empty context's null entry (a guess may run into one)
-                len = 1;
-                bad = bad || crossed;
+            uint32_t w0[K], w1[K], win[K], e[K], e2[K];
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const lds_u32 *wp = lds_ptr<uint32_t>((q[j] >> 3) & ~3u);
+                w0[j] = wp[0];
+                w1[j] = wp[1];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                win[j] = __builtin_amdgcn_alignbit(w1[j], w0[j], q[j]);
+                e[j] = *lds_ptr<uint16_t>(((win[j] << 1) & ((2u << P) - 2u)) | (ctx[j] << (P + 1)));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const uint32_t idx2 = (e[j] << (H + 1)) | ((win[j] >> (P - 1)) & ((2u << H) - 2u));
+                e2[j] = uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(sec_rsrc, int(idx2), 0, 0)));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const bool in = q[j] >= qb0[j], go = q[j] < qe0[j];     // inside its segment (or past it); still decoding
+                if (MODE == 0) S[j] = (in && S[j] == IX_INVALID) ? ((ctx[j] << 8) | (q[j] - qb0[j])) : S[j];
+                const uint32_t ef = e[j] > e2[j] ? e[j] : e2[j];
+                const uint32_t len = __builtin_amdgcn_ubfe(ef, 8, 5);
+                const bool ok = (ef & DEC16_LEAF) && len != 0;            // (no: an empty context's null entry — a guess may run into one)
+                badv[j] |= (in && go && !ok) ? 1u : 0u;
+                ctx[j] = (ok && go) ? (ef & 255u) : ctx[j];
+                q[j] += go ? (ok ? len : 1u) : 0u;
+                k[j] += (in && go) ? 1u : 0u;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            if (!active[j]) continue;
+            const bool done = q[j] >= qe0[j];
+            const uint32_t E = (ctx[j] << 8) | (q[j] - qe0[j]);
+            if (MODE == 0) {
+                if (S[j] == IX_INVALID && done) S[j] = E;         // (a code that spans the whole segment: entered and left at once)
+                p.s16[seg[j]] = uint16_t(badv[j] || !done ? IX_INVALID : S[j]);
+                p.e16[seg[j]] = uint16_t(done ? E : IX_INVALID);
+                p.c16[seg[j]] = uint16_t(k[j]);
             } else {
-                ctx = ef & 255u;
-            }
-            if (!done) {
-                q += len;
-                k += crossed ? 1u : 0u;
+                // with true start states a null entry, an end state or a count that differs from the converged ones, or a stream
+                // that does not end exactly at nbits (src/coding.cpp:124,158) means the stream does not belong to this table
+                if (badv[j] || !done || E != want_e[j] || k[j] != want_c[j] || (last[j] && (E & 255u) != 0u)) atomicExch(p.status, MHK_STATUS_CORRUPT);
             }
         }
-        if (MODE == 0) {
-            if (active) {
-                p.s16[seg] = uint16_t(bad || !done ? IX_INVALID : S);
-                p.e16[seg] = uint16_t(E);
-                p.c16[seg] = uint16_t(k);
-            }
-        } else if (MODE == 2) {
-            if (dirty) {
-                // (a state that runs into a null entry is parked at the segment's end: if it was the true one the fill pass says so)
-                if (bad || !done) E = (ctx << 8);
-                __hip_atomic_store(&p.e16[seg], uint16_t(E), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                p.c16[seg] = uint16_t(k);
-                p.s16[seg] = uint16_t(pe2 == IX_INVALID ? 0xFFFEu : pe2);
-            }
-        } else {
-            if (overflow) atomicExch(p.status, MHK_STATUS_CAPACITY);
-            // with true start states a null entry, an end state or a count that differs from the converged ones, or a stream
-            // that does not end exactly at nbits (src/coding.cpp:124,158) means the stream does not belong to this table
-            const bool last = active && e0 == p.nbits;
-            if (active && (bad || !done || E != want_e || k != want_c || (last && (E & 255u) != 0u))) atomicExch(p.status, MHK_STATUS_CORRUPT);
-        }
+        if (MODE == 1 && overflow) atomicExch(p.status, MHK_STATUS_CAPACITY);
     }
 }
 
 hipError_t launch_index_tile(const IdxParams &p, int mode, hipStream_t st) {
     if (p.tP != 7 || !p.tprim || p.order == 2) return hipErrorInvalidValue;
     if (mode == 0 && (p.warm_bits == 0 || p.warm_bits > IX_WARM_BITS_MAX)) return hipErrorInvalidValue;
-    void (*kern)(IdxParams) = mode == 0 ? index_tile_kernel<0, 7> : mode == 1 ? index_tile_kernel<1, 7> : index_tile_kernel<2, 7>;
+    void (*kern)(IdxParams) = mode == 0 ? index_tile_kernel<0, 7> : index_tile_kernel<1, 7>;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
