@@ -1157,7 +1157,12 @@ __global__ __launch_bounds__(E_THREADS) void enc_chain_kernel(ChainParams cp) {
 // whole workgroup then flushes with coalesced stores.  No second read of the input, no per-tile offsets in
 // HBM: traffic is the algorithmic (1 + r) n.  Two workgroup barriers per round are the price.
 // Only for models without escape codes (max length <= 12); others take the three-kernel path.
-constexpr int R_IMG_WORDS = E_WAVES * (E_STAGE_BITS / 32) + 16;          // 16 pieces of <= 12288 bits + carry + slack
+// the image: all the LDS the codeword table leaves.  A round whose bits fit HALF of it alternates between the halves with its
+// neighbours (one barrier per round, see enc_region_kernel); any other round takes the whole image (two barriers).
+constexpr int R_IMG_WORDS = ((163840 - 131072 - 128) / 4) & ~7;             // 8160 words >= 16 pieces of <= 12288 bits + carry + slack
+constexpr int R_HALF_WORDS = R_IMG_WORDS / 2;
+constexpr uint32_t R_HALF_CAP_BITS = uint32_t(R_HALF_WORDS - 8) * 32u;    // (the carried partial word and the flush's 16-byte groups stay inside)
+static_assert(R_IMG_WORDS >= E_WAVES * (E_STAGE_BITS / 32) + 16 && R_HALF_WORDS % 4 == 0, "image size");
 constexpr int REGION_LDS_BYTES = 131072 + R_IMG_WORDS * 4 + 128;           // + the waves' piece counts, two rounds' worth
 constexpr uint64_t HIST_WS_MAGIC = 0x4D48525247303031ull;                 // "MHRRG001"
 
@@ -1332,6 +1337,7 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
     // cleared) its 16-byte group during the flush, and is OR-ed back into word 0 behind the next round's first
     // barrier: no thread ever reads a word that another thread's clear may touch in the same phase.
     uint32_t carry = 0;
+    bool prev_half = false;                      // the previous round used a half of the image (see round())
 
     auto fetch = [&](uint64_t r) -> LaneIn {
         const uint64_t v = v0 + r * E_THREADS + tid;
@@ -1347,11 +1353,12 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
     // the workgroup stores image words [0, nfull) to output dwords gbase + j (coalesced, MSB-first bytes) and
     // clears them; four words per lane: one 16-byte LDS read, one 16-byte clear, one 16-byte store.  The group
     // that holds word nfull (the partial tail) is visited too: its reader returns that word.
+    uint32_t *imgr = img;                        // the image of the round at hand: the whole one, or one of its halves
     auto flush = [&](uint32_t nfull) -> uint32_t {
         uint32_t tail = 0;
         for (uint32_t j = tid * 4u; j <= nfull; j += E_THREADS * 4u) {
-            const uint4 w = *reinterpret_cast<const uint4 *>(img + j);
-            *reinterpret_cast<uint4 *>(img + j) = make_uint4(0, 0, 0, 0);
+            const uint4 w = *reinterpret_cast<const uint4 *>(imgr + j);
+            *reinterpret_cast<uint4 *>(imgr + j) = make_uint4(0, 0, 0, 0);
             const uint32_t v[4] = {__builtin_bswap32(w.x), __builtin_bswap32(w.y), __builtin_bswap32(w.z), __builtin_bswap32(w.w)};
             if (j + 4u <= nfull && !(j == 0 && seam_first) && gbase + j + 4u <= rp.cap_words) {
                 struct __attribute__((packed, aligned(4))) Q4 { uint32_t a, b, c, d; };
@@ -1451,17 +1458,29 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
         constexpr bool FULL = decltype(full_c)::value, ESC = ESCK;
         uint32_t *sbr = sb + (r & 1u) * 16u, *sbn = sb + ((r + 1u) & 1u) * 16u;
         ENC_STAMP(0);                            // flush of the previous round (+ loop overhead)
-        __syncthreads();
-        ENC_STAMP(1);                            // barrier 1
-        if (carry) { atomicOr(&img[0], carry); carry = 0; }      // the previous round's partial word (every clear is behind the barrier)
-        // bits of the round in front of this wave / in the whole round: every row of 16 lanes scans the 16 counts
+        // [r4] ONE barrier per round where the rounds fit half the image.  The first barrier orders two things: the waves'
+        // bit counts of this round (written before the previous round's second barrier: visible without it) and "every wave
+        // has flushed round r - 1" before anything of round r is deposited.  With round r in the OTHER half of the image than
+        // round r - 1 the second needs no barrier: half (r & 1) was last flushed for round r - 2, and every wave finished that
+        // flush before it reached round r - 1's second barrier, which lies behind us.  A round that does not fit a half (more
+        // than ~7.9 bits per symbol: uniform bytes), the round behind one, the first round and the escape kernel keep both.
         uint32_t cs = sbr[lane & 15u];
+        if (r == 0 || !prev_half) { __syncthreads(); cs = sbr[lane & 15u]; }
+        ENC_STAMP(1);                            // barrier 1 (if any)
+        // bits of the round in front of this wave / in the whole round: every row of 16 lanes scans the 16 counts
         cs += uint32_t(__builtin_amdgcn_update_dpp(0, int(cs), 0x111, 0xF, 0xF, true));      // row_shr:1
         cs += uint32_t(__builtin_amdgcn_update_dpp(0, int(cs), 0x112, 0xF, 0xF, true));      // row_shr:2
         cs += uint32_t(__builtin_amdgcn_update_dpp(0, int(cs), 0x114, 0xF, 0xF, true));      // row_shr:4
         cs += uint32_t(__builtin_amdgcn_update_dpp(0, int(cs), 0x118, 0xF, 0xF, true));      // row_shr:8
         const uint32_t tot = uint32_t(__builtin_amdgcn_readlane(int(cs), 15));
         const uint32_t pre = wave ? uint32_t(__builtin_amdgcn_readlane(int(cs), int(wave) - 1)) : 0u;
+        // (workgroup-uniform: cur and tot are) this round in a half of its own?  If the previous one was not, its flush of the
+        // whole image may still be running: the barrier above was taken (prev_half false) and the halves are free again.
+        const bool half = !ESC && cur + tot <= R_HALF_CAP_BITS;
+        if (!half && r != 0 && prev_half) __syncthreads();       // a whole-image round behind a half round: wait for that flush
+        imgr = half ? img + (r & 1u) * uint32_t(R_HALF_WORDS) : img;
+        prev_half = half;
+        if (carry) { atomicOr(&imgr[0], carry); carry = 0; }     // the previous round's partial word (the words it lands in are free: see above)
         const uint32_t exc = pre + P.inc - P.L;  // bits of the round in front of this lane
         const uint64_t off = (v0 + r * E_THREADS + tid) * E_VEC;
         const uint32_t nvalid = FULL ? uint32_t(E_VEC) : nvalid0;
@@ -1475,11 +1494,11 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
             if (!ESC || !P.esc) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    if (P.gl[q]) deposit<false>(img, P.g[q] << (64u - P.gl[q]), o, 0, 0);
+                    if (P.gl[q]) deposit<false>(imgr, P.g[q] << (64u - P.gl[q]), o, 0, 0);
                     o += P.gl[q];
                 }
             } else {
-                region_escape_deposit(p.len8, p.code64, tab, img, x0, pb0, nvalid, o);
+                region_escape_deposit(p.len8, p.code64, tab, imgr, x0, pb0, nvalid, o);
             }
         } else {
             // more bits than the image holds (only a model with many codes far over 12 bits can do that): one
@@ -3437,6 +3456,25 @@ hipError_t launch_build_index(IdxParams p, void *d_ws, hipStream_t st) {
         uint32_t it = 0;
         q.warm_bits = 256;
         if (const char *wv = getenv("MH_INDEX_WARM_BITS")) { const int v = atoi(wv); if (v >= 16 && v <= int(IX_WARM_BITS_MAX)) q.warm_bits = uint32_t(v); }
+        else if (q.ntile5 >= 4096) {
+            // how long a warm-up this stream needs is a property of the source: a sample (the first 1/64 of the tiles) with 128
+            // bits tells — where that leaves under 2 % of the segments to repair the short warm-up serves the whole stream
+            // (the pass decodes warm-up + segment: 1.5 instead of 2 segment lengths)
+            IdxParams sq = q;
+            sq.ntile5 = q.ntile5 / 64;
+            sq.nseg5 = sq.ntile5 * IX_TILE_SEGS;
+            sq.warm_bits = 128;
+            sq.iter = it;
+            e = launch_index_tile(sq, 0, st);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(index_tile_dirty_kernel, dim3(256), dim3(256), 0, st, sq);
+            unsigned int dirty = ~0u;
+            e = hipMemcpyAsync(&dirty, q.changed + it, 4, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) return e;
+            ++it;
+            if (uint64_t(dirty) * 50u < sq.nseg5) q.warm_bits = 128;
+        }
         for (int attempt = 0; attempt < 2 && !ok; ++attempt) {
             e = launch_index_tile(q, 0, st);
             if (e != hipSuccess) return e;
