@@ -35,6 +35,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+COPY_CEILING_GBS = 6290.0  # same guide: what a float4 copy kernel reaches
 CHUNK = int(os.environ.get("MH_BENCH_CHUNK", "0"))   # 0: 1024 symbols, 256 below 2 GiB per GPU (keeps every CU busy)
 
 
@@ -419,12 +420,15 @@ def main():
         # traffic per launch, and the secondary bounds — share of the kernel's time its vector ALUs issue, its LDS is
         # busy, its texture-address units are busy — because every kernel of this path is issue-/LDS-bound long before
         # HBM (tools/make_traffic_json.py writes both files from gpurun_out/<pmc run>)
-        traffic, secondary = None, None
+        traffic, secondary, counters_from = None, None, {}
         for fname, key in (("traffic.json", "traffic"), ("secondary.json", "secondary")):
             fpath = os.path.join(ROOT, "profiles", fname)
             if os.path.exists(fpath):
                 try:
-                    v = json.load(open(fpath)).get("%s:%d" % (dom, n))
+                    blob = json.load(open(fpath))
+                    v = blob.get("%s:%d" % (dom, n))
+                    if v is not None:                 # where the figure comes from: a committed counter run, NOT this run
+                        counters_from[key] = "profiles/%s <- %s (rocprofv3 --pmc, committed; not collected in this run)" % (fname, blob.get("_counters"))
                 except Exception:
                     v = None
                 if key == "traffic":
@@ -458,7 +462,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_ratio": round(traffic / kernels[dom][0], 3) if traffic else None,
-                         "secondary": secondary,
+                         "secondary": secondary, "counters_from": counters_from or None,
                          "algorithmic_bytes_per_launch": int(kernels[dom][0])},
             "stages_ms": {k: round(v, 3) for k, v in ms.items()},
             "compress_ms": round(ms["hist"] + ms["allreduce"] + ms["tree"] + ms["encode"], 3),      # compress = hist + tree + encode
@@ -466,6 +470,9 @@ def main():
             "stage_GBps_input": {k: (round(n / (v * 1e-3) / 1e9, 2) if v > 0 else None) for k, v in ms.items()},
             "kernel_roofline_frac": {k: round(b / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if t > 0 else None for k, (b, t) in kernels.items()},
             "encode_read_roofline_frac": round(n / (ms["encode"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms["encode"] > 0 else None,
+            # what that fraction can reach at all: the encoder moves (1 + r) bytes per input byte, and a plain copy reaches
+            # 6.29 of the 8.0 TB/s (MI355X_MICROARCH.md): 1 / (1 + r) x 6.29 / 8.0 — the north star's 0.50 lies above it
+            "encode_read_ceiling": round(1.0 / (1.0 + r) * COPY_CEILING_GBS / HBM_PEAK_GBS, 4),
             "compressed_ratio": round(r, 5), "total_payload_bits": int(tot_bits.item()), "round_trip_bit_exact": round_trip_all,
             # out-of-band bytes the decoder is handed beside the payload: the sidecar chunk index (8 B per chunk) and the
             # device-only fine index (4 B per 64 symbols); traffic of both kernels, never credit

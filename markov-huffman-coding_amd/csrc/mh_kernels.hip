@@ -162,7 +162,13 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_o1_kernel(const uint8_t *__
         const uint32_t head = nhead;
         if (v + v_step < v_end) {
             nx4 = vdata[v + v_step];
+#ifndef MH_HIST_PROBE_NOHEAD      /* diagnostic build (counts wrong): without the one-byte load in front of every wave's KiB — is it the 9 % of extra read requests? */
+            // (this one-byte load in front of every wave's KiB is what the counters show as 4-9 % more read requests than the
+            // input has lines: profiles/r04/hist_head_byte_*.txt — the line is the neighbouring wave's and gets fetched twice.
+            // Giving every wave its own contiguous sixteenth of the region, so that the byte is a lane read, removed the
+            // requests and cost 4 % in time (5.70 vs 5.48 ms per 16 GiB: sixteen streams per workgroup 4 MiB apart); not kept.)
             if (lane0) nhead = uint32_t(data[(v + v_step) * 16 - 1]);
+#endif
         }
         const uint32_t up = __shfl_up(x4.w >> 24, 1);
         uint32_t pb = lane0 ? head : up;
@@ -2989,8 +2995,12 @@ hipError_t launch_hist_o1(const uint8_t *d_data, uint64_t n, uint32_t prev0, uns
     const bool regions = ws_ok && ws_bytes >= g.total;
     // debug (tests of the conservation check): MH_DEBUG_HIST_GUARD_BITS=1 one guard bit (round 1's kernel: can lose counts
     // on long runs of one pair, depending on timing), =0 none (a field that wraps carries into its neighbour: always does)
+#ifdef MH_EXP_PROBES                         /* diagnostic library only (libmhc_diag.so): the shipped one always has two guard bits */
     const char *dbg = getenv("MH_DEBUG_HIST_GUARD_BITS");
     const int guard_bits = dbg ? atoi(dbg) : 2;
+#else
+    const int guard_bits = 2;
+#endif
     const bool guard1 = guard_bits == 0 || guard_bits == 1;
     // workspace: [0,64) status block (status word, the conservation check's total and ticket) | [64,256) header
     if (ws_ok && ws_bytes >= 256) {
@@ -3009,11 +3019,18 @@ hipError_t launch_hist_o1(const uint8_t *d_data, uint64_t n, uint32_t prev0, uns
     }
     e = once_per_device(&DeviceState::hist_ready, [] {
         hipError_t r = allow_lds(reinterpret_cast<const void *>(hist_o1_kernel<14>), HIST_LDS_BYTES);
+#ifdef MH_EXP_PROBES
         if (r == hipSuccess) r = allow_lds(reinterpret_cast<const void *>(hist_o1_kernel<15>), HIST_LDS_BYTES);
-        return r != hipSuccess ? r : allow_lds(reinterpret_cast<const void *>(hist_o1_kernel<16>), HIST_LDS_BYTES);
+        if (r == hipSuccess) r = allow_lds(reinterpret_cast<const void *>(hist_o1_kernel<16>), HIST_LDS_BYTES);
+#endif
+        return r;
     });
     if (e != hipSuccess) return e;
+#ifdef MH_EXP_PROBES
     auto kern = guard_bits == 0 ? hist_o1_kernel<16> : guard_bits == 1 ? hist_o1_kernel<15> : hist_o1_kernel<14>;
+#else
+    auto kern = hist_o1_kernel<14>;
+#endif
     if (regions) {
         uint32_t *slab = reinterpret_cast<uint32_t *>(ws + g.off_slab);
         hipLaunchKernelGGL(kern, dim3(g.grid), dim3(HIST_THREADS), HIST_LDS_BYTES, st, d_data, n, prev0, d_counts, slab,

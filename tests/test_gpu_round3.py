@@ -42,18 +42,30 @@ def dev_hist(mhc, data, prev0=0x20):
 def test_histogram_conservation_check_catches_a_spilled_counter(mhc):
     """64 MiB of zeros: every add of a workgroup goes to ONE 16-bit LDS field.  The product (two guard bits) counts
     them all and the device-side check (sum of counts == n, src/main.cpp:176-178) stays silent; the debug variants
-    with one guard bit (round 1's kernel) or none let the field spill into its neighbour, and the check reports it."""
+    with one guard bit (round 1's kernel) or none let the field spill into its neighbour, and the check reports it.
+    Those variants exist only in the diagnostic library (libmhc_diag.so, -DMH_EXP_PROBES): the shipped one has no switch
+    that makes a result wrong."""
+    import ctypes as C
     data = np.zeros(64 << 20, dtype=np.uint8)
     lib = mhc.lib()
     d_data, d_counts, d_hws, hws = dev_hist(mhc, data)
     assert lib.mh_dev_status(d_hws.ptr, None) == 0
     counts = d_counts.download(np.uint64)
     assert int(counts.sum()) == data.size and int(counts[0]) == data.size - 1
+    os.environ["MH_DEBUG_HIST_GUARD_BITS"] = "0"                 # the shipped library does not look at it
+    try:
+        d_data, d_counts, d_hws, hws = dev_hist(mhc, data)
+        assert lib.mh_dev_status(d_hws.ptr, None) == 0 and int(d_counts.download(np.uint64).sum()) == data.size
+    finally:
+        del os.environ["MH_DEBUG_HIST_GUARD_BITS"]
+    diag = C.CDLL(os.path.join(os.path.dirname(mhc.LIB_PATH), "libmhc_diag.so"))
+    diag.mh_dev_histogram_o1.argtypes = [C.c_void_p, C.c_size_t, C.c_uint8, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    diag.mh_dev_status.argtypes = [C.c_void_p, C.c_void_p]
     for bits in ("0", "1"):          # no guard bit: a wrapping field always carries into its neighbour; one: timing decides
         os.environ["MH_DEBUG_HIST_GUARD_BITS"] = bits
         try:
-            d_data, d_counts, d_hws, hws = dev_hist(mhc, data)
-            rc = lib.mh_dev_status(d_hws.ptr, None)
+            assert diag.mh_dev_histogram_o1(d_data.ptr, data.size, 0x20, d_counts.ptr, d_hws.ptr, hws, None) == 0
+            rc = diag.mh_dev_status(d_hws.ptr, None)
             lost = data.size - int(d_counts.download(np.uint64).sum())
         finally:
             del os.environ["MH_DEBUG_HIST_GUARD_BITS"]
