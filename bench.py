@@ -256,10 +256,11 @@ def main():
     ap.add_argument("--kind", default=None, choices=["zipf", "uniform", "text"])
     ap.add_argument("--order", type=int, default=1, choices=[1, 2],
                     help="2 = order-2 contexts (BASELINE configs[4]; extension the reference does not have: parity unpinned; 1 GPU)")
-    ap.add_argument("--o2-exchange", default="compact", choices=["compact", "scatter", "allreduce"],
-                    help="order 2, N > 1: compact = all-reduce of the live contexts' rows only (default); scatter = reduce-scatter of the "
-                         "1 << 24 counts + per-rank tree build of 65536 / N contexts + all-gather of the per-context arrays (SURVEY 8e); "
-                         "allreduce = all-reduce all 128 MiB and build everything on every rank")
+    ap.add_argument("--o2-exchange", default="compact", choices=["compact", "allreduce"],
+                    help="order 2, N > 1: compact = all-reduce of the live contexts' rows only (default); allreduce = all-reduce all "
+                         "128 MiB.  (SURVEY 8e's reduce-scatter + per-rank tree build + all-gather form moves MORE bytes than the "
+                         "all-reduce it replaces — the dense node arrays travel — and is no longer offered here; "
+                         "sharded.order2_model(exchange='scatter') keeps it for the API's test.)")
     ap.add_argument("--cpu-sample", type=int, default=256 << 20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -455,9 +456,7 @@ def main():
                        "sharding": ("contiguous byte ranges, histogram all-reduce (%s, %s)" %
                                     ("RCCL over xGMI" if args.backend == "nccl" else "gloo staged through host memory: REHEARSAL, not RCCL",
                                      "512 KiB" if args.order == 1 else (
-                                         "order 2: the rows of the live contexts only" if args.o2_exchange == "compact" else
-                                         "128 MiB" if args.o2_exchange != "scatter" or 65536 % world else
-                                         "order 2: reduce-scatter of the counts, 65536 / N trees per rank, all-gather of the per-context arrays"))) if multi else "single GPU",
+                                         "order 2: the rows of the live contexts only" if args.o2_exchange == "compact" else "128 MiB"))) if multi else "single GPU",
                        "backend": (dist.get_backend() if multi else None), "ranks": (dist.get_world_size() if multi else 1)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,

@@ -27,7 +27,7 @@ run weak_zipf_2g --size 2147483648
 run strong_zipf_4g --total-size 4294967296
 run config4_1g --config 4 --size 1073741824
 run order2_text_1g --order 2 --kind text --size 1073741824
-run order2_text_1g_scatter --order 2 --kind text --size 1073741824 --o2-exchange scatter
+
 run order2_text_1g_allreduce --order 2 --kind text --size 1073741824 --o2-exchange allreduce
 # ONE rank through the same N > 1 code path on the real backend (RCCL): process group, all-reduce, all-gather,
 # reduce-scatter, barrier, pre-shifted encode — the calls the driver's multi-GPU bench will make
@@ -47,6 +47,6 @@ PY
 run1 rccl_world1_16g
 run1 rccl_world1_config4 --config 4
 run1 rccl_world1_order2 --order 2 --kind text --size 4294967296
-run1 rccl_world1_order2_scatter --order 2 --kind text --size 4294967296 --o2-exchange scatter
+
 run1 rccl_world1_order2_allreduce --order 2 --kind text --size 4294967296 --o2-exchange allreduce
 cat $OUT/rehearse.txt
