@@ -3473,12 +3473,12 @@ hipError_t launch_build_index(IdxParams p, void *d_ws, hipStream_t st) {
         uint32_t it = 0;
         q.warm_bits = 256;
         if (const char *wv = getenv("MH_INDEX_WARM_BITS")) { const int v = atoi(wv); if (v >= 16 && v <= int(IX_WARM_BITS_MAX)) q.warm_bits = uint32_t(v); }
-        else if (q.ntile5 >= 4096) {
-            // how long a warm-up this stream needs is a property of the source: a sample (the first 1/64 of the tiles) with 128
-            // bits tells — where that leaves under 2 % of the segments to repair the short warm-up serves the whole stream
-            // (the pass decodes warm-up + segment: 1.5 instead of 2 segment lengths)
+        else if (q.ntile5 >= 16384) {
+            // how long a warm-up this stream needs is a property of the source: a sample (the first 1/256 of the tiles, one tile
+            // per wave of the card at least) with 128 bits tells — where that leaves under 2 % of the segments to repair the
+            // short warm-up serves the whole stream (the pass decodes warm-up + segment: 1.44 instead of 1.89 segment lengths)
             IdxParams sq = q;
-            sq.ntile5 = q.ntile5 / 64;
+            sq.ntile5 = q.ntile5 / 256 > 4096 ? q.ntile5 / 256 : 4096;
             sq.nseg5 = sq.ntile5 * IX_TILE_SEGS;
             sq.warm_bits = 128;
             sq.iter = it;

@@ -110,11 +110,19 @@ def order2_model(mhc, local_counts, stream=None, group=None, exchange="scatter")
                    all-gathered in place, mh_dev_model2_finish derives the tables.  Needs G to divide 65536.
       "allreduce"  all-reduce the counts, every rank builds everything (local_counts becomes the global histogram).
       "compact"    the same, but only the rows of live contexts travel (merged_histogram_o2_compact).
+    `stream` must be torch's CURRENT stream (the default when None is passed means the null stream: pass
+    torch.cuda.current_stream().cuda_stream as HipBackend does): the torch collectives here order against the current stream
+    only, so library kernels launched on any other stream would race them (checked below).  The in-place RCCL all-gather of
+    the scatter form has run with one rank on the real backend and with two ranks on gloo, never with N > 1 on RCCL.
     Returns the Model; it borrows a workspace tensor that is kept alive on the object.  With gloo (rehearsals with the
     shards on one card) the collectives are staged through host memory and the reduce-scatter is an all-reduce + slice
     (gloo has none)."""
     import ctypes as C
     lib = mhc.lib()
+    if local_counts.is_cuda:
+        given = stream.value if isinstance(stream, C.c_void_p) else stream
+        if (given or 0) != torch.cuda.current_stream().cuda_stream:
+            raise ValueError("order2_model: `stream` must be torch's current stream (the collectives order against that one only)")
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     staged = local_counts.is_cuda and dist.get_backend(group) != "nccl"
     nctx = 65536
