@@ -336,6 +336,7 @@ def main():
     stage_ms = {"hist": 0.0, "allreduce": 0.0, "tree": 0.0, "encode": 0.0, "decode": 0.0}
     model = None
     last_step = {}
+    recorded = []                                     # the timed steps' events
 
     def step(record):
         nonlocal model, last_step
@@ -350,10 +351,12 @@ def main():
         model = last_step["model"]
         codec.decode(model)                           # reads the payload length where the encoder left it (HBM)
         mark("decode")
-        torch.cuda.synchronize()
+        # no device-wide wait here: the step's only host wait is the model build's (16 KiB of table sizes); the next step is
+        # enqueued behind this one on the same stream, and the stage times are read from the events after the timed loop
         if record:
-            for i, k in enumerate(stage_ms):
-                stage_ms[k] += marks[i].elapsed_time(marks[i + 1])
+            recorded.append(marks)
+        else:
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step(False)
@@ -368,6 +371,9 @@ def main():
     if multi:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    for marks in recorded:
+        for i, k in enumerate(stage_ms):
+            stage_ms[k] += marks[i].elapsed_time(marks[i + 1])
     def all_reduce(t, op=dist.ReduceOp.SUM):       # (after the timed region: timing and verdicts of the ranks)
         if t.is_cuda and dist.get_backend() != "nccl":
             c = t.cpu()
