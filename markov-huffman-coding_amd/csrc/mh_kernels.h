@@ -29,7 +29,7 @@ struct EncodeArgs {
     const unsigned long long *start_bit;   // device: global bit position of this payload (low 3 bits used) or nullptr
     uint32_t *fine;               // out, optional: the device-only fine index (TileParams), one entry per 64 input bytes
     int max_len;                  // the model's longest code (the region encoder launches its escape variant only above 12)
-    const uint8_t *o2hot;         // order 2, optional: the live contexts' tables for LDS (mh_kernels.hip, o2hot_lookup16)
+    const uint8_t *o2hot;         // order 2, optional: the live contexts' tables for LDS (mh_encode.hip, o2hot_lookup16)
     uint32_t o2hot_bytes;
     bool no_chain;                // order 2: the length pass + emit pair even where the one-pass encoder would run
 };
@@ -228,7 +228,7 @@ struct O2HotArgs {
     uint8_t id_sym[64];           // byte value of id 0..62 (unused ids: any value with id_used 0)
     uint8_t id_used[64];
     const uint8_t *len8; const unsigned long long *code64;
-    uint16_t *hot;                // (nslots + 1) * 64 u16: the encoder's rows (mh_kernels.hip, o2hot_lookup16)
+    uint16_t *hot;                // (nslots + 1) * 64 u16: the encoder's rows (mh_encode.hip, o2hot_lookup16)
     // tile decoder tables (nullptr: none)
     const uint16_t *node_left, *node_right; const uint8_t *node_sym; const uint32_t *ctx_meta;
     const uint16_t *ctx2slot;

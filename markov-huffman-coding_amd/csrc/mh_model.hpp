@@ -15,7 +15,7 @@
 
 namespace mh {
 
-// ---- device table formats (shared with mh_kernels.hip) ------------------------------------------
+// ---- device table formats (shared with the kernel files: mh_encode.hip, mh_decode.hip, mh_tile.hip, mh_tree.hip) ------------------------------------------
 
 // Encode table, LDS-resident: 65536 x u16, entry = len(4) << 12 | code(12) for len <= 12,
 // 0 = "no code" (symbol skipped, src/coding.cpp:72 under NDEBUG), ENC16_ESCAPE = look the

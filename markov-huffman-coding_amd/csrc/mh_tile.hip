@@ -1,6 +1,6 @@
 // mh_tile.hip — the wave-contiguous ("tile") decoder of the order-1 hot path.
 //
-// decode_kernel (mh_kernels.hip) gives every lane its own 1024-symbol chunk: a lane's compressed bytes are
+// decode_kernel (mh_decode.hip) gives every lane its own 1024-symbol chunk: a lane's compressed bytes are
 // ~0.7 KiB from its neighbour's, so every 32-byte input granule and every 64-byte output burst is a cache line
 // of its own — 64 lines per wave instruction, 2.3x the algorithmic HBM traffic, the vector-memory pipe 63 % busy.
 // Here a WAVE decodes 64 ADJACENT sub-chunks of 64 symbols (one per lane; K such tiles side by side): with the
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
 }
 
 // ---- index builder, fast path (the reference's streams carry no index, src/coding.cpp:35-59) ---------
-// The segment iteration of mh_kernels.hip gives a lane 4096 bits of payload 512 bytes from its neighbour's and gathers both
+// The segment iteration of mh_index.hip gives a lane 4096 bits of payload 512 bytes from its neighbour's and gathers both
 // table levels from L2: three such passes cost ten times the decode they prepare.  Here a WAVE takes 128 ADJACENT segments of
 // IX_SEG_BITS bits (two per lane) — one contiguous 4 KiB of payload, staged through LDS exactly as the tile decoder stages
 // its pieces — with the tile decoder's first level in LDS:

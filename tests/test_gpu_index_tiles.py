@@ -138,3 +138,43 @@ def test_tiles_report_a_stream_that_does_not_belong_to_the_table(mhc, oracle):
     m = mhc.Model.from_table(om.table_bytes())
     st, path, ns, _, _ = build(mhc, m, blob[1:], nbits - 3, 1024)       # ends inside the last code
     assert path == IDX_TILES and (st == mhc.MH_ERR_CORRUPT or ns != data.size)
+
+
+def _random_source(seed):
+    """Seeded sources of many shapes: alphabets of 3..256 symbols, Zipf exponents 0.3..2.5, iid or first-order Markov
+    (a random permutation of the ranks per context: the decode then depends on the context at every step)."""
+    rng = np.random.default_rng(1000 + seed)
+    k = int(rng.choice([3, 5, 16, 40, 64, 100, 256]))
+    s = float(rng.uniform(0.3, 2.5))
+    n = int(rng.integers(260_000, 900_000))
+    w = 1.0 / np.arange(1, k + 1) ** s
+    w /= w.sum()
+    if seed % 3 == 0:                                            # Markov: every context ranks the symbols differently
+        perms = [rng.permutation(k).tolist() for _ in range(k)]
+        ranks = rng.choice(k, size=n, p=w).tolist()
+        out = bytearray(n)
+        prev = 0
+        for i, r in enumerate(ranks):
+            prev = perms[prev][r]
+            out[i] = prev
+        return np.frombuffer(bytes(out), dtype=np.uint8).copy()
+    return rng.choice(k, size=n, p=w).astype(np.uint8)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_index_builder_on_random_sources_matches_the_oracle_s_positions(mhc, oracle, seed):
+    """Differential run over seeded random sources (tools/fuzz_index_free.py's idea, as a test): whichever way the index is
+    built — the fast path over tiles where the model allows it, the segment iteration or one of its fallbacks elsewhere — chunk
+    index, fine index and symbol count equal what the oracle's code lengths say, and the host-buffer decode of the
+    oracle's stream (no index: the reference's file format) gives the input back."""
+    data = _random_source(seed)
+    om = oracle.Model.from_data(data.tobytes(), 1)
+    blob, nbits = om.compress(data.tobytes())
+    m = mhc.Model.from_table(om.table_bytes())
+    lens = np.asarray(om.codes()[0]).astype(np.int64)
+    chunk = [256, 1024, 4096][seed % 3]
+    want_idx, want_fine = expected_entries(lens, data, chunk)
+    st, path, ns, idx, fine = build(mhc, m, blob[1:], nbits, chunk)
+    assert (st, ns) == (0, data.size), (st, ns, path)
+    assert np.array_equal(idx[:want_idx.size], want_idx) and np.array_equal(fine[:want_fine.size], want_fine), path
+    assert m.decompress(blob) == data.tobytes()

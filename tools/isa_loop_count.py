@@ -6,7 +6,7 @@ Prints, for every backward branch of the kernel, the loop's span and its VALU / 
 so a change to a hot loop can be priced before it goes to the GPU box."""
 import re, subprocess, sys, os
 here = os.path.dirname(os.path.abspath(__file__))
-src = os.path.join(here, "..", "markov-huffman-coding_amd", "csrc", os.environ.get("MH_ISA_SRC", "mh_kernels.hip"))
+src = os.path.join(here, "..", "markov-huffman-coding_amd", "csrc", os.environ.get("MH_ISA_SRC", "mh_encode.hip"))
 name = sys.argv[1]
 out = "/tmp/isa_loop_count.s"
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", src, "-o", out] + sys.argv[2:],
