@@ -126,7 +126,6 @@ struct TileParams {
     uint32_t P, H, nsec;
     int *status;
     uint32_t *redo;                      // [0] = count, [1..] chunk numbers handed to the redo pass (legacy tables)
-    uint32_t *geom;                      // [0] = largest staged piece of a wave (bytes), written by tile_geom_kernel
     uint64_t ntiles;                     // full wave pieces (K tiles of 4096 symbols each)
     uint32_t probe;                      // timing probes (MH_TILE_PROBE): results are wrong and nothing is reported
     // order 2 (extension, parity unpinned): the LIVE contexts' tables, one slot each.  prim / sec then hold uint32

@@ -16,9 +16,9 @@
 //     second-level tables (2^H entries) gathered from L2 by every lane through a bounds-checked buffer load
 //     (a leaf entry used as a table id lands past the end of the table: answered with 0, no cache access);
 //   * 64 symbols per stream end in four 16-byte stores per lane; adjacent lanes complete whole lines.
-// The LDS not taken by the first-level table is divided into the waves' regions; tile_geom_kernel finds the
-// largest piece any wave will stage, and the workgroup sizes its regions (and the number of waves it keeps) from
-// that: nothing is assumed about the compression ratio, locally or globally.
+// The LDS not taken by the first-level table is divided into the waves' regions; every workgroup first finds the
+// largest piece any of its waves will stage and sizes its regions (and the number of waves it keeps) from that:
+// nothing is assumed about the compression ratio, locally or globally.
 // Chunks the tiles do not cover (the stream's ragged end, pieces larger than the whole LDS, codes longer than
 // P + H bits) go to the redo pass of the chunk decoder (one lane per chunk, legacy tables, tree walk).
 // Reference semantics: i_coding_provider::decompress, src/coding.cpp:118-157; bit order src/bitbuffer.cpp:12.
@@ -65,24 +65,6 @@ __device__ __forceinline__ uint64_t sub_pos(const TileParams &p, uint64_t j, uin
 
 // first payload byte a wave stages for a piece that starts at bit `start` (16-byte aligned), and the byte count
 __device__ __forceinline__ uint64_t stage_first(uint64_t start) { return (start >> 3) & ~uint64_t(15); }
-
-// ---- geometry: the largest piece any wave stages ----------------------------------------------------------
-template <int K, int O2>
-__global__ __launch_bounds__(256) void tile_geom_kernel(TileParams p, uint32_t cap_bytes) {
-    if (p.d_nbits) p.nbits = *p.d_nbits;
-    const uint64_t nsub = (p.n + T_SUB - 1) >> T_SUB_SHIFT;
-    uint32_t mx = 0;
-    for (uint64_t t = uint64_t(blockIdx.x) * 256 + threadIdx.x; t < p.ntiles; t += uint64_t(gridDim.x) * 256) {
-        const uint64_t j0 = t * (64u * K), j1 = j0 + 64u * K;
-        const uint64_t start = sub_pos<O2>(p, j0, p.fine[j0]);
-        const uint64_t end = j1 < nsub ? sub_pos<O2>(p, j1, p.fine[j1]) : p.nbits;
-        if (end < start || end > p.nbits) continue;               // the decoder reports it
-        const uint64_t bytes = ((end + 7) >> 3) - stage_first(start);
-        if (bytes <= cap_bytes && uint32_t(bytes) > mx) mx = uint32_t(bytes);
-    }
-    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
-    if ((threadIdx.x & 63u) == 0 && mx) atomicMax(&p.geom[0], mx);
-}
 
 // LDS through absolute byte addresses: the kernel's address arithmetic happens on plain integers (a pointer
 // derived from `smem` costs an add of the segment's base, which the compiler does not fold, on every access)
@@ -134,16 +116,51 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
     for (uint32_t i = tid; i < PRIM_BYTES / 16u; i += T_THREADS)
         reinterpret_cast<uint4 *>(lut)[i] = reinterpret_cast<const uint4 *>(p.prim)[i];
     __syncthreads();
-    // ---- the waves' LDS regions: as many waves as regions of the largest piece fit (the rest leave)
+    const uint64_t nsub = (p.n + T_SUB - 1) >> T_SUB_SHIFT;
     const uint32_t free_bytes = uint32_t(T_LDS_BYTES) - PRIM_BYTES;
-    const uint32_t maxb = p.geom[0];
+    // ---- [r4] geometry, per workgroup: the largest piece any of ITS waves will stage.  The workgroup owns blocks of T_WAVES
+    // consecutive wave pieces (block B = blockIdx.x + m * gridDim.x), whatever the number of waves it keeps, so the set is
+    // known before the regions are sized (a kernel of its own did this for the whole stream: 0.11 ms per 16 GiB, 1 % of a
+    // 2 GiB shard's step).  A piece too large for all of the LDS is not counted: its chunks go to the redo pass below.
+    // If all T_WAVES waves fit but for a few outsized pieces (the tail of 8 192 pieces' lengths), the regions are sized for
+    // sixteen waves anyway and those pieces take the redo pass with the other leftovers: a sixteenth more streams in flight
+    // for the whole workgroup is worth more than the chunk decoder costs on under 1 % of it.
+    uint32_t maxb;
+    {
+        uint32_t *s_max = reinterpret_cast<uint32_t *>(smem + PRIM_BYTES);       // (the first region: not in use yet)
+        if (tid < 2) s_max[tid] = 0;
+        __syncthreads();
+        const uint32_t cap_bytes = free_bytes - 32u;
+        const uint32_t fit_all = ((free_bytes / uint32_t(T_WAVES)) & ~15u) - 32u;   // a piece of at most this many bytes: T_WAVES regions fit
+        uint32_t mx = 0, over = 0;
+        const uint64_t nblk = (p.ntiles + T_WAVES - 1) / T_WAVES;          // blocks of T_WAVES pieces in the stream
+        const uint64_t mine = nblk > blockIdx.x ? (nblk - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;   // ... of this workgroup
+        for (uint64_t i = tid; i < mine * T_WAVES; i += T_THREADS) {          // all of its pieces, spread over its threads
+            const uint64_t t = (blockIdx.x + (i / T_WAVES) * gridDim.x) * T_WAVES + (i % T_WAVES);
+            if (t >= p.ntiles) continue;
+            const uint64_t j0 = t * (64u * K), j1 = j0 + 64u * K;
+            const uint64_t start = sub_pos<O2>(p, j0, p.fine[j0]);
+            const uint64_t end = j1 < nsub ? sub_pos<O2>(p, j1, p.fine[j1]) : p.nbits;
+            if (end < start || end > p.nbits) continue;              // the decoding wave reports it
+            const uint64_t bytes = ((end + 7) >> 3) - stage_first(start);
+            if (bytes <= cap_bytes && uint32_t(bytes) > mx) mx = uint32_t(bytes);
+            over += bytes > fit_all ? 1u : 0u;
+        }
+        if (mx) atomicMax(&s_max[0], mx);
+        if (over) atomicAdd(&s_max[1], over);
+        __syncthreads();
+        maxb = s_max[0];
+        const uint32_t nover = s_max[1];
+        __syncthreads();                                              // (read by everybody before a wave stages into it)
+        if (maxb > fit_all && uint64_t(nover) * 128u <= mine * T_WAVES) maxb = fit_all;
+    }
+    // ---- the waves' LDS regions: as many waves as regions of the largest piece fit (the rest leave)
     uint32_t region = (maxb + 15u + 16u) & ~15u;                  // + the dword behind the last one a window read may touch
     if (OUT == 2 && region < 1024u) region = 1024u;               // the output transposition needs one KiB
     uint32_t nw = free_bytes / region;
     if (nw == 0) { nw = 1; region = free_bytes & ~15u; }
     if (nw > uint32_t(T_WAVES)) nw = T_WAVES;
     const uint32_t H = HC ? uint32_t(HC) : p.H;
-    const uint64_t nsub = (p.n + T_SUB - 1) >> T_SUB_SHIFT;
     constexpr uint32_t TSYM = uint32_t(K) * T_TILE;               // symbols per wave piece
     // ---- what the tiles do not cover: the chunks behind the last full piece (block 0, wave 0)
     if (blockIdx.x == 0 && wave == 0) {
@@ -162,7 +179,10 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
     const uint32_t chunks_per_tile = T_TILE >> p.chunk_shift;     // >= 1: chunk_shift <= 12 (launch_decode_tile)
 
     unsigned long long seg[4] = {0, 0, 0, 0};
-    for (uint64_t t = uint64_t(blockIdx.x) * nw + wave; t < p.ntiles; t += uint64_t(gridDim.x) * nw) {
+    for (uint64_t tb = blockIdx.x; tb * T_WAVES < p.ntiles; tb += gridDim.x)
+    for (uint32_t tj = wave; tj < uint32_t(T_WAVES); tj += nw) {
+        const uint64_t t = tb * T_WAVES + tj;
+        if (t >= p.ntiles) break;
         unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
         if (STAMP) t0 = tile_stamp();
         // ---- positions: lane l, stream k decodes sub-chunk j = (t * K + k) * 64 + l
@@ -657,16 +677,12 @@ static hipError_t launch_tile_with(void (*kern)(TileParams), TileParams p, const
     // workspace: [0,64) status | [64, 64 + 16) redo count ... as launch_decode lays it out; the geometry word lives in
     // the status block (bytes 4..7; bytes 8..39 take the diagnostic build's cycle sums)
     p.status = reinterpret_cast<int *>(d_ws);
-    p.geom = reinterpret_cast<uint32_t *>(static_cast<char *>(d_ws) + 4);
     p.redo = reinterpret_cast<uint32_t *>(static_cast<char *>(d_ws) + 64);
     e = hipMemsetAsync(d_ws, 0, 64 + 16, st);
     if (e != hipSuccess) return e;
     if (p.ntiles) {
         const uint32_t prim_bytes = O2 ? (((p.nslots << p.P) * 4u + 15u) & ~15u) : (256u << p.P) * 2u;
         if (prim_bytes + 4096u > uint32_t(T_LDS_BYTES)) return hipErrorInvalidValue;
-        const uint32_t cap = uint32_t(T_LDS_BYTES) - prim_bytes - 32u;
-        const uint64_t gwant = (p.ntiles + 255) / 256;
-        hipLaunchKernelGGL((tile_geom_kernel<K, O2>), dim3(unsigned(gwant > 1024 ? 1024 : gwant)), dim3(256), 0, st, p, cap);
     }
     // one workgroup per CU (the first-level table takes most of the LDS); with few pieces, fewer workgroups
     const uint64_t want = (p.ntiles + T_WAVES - 1) / T_WAVES;

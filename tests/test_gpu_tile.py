@@ -238,9 +238,9 @@ def o2_round_trip(mhc, oracle, data, chunk=1024, expect_tiles=None):
     assert lib.mh_dev_status(d_dws.ptr, None) == 0
     out = d_out.download()
     assert np.all(out[n:] == 0xAB) and np.array_equal(out[:n], data)
-    if expect_tiles is not None:                 # bytes 4..7 of the status block: the largest staged piece (tile decoder only)
-        staged = int(d_dws.download(np.uint32)[1])
-        assert (staged > 0) == expect_tiles, staged
+    if expect_tiles is not None:                 # which decoder ran is on record in the workspace (1 = the tile decoder)
+        path = lib.mh_dev_decode_path(d_dws.ptr, None)
+        assert (path == 1) == expect_tiles, path
 
 
 @pytest.mark.parametrize("chunk", [256, 1024])
