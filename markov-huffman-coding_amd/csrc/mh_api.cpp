@@ -524,8 +524,19 @@ int dev_model_build(const uint64_t *d_counts, void *d_ws, size_t ws_bytes, hipSt
     mhk::TreeBuildOut tb{m->d_len8, reinterpret_cast<unsigned long long *>(m->d_code64), m->d_enc16, m->d_len_slot,
                          m->d_node_left, m->d_node_right, m->d_node_sym, d_node_height, m->d_meta, 8u};
     HIP_TRY_M(mhk::launch_tree_build(reinterpret_cast<const unsigned long long *>(d_counts), 256, tb, st));
-    std::vector<uint32_t> meta(size_t(256) * mhk::TB_META_STRIDE);
-    HIP_TRY_M(hipMemcpyAsync(meta.data(), m->d_meta, meta.size() * 4, hipMemcpyDeviceToHost, st));
+    // (a pinned landing place, one per thread, kept for the life of the process — 16 KiB; freeing it from a destructor at exit
+    // would call into a runtime that may already be gone: a copy into pageable memory is staged by the runtime)
+    struct PinnedMeta { uint32_t *p = nullptr; };
+    static thread_local PinnedMeta pinned;
+    const size_t meta_words = size_t(256) * mhk::TB_META_STRIDE;
+    std::vector<uint32_t> meta_pageable;
+    if (!pinned.p && hipHostMalloc(reinterpret_cast<void **>(&pinned.p), meta_words * 4, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        pinned.p = nullptr;
+    }
+    if (!pinned.p) meta_pageable.resize(meta_words);
+    uint32_t *meta = pinned.p ? pinned.p : meta_pageable.data();
+    HIP_TRY_M(hipMemcpyAsync(meta, m->d_meta, meta_words * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY_M(hipStreamSynchronize(st));                      // 16 KiB of sizes: the one sync of this call
 
     // same layout rule as mh::Model::pack()
@@ -578,7 +589,7 @@ int dev_model_build(const uint64_t *d_counts, void *d_ws, size_t ws_bytes, hipSt
     pa.ctx_meta = m->d_meta; pa.sec_base = m->d_sec_base;
     pa.P = uint32_t(P); pa.direct = m->dec_direct ? 1u : 0u; pa.H = uint32_t(m->dec_h); pa.hcap = 8u;
     pa.prim = m->d_prim; pa.sec = m->d_sec; pa.tree = m->d_tree;
-    HIP_TRY_M(mhk::launch_tree_pack(pa, 256, st));
+    bool packed = false;                                      // (the tile tables' packing below takes this one along: one launch)
     // ---- the tile decoder's tables: the same trees packed once more, LSB-first, with a first level of tile_p bits
     if (const int tP = tile_p_choice()) {
         const int tH = std::min(std::max(m->max_len - tP, 1), 8);
@@ -608,10 +619,12 @@ int dev_model_build(const uint64_t *d_counts, void *d_ws, size_t ws_bytes, hipSt
             pt.ctx_meta = m->d_meta; pt.sec_base = nullptr; pt.sec_base_in = nullptr;
             pt.P = uint32_t(tP); pt.direct = 1u; pt.H = uint32_t(tH); pt.hcap = 8u;
             pt.prim = m->d_tprim; pt.sec = m->d_tsec; pt.tree = nullptr; pt.lsb = 1u;
-            HIP_TRY_M(mhk::launch_tree_pack(pt, 256, st));
+            HIP_TRY_M(mhk::launch_tree_pack2(pa, pt, 256, st));
+            packed = true;
             m->tile_p = tP; m->tile_h = tH; m->tile_nsec = uint32_t(ntab << tH);
         }
     }
+    if (!packed) HIP_TRY_M(mhk::launch_tree_pack(pa, 256, st));
 #undef HIP_TRY_M
     *out = m;
     return MH_OK;

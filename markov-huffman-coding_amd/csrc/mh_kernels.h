@@ -237,6 +237,7 @@ struct O2HotArgs {
 hipError_t launch_o2_hot_pack(const O2HotArgs &a, hipStream_t st);
 hipError_t launch_tree_build(const unsigned long long *d_counts, int nctx, const TreeBuildOut &o, hipStream_t st);
 hipError_t launch_tree_pack(const TreePackArgs &a, int nctx, hipStream_t st);
+hipError_t launch_tree_pack2(const TreePackArgs &a, const TreePackArgs &b, int nctx, hipStream_t st);   // both in one launch
 
 size_t hist_workspace_bytes(uint64_t n);
 hipError_t launch_hist_o1(const uint8_t *d_data, uint64_t n, uint32_t prev0, unsigned long long *d_counts, void *d_ws, size_t ws_bytes,

@@ -417,8 +417,8 @@ __global__ __launch_bounds__(64) void tree_build_kernel(const unsigned long long
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tree_pack_kernel(TreePackArgs a) {
-    const uint32_t c = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void tree_pack_body(const TreePackArgs &a, const uint32_t c) {
+    const uint32_t tid = threadIdx.x;
     __shared__ uint16_t left[TB_NODE_STRIDE], right[TB_NODE_STRIDE], nid[TB_NODE_STRIDE];
     __shared__ uint8_t sym[TB_NODE_STRIDE], height[TB_NODE_STRIDE];
     __shared__ uint32_t tr[TREE_STRIDE];
@@ -495,6 +495,14 @@ __global__ __launch_bounds__(256) void tree_pack_kernel(TreePackArgs a) {
     if (a.tree) a.tree[c * TREE_STRIDE + tid] = tr[tid];      // (a second packing of the same trees leaves the walk tree alone)
 }
 
+__global__ __launch_bounds__(256) void tree_pack_kernel(TreePackArgs a) { tree_pack_body(a, blockIdx.x); }
+// [r4] two packings of the same trees in ONE launch (the chunk decoder's tables and the tile decoder's: blocks 0 .. nctx - 1
+// and nctx .. 2 nctx - 1): they ran one after the other, 0.04 ms each, with nothing between them but a launch gap
+__global__ __launch_bounds__(256) void tree_pack2_kernel(TreePackArgs a, TreePackArgs b, uint32_t nctx) {
+    if (blockIdx.x < nctx) tree_pack_body(a, blockIdx.x);
+    else tree_pack_body(b, blockIdx.x - nctx);
+}
+
 // ---- order 2: the live contexts' tables ("LDS codeword-table staging") --------------------------
 // one wave per slot; the last block (slot == nslots) writes the encoder's all-escape row
 __global__ __launch_bounds__(64) void o2_hot_pack_kernel(O2HotArgs a) {
@@ -557,6 +565,10 @@ hipError_t launch_tree_build(const unsigned long long *d_counts, int nctx, const
 
 hipError_t launch_tree_pack(const TreePackArgs &a, int nctx, hipStream_t st) {
     hipLaunchKernelGGL(tree_pack_kernel, dim3(nctx), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+hipError_t launch_tree_pack2(const TreePackArgs &a, const TreePackArgs &b, int nctx, hipStream_t st) {
+    hipLaunchKernelGGL(tree_pack2_kernel, dim3(2 * nctx), dim3(256), 0, st, a, b, uint32_t(nctx));
     return hipGetLastError();
 }
 
