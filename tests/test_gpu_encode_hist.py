@@ -138,3 +138,24 @@ def test_encode_hist_rejects_a_foreign_workspace(mhc):
     mhc._check(lib.mh_dev_encode_hist(m.handle, d_b.ptr, n, 0x20, None, d_payload.ptr, cap, d_nbits.ptr, None, 0,
                                       d_hws.ptr, hws, d_ws.ptr, wsb, None), "encode_hist")
     assert lib.mh_dev_status(d_ws.ptr, None) == mhc.MH_ERR_CORRUPT
+
+
+@pytest.mark.parametrize("block", [8 << 10, 16 << 10, 48 << 10, 1 << 20])
+def test_region_encoder_rounds_that_fit_half_the_image_next_to_rounds_that_do_not(mhc, oracle, block):
+    """[r4] The region encoder alternates between the two halves of its LDS image (one barrier per 16 KiB round) for rounds
+    whose bits fit a half, and takes the whole image (two barriers) for a round that does not — and for the round BEHIND such
+    a round, whose predecessor's flush of the whole image may still be running.  Blocks of random bytes (8+ bits per symbol
+    under a model that also holds a cheap symbol: a round of them does not fit) alternate with blocks of that cheap symbol
+    (1-2 bits: fits), with block lengths under, at and over the round length and far over it: every transition
+    half -> whole -> half, runs of whole rounds and runs of half rounds, all in one stream; the bytes are the oracle's."""
+    n = (12 << 20) + 345
+    rng = np.random.default_rng(block)
+    data = rng.integers(0, 256, n, dtype=np.uint8)
+    for lo in range(block, n, 2 * block):                        # every second block: one cheap symbol
+        data[lo:lo + block] = 0x41
+    m, counts, a, b = run_both(mhc, data, chunk=1024)
+    assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2])
+    ref, ref_bits = oracle.Model.from_counts(counts, 1).compress(data.tobytes())
+    assert a[0] == ref_bits and a[1] == ref[1:]
+    lens = np.asarray(oracle.Model.from_counts(counts, 1).codes()[0]).reshape(256, 256)
+    assert lens[0x41, 0x41] <= 2 and np.median(lens[lens > 0]) >= 8    # the two kinds of round really differ
