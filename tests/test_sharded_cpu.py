@@ -104,7 +104,7 @@ def _run(world, data):
     return sorted(out)
 
 
-@pytest.mark.parametrize("world,n", [(2, 100000), (2, 33), (3, 50001), (2, 0), (2, 10)])
+@pytest.mark.parametrize("world,n", [(2, 100000), (2, 33), (3, 50001), (2, 0), (2, 10), (8, 200003)])   # 8: the node the scaling bench runs on
 def test_sharded_compress_equals_whole_stream(oracle, world, n):
     rng = np.random.default_rng(n + world)
     w = 1.0 / np.arange(1, 257) ** 1.1
