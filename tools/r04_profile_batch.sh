@@ -12,11 +12,8 @@ python3 tools/pmc_summary.py gpurun_out/r04_prof/pmc16g $O/pmc16g_summary.json >
 bash tools/pmc_traffic.sh r04_prof/traffic16g --size 17179869184 > $O/pmc_traffic.log 2>&1
 python3 tools/pmc_summary.py gpurun_out/r04_prof/traffic16g $O/traffic16g_counters.json > $O/traffic16g_counters.txt 2>&1
 cd /tmp
-for lib in base nohead; do
-  ( [ $lib != base ] && export MH_LIB=$R/markov-huffman-coding_amd/libmhc_$lib.so
-    timeout -k 10 200 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum --kernel-trace --output-format csv -d $O/hist_$lib/p1 -- python3 $R/tools/hist_only.py > $O/hist_$lib.log 2>&1 )
-  python3 $R/tools/pmc_summary.py $O/hist_$lib > $O/hist_${lib}_counters.txt 2>&1
-done
+# (the histogram's head-byte probe needs a diagnostic build: make -C markov-huffman-coding_amd/csrc exp TAG=nohead EXPFLAGS=-DMH_HIST_PROBE_NOHEAD,
+#  then: MH_LIB=.../libmhc_nohead.so rocprofv3 --pmc TCC_EA0_RDREQ_sum ... -- python3 tools/hist_only.py; record: profiles/r04/hist_head_byte_*.txt)
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/index4g/p1 -- python3 $R/tools/index_free_rate.py --size 4294967296 > $O/index4g_p1.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TA_BUSY_avr --kernel-trace --output-format csv -d $O/index4g/p2 -- python3 $R/tools/index_free_rate.py --size 4294967296 > $O/index4g_p2.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/index4g/p3 -- python3 $R/tools/index_free_rate.py --size 4294967296 > $O/index4g_p3.log 2>&1
