@@ -317,7 +317,11 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
                     } else {
                         const uint32_t csh = P == 7 ? __builtin_amdgcn_perm(0u, cf[k], 0x0C0C000Cu)       // byte 0 -> byte 1
                                                     : (cf[k] & 255u) << (P + 1);
+#ifdef MH_TILE_SWIZZLE
+                        e[k] = *lds_ptr<uint16_t>((((win[k] ^ ((cf[k] & 255u) * 0x9Du)) << 1) & ((2u << P) - 2u)) | csh);
+#else
                         e[k] = *lds_ptr<uint16_t>(((win[k] << 1) & ((2u << P) - 2u)) | csh);
+#endif
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
