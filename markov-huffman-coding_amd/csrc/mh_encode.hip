@@ -802,6 +802,10 @@ __global__ __launch_bounds__(1024) void region_bits_kernel(const HistHeader *hdr
                                                            unsigned long long *region_bits, uint32_t *region_esc, int *status) {
     __shared__ unsigned long long part[16];
     __shared__ uint32_t any_esc;
+    // [r4] the 64 KiB of code lengths go through LDS (dynamic: REGION_BITS_LDS): in slab order the pairs' lengths lie 256 bytes
+    // apart in len8, and two such byte gathers per word made this little kernel take 60 us (1.2 % of a 2 GiB shard's step)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lens[];
+    for (uint32_t i = threadIdx.x; i < 65536u / 16u; i += 1024u) reinterpret_cast<uint4 *>(lens)[i] = reinterpret_cast<const uint4 *>(len8)[i];
     if (threadIdx.x == 0) any_esc = 0;
     __syncthreads();
     const uint32_t w = blockIdx.x, tid = threadIdx.x;
@@ -816,7 +820,7 @@ __global__ __launch_bounds__(1024) void region_bits_kernel(const HistHeader *hdr
     for (uint32_t i = tid; i < 32768u; i += 1024u) {
         const uint32_t v = sl[i];
         const uint32_t s0 = i, s1 = i | 0x8000u;
-        const uint32_t l0 = len8[hist_slot_prev(s0) * 256u + (s0 >> 8)], l1 = len8[hist_slot_prev(s1) * 256u + (s1 >> 8)];
+        const uint32_t l0 = lens[hist_slot_prev(s0) * 256u + (s0 >> 8)], l1 = lens[hist_slot_prev(s1) * 256u + (s1 >> 8)];
         acc += (unsigned long long)(v & 0xFFFFu) * l0;
         acc += (unsigned long long)(v >> 16) * l1;
         esc |= ((v & 0xFFFFu) && l0 > uint32_t(mh::ENC16_MAX_LEN)) || ((v >> 16) && l1 > uint32_t(mh::ENC16_MAX_LEN));
@@ -826,7 +830,7 @@ __global__ __launch_bounds__(1024) void region_bits_kernel(const HistHeader *hdr
     if (nc > expect.cross_cap && tid == 0) atomicExch(status, MHK_STATUS_CAPACITY);
     for (uint32_t i = tid; i < (nc < expect.cross_cap ? nc : expect.cross_cap); i += 1024u) {
         const uint32_t sl2 = cross[1u + i];
-        const uint32_t l2 = len8[hist_slot_prev(sl2) * 256u + (sl2 >> 8)];
+        const uint32_t l2 = lens[hist_slot_prev(sl2) * 256u + (sl2 >> 8)];
         acc += 16384ull * l2;
         esc |= l2 > uint32_t(mh::ENC16_MAX_LEN);
     }
@@ -1471,6 +1475,7 @@ hipError_t launch_encode_regions(const EncodeArgs &a, const void *d_hist_ws, siz
     if (!d_hist_ws || hist_ws_bytes < g.total || g.grid > 1024) return hipErrorInvalidValue;
     e = once_per_device(&DeviceState::region_ready, [] {
         hipError_t r = allow_lds(reinterpret_cast<const void *>(enc_region_kernel<false>), REGION_LDS_BYTES);
+        if (r == hipSuccess) r = allow_lds(reinterpret_cast<const void *>(region_bits_kernel), 65536);
         return r != hipSuccess ? r : allow_lds(reinterpret_cast<const void *>(enc_region_kernel<true>), REGION_LDS_BYTES);
     });
     if (e != hipSuccess) return e;
@@ -1479,7 +1484,7 @@ hipError_t launch_encode_regions(const EncodeArgs &a, const void *d_hist_ws, siz
     unsigned long long *region_start = region_bits + 1024;
     uint32_t *region_esc = reinterpret_cast<uint32_t *>(region_start + 1024);
     const HistHeader expect{HIST_WS_MAGIC, a.n, reinterpret_cast<unsigned long long>(a.data), g.region_vecs, uint32_t(g.grid), a.prev0, g.cross_cap, 0};
-    hipLaunchKernelGGL(region_bits_kernel, dim3(g.grid), dim3(1024), 0, st, reinterpret_cast<const HistHeader *>(hws + 64), expect,
+    hipLaunchKernelGGL(region_bits_kernel, dim3(g.grid), dim3(1024), 65536, st, reinterpret_cast<const HistHeader *>(hws + 64), expect,
                        reinterpret_cast<const uint32_t *>(hws + g.off_slab), reinterpret_cast<const uint32_t *>(hws + g.off_cross), a.len8,
                        region_bits, region_esc, status);
     hipLaunchKernelGGL(region_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, region_bits, uint32_t(g.grid), region_start, a.start_bit,

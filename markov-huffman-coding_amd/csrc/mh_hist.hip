@@ -176,16 +176,27 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_o1_kernel(const uint8_t *__
 // must be the number of bytes counted (the reference's counts sum to the file size, src/main.cpp:176-178); a 16-bit
 // field that spilled into its neighbour, a lost fix-up or a damaged slab all break that, and the last block to finish
 // says so in the status word (mh_dev_status -> MH_ERR_CORRUPT).
+// [r4] A block is 64 words x 4 slices of the slabs (a thread's loop over all 256 slabs was a chain of 256 loads on 2 waves per
+// CU: 72 us whatever the input size, 1.5 % of a 2 GiB shard's step); the four partial sums meet in LDS.
+constexpr uint32_t HIST_REDUCE_WORDS = 64, HIST_REDUCE_SLICES = 4;
 __global__ __launch_bounds__(256) void hist_reduce_kernel(const uint32_t *__restrict__ slab, uint32_t nslab, unsigned long long *counts,
                                                           unsigned int *check, unsigned long long n) {
-    __shared__ unsigned long long part[4];
-    const uint32_t w = blockIdx.x * 256u + threadIdx.x;          // < 32768
+    __shared__ unsigned long long plo[HIST_REDUCE_SLICES][HIST_REDUCE_WORDS], phi[HIST_REDUCE_SLICES][HIST_REDUCE_WORDS];
+    const uint32_t col = threadIdx.x & (HIST_REDUCE_WORDS - 1u), slice = threadIdx.x / HIST_REDUCE_WORDS;
+    const uint32_t w = blockIdx.x * HIST_REDUCE_WORDS + col;     // < 32768
+    const uint32_t per = (nslab + HIST_REDUCE_SLICES - 1u) / HIST_REDUCE_SLICES;
+    const uint32_t s_begin = slice * per, s_end = s_begin + per < nslab ? s_begin + per : nslab;
     unsigned long long lo = 0, hi = 0;
-    for (uint32_t s = 0; s < nslab; ++s) {
+    for (uint32_t s = s_begin; s < s_end; ++s) {
         const uint32_t v = slab[size_t(s) * 32768u + w];
         lo += v & 0xFFFFu;
         hi += v >> 16;
     }
+    plo[slice][col] = lo; phi[slice][col] = hi;
+    __syncthreads();
+    if (slice != 0) return;
+#pragma unroll
+    for (uint32_t k = 1; k < HIST_REDUCE_SLICES; ++k) { lo += plo[k][col]; hi += phi[k][col]; }
     const uint32_t s1 = w | 0x8000u;
     const unsigned long long c0 = counts[hist_slot_prev(w) * 256u + (w >> 8)] + lo;
     const unsigned long long c1 = counts[hist_slot_prev(s1) * 256u + (s1 >> 8)] + hi;
@@ -193,12 +204,10 @@ __global__ __launch_bounds__(256) void hist_reduce_kernel(const uint32_t *__rest
     counts[hist_slot_prev(s1) * 256u + (s1 >> 8)] = c1;
     if (!check) return;
     unsigned long long t = c0 + c1;
-    for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d);
-    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = t;
-    __syncthreads();
+    for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d);     // (slice 0 is one wave)
     if (threadIdx.x == 0) {
         unsigned long long *total = reinterpret_cast<unsigned long long *>(check + 2);
-        atomicAdd(total, part[0] + part[1] + part[2] + part[3]);
+        atomicAdd(total, t);
         __threadfence();
         if (atomicAdd(check + 4, 1u) == gridDim.x - 1u) {       // the last block: every block's share is in
             const unsigned long long all = atomicAdd(total, 0ull);
@@ -413,7 +422,7 @@ hipError_t launch_hist_o1(const uint8_t *d_data, uint64_t n, uint32_t prev0, uns
         uint32_t *slab = reinterpret_cast<uint32_t *>(ws + g.off_slab);
         hipLaunchKernelGGL(kern, dim3(g.grid), dim3(HIST_THREADS), HIST_LDS_BYTES, st, d_data, n, prev0, d_counts, slab,
                            g.region_vecs, reinterpret_cast<uint32_t *>(ws + g.off_cross), g.cross_cap);
-        hipLaunchKernelGGL(hist_reduce_kernel, dim3(32768 / 256), dim3(256), 0, st, slab, uint32_t(g.grid), d_counts, check,
+        hipLaunchKernelGGL(hist_reduce_kernel, dim3(32768 / HIST_REDUCE_WORDS), dim3(256), 0, st, slab, uint32_t(g.grid), d_counts, check,
                            (unsigned long long)(n));
         return hipGetLastError();
     }
@@ -424,7 +433,7 @@ hipError_t launch_hist_o1(const uint8_t *d_data, uint64_t n, uint32_t prev0, uns
     uint32_t *slab = (ws_ok && ws_bytes >= 256 + size_t(grid) * 32768u * 4u) ? reinterpret_cast<uint32_t *>(ws + 256) : nullptr;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(HIST_THREADS), HIST_LDS_BYTES, st, d_data, n, prev0, d_counts, slab,
                        uint64_t(0), static_cast<uint32_t *>(nullptr), 0u);
-    if (slab) hipLaunchKernelGGL(hist_reduce_kernel, dim3(32768 / 256), dim3(256), 0, st, slab, uint32_t(grid), d_counts, check,
+    if (slab) hipLaunchKernelGGL(hist_reduce_kernel, dim3(32768 / HIST_REDUCE_WORDS), dim3(256), 0, st, slab, uint32_t(grid), d_counts, check,
                                  (unsigned long long)(n));
     return hipGetLastError();
 }
