@@ -33,7 +33,7 @@ EXPORTS = [
     "mh_model_from_table_bits", "mh_model_write_table",
     "mh_model_type", "mh_model_max_code_len", "mh_model_get_code", "mh_model_get_lut", "mh_model_decode_layout", "mh_model_tile_layout",
     "mh_model_image", "mh_model_free",
-    "mh_set_input_residency", "mh_histogram_o1", "mh_histogram_o0", "mh_histogram_o2", "mh_dev_histogram_o2", "mh_encode", "mh_encode_bound", "mh_stream_header",
+    "mh_set_input_residency", "mh_histogram_o1", "mh_histogram_o0", "mh_histogram_o2", "mh_dev_histogram_o2", "mh_dev_histogram_o2_ws", "mh_dev_histogram_o2_workspace", "mh_encode", "mh_encode_bound", "mh_stream_header",
     "mh_stream_parse_header", "mh_decode",
     "mh_dev_histogram_workspace", "mh_dev_histogram_o1", "mh_dev_histogram_o0",
     "mh_decode_to", "mh_model_payload_bits", "mh_dev_encode_workspace", "mh_dev_encode", "mh_dev_payload_bits", "mh_dev_encode_at", "mh_dev_encode_ctx", "mh_dev_encode_hist", "mh_dev_decode_workspace", "mh_dev_decode", "mh_dev_decode_dn",
@@ -90,6 +90,9 @@ def lib():
         l.mh_histogram_o0.argtypes = [vp, sz, vp]
         l.mh_histogram_o2.argtypes = [vp, sz, vp]
         l.mh_dev_histogram_o2.argtypes = [vp, sz, C.c_uint16, vp, vp]
+        l.mh_dev_histogram_o2_ws.argtypes = [vp, sz, C.c_uint16, vp, vp, sz, vp]
+        l.mh_dev_histogram_o2_workspace.argtypes = [sz]
+        l.mh_dev_histogram_o2_workspace.restype = sz
         l.mh_encode.argtypes = [vp, vp, sz, u8, vp, sz, pu64, vp, u32]
         l.mh_encode_bound.argtypes = [vp, sz]
         l.mh_encode_bound.restype = sz

@@ -1144,10 +1144,18 @@ int mh_dev_histogram_o0(const uint8_t *d_data, size_t n, uint64_t *d_counts, voi
     return MH_OK;
 }
 
-int mh_dev_histogram_o2(const uint8_t *d_data, size_t n, uint16_t ctx0, uint64_t *d_counts, void *stream) {
+size_t mh_dev_histogram_o2_workspace(size_t n) { return mhk::hist2_workspace_bytes(n); }
+
+int mh_dev_histogram_o2_ws(const uint8_t *d_data, size_t n, uint16_t ctx0, uint64_t *d_counts, void *d_ws, size_t ws_bytes, void *stream) {
     if ((!d_data && n) || !d_counts || !aligned16(d_data)) return MH_ERR_ARG;
-    HIP_TRY(mhk::launch_hist_o2(d_data, n, ctx0, reinterpret_cast<unsigned long long *>(d_counts), static_cast<hipStream_t>(stream)));
+    if (d_ws && (reinterpret_cast<uintptr_t>(d_ws) & 255u)) return MH_ERR_ARG;
+    HIP_TRY(mhk::launch_hist_o2(d_data, n, ctx0, reinterpret_cast<unsigned long long *>(d_counts), d_ws, ws_bytes,
+                                static_cast<hipStream_t>(stream)));
     return MH_OK;
+}
+
+int mh_dev_histogram_o2(const uint8_t *d_data, size_t n, uint16_t ctx0, uint64_t *d_counts, void *stream) {
+    return mh_dev_histogram_o2_ws(d_data, n, ctx0, d_counts, nullptr, 0, stream);
 }
 
 // The encode workspace also has room for a region-mode histogram of the input (workspace + 65536 counts): an
@@ -1511,7 +1519,8 @@ static int histogram_host(const uint8_t *data, size_t n, uint8_t prev0, uint64_t
     }
     if (!d_all) HIP_TRY(d_data.alloc(n < seg ? n : seg));
     HIP_TRY(d_counts.alloc(nc * 8));
-    const size_t hws = order == 1 && n >= (size_t(1) << 20) ? mh_dev_histogram_workspace(n) : 0;   // pays from about a megabyte on
+    const size_t hws = order == 1 && n >= (size_t(1) << 20) ? mh_dev_histogram_workspace(n)   // pays from about a megabyte on
+                       : order == 2 ? mh_dev_histogram_o2_workspace(n < seg ? n : seg) : 0;  // (order 2: room for the partition path)
     if (hws) HIP_TRY(d_hws.alloc(hws));
     std::vector<uint64_t> part(nc);
     for (size_t i = 0; i < nc; ++i) counts[i] = 0;
@@ -1521,7 +1530,7 @@ static int histogram_host(const uint8_t *data, size_t n, uint8_t prev0, uint64_t
         if (len) HIP_TRY(stage_h2d(d_seg, data + off, len, nullptr));
         const uint8_t p0 = off ? data[off - 1] : prev0;            // context carried across the seam (src/main.cpp:32,36)
         const uint16_t c0 = off ? uint16_t(data[off - 2] << 8 | data[off - 1]) : uint16_t(prev0 << 8 | prev0);   // segments are >= 8 KiB
-        int rc = order == 2 ? mh_dev_histogram_o2(d_seg, len, c0, d_counts.as<uint64_t>(), nullptr)
+        int rc = order == 2 ? mh_dev_histogram_o2_ws(d_seg, len, c0, d_counts.as<uint64_t>(), d_hws.p, hws, nullptr)
                  : order ? mh_dev_histogram_o1(d_seg, len, p0, d_counts.as<uint64_t>(), hws ? d_hws.p : nullptr, hws, nullptr)
                          : mh_dev_histogram_o0(d_seg, len, d_counts.as<uint64_t>(), nullptr, 0, nullptr);
         if (rc != MH_OK) return rc;

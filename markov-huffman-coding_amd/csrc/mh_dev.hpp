@@ -196,6 +196,32 @@ __device__ __forceinline__ uint32_t hist_mix(uint32_t sym) { return (sym ^ (sym 
 __device__ __forceinline__ uint32_t hist_slot(uint32_t prev, uint32_t sym) { return (sym << 8) | (prev ^ hist_mix(sym)); }
 __device__ __forceinline__ uint32_t hist_slot_prev(uint32_t slot) { return (slot & 255u) ^ hist_mix(slot >> 8); }
 
+// cross (region mode): the workgroup's list of crossings, [0] = count, then the slots — with the slab it gives
+// the workgroup's own exact pair counts (field + 16384 per listed crossing), which is what lets the encoder
+// price its region without a length pass (enc_region_kernel)
+// GUARD = counter bits of a 16-bit field: 14 (two guard bits, the product) or 15 (one guard bit: round 1's
+// version, which loses counts on runs of one pair — kept ONLY as MH_DEBUG_HIST_GUARD1=1, so that a test can watch
+// the conservation check of hist_reduce_kernel catch a spill)
+template <int GUARD>
+__device__ __forceinline__ void hist_fixup(uint32_t *h, unsigned long long *counts, uint32_t slot, uint32_t *cross, uint32_t cross_cap) {
+    atomicSub(&h[slot & 0x7FFFu], (slot >> 15) ? (GUARD < 16 ? (0x10000u << (GUARD & 15)) : 0u) : (1u << GUARD));
+    atomicAdd(&counts[hist_slot_prev(slot) * 256u + (slot >> 8)], (unsigned long long)(1u << GUARD));
+    if (cross) {
+        const uint32_t i = atomicAdd(&cross[0], 1u);
+        if (i < cross_cap) cross[1u + i] = slot;
+    }
+}
+
+template <int GUARD>
+__device__ __forceinline__ void hist_add(uint32_t *h, unsigned long long *counts, uint32_t prev, uint32_t sym, uint32_t *cross,
+                                         uint32_t cross_cap) {
+    constexpr uint32_t CROSS = ((0x10000u - (1u << GUARD)) & 0xFFFFu) * 0x10001u;   // 0xC000C000 for 14 bits
+    const uint32_t slot = hist_slot(prev, sym);
+    const uint32_t inc = (slot >> 15) ? 0x10000u : 1u;
+    const uint32_t old = atomicAdd(&h[slot & 0x7FFFu], inc);
+    if (((old + inc) ^ old) & CROSS) hist_fixup<GUARD>(h, counts, slot, cross, cross_cap);
+}
+
 constexpr uint64_t HIST_WS_MAGIC = 0x4D48525247303031ull;                 // "MHRRG001"
 
 struct HistHeader { unsigned long long magic, n, data, region_vecs; uint32_t grid, prev0, cross_cap, pad; };

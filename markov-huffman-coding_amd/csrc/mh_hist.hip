@@ -1,7 +1,7 @@
 // mh_hist.hip — histograms of the Markov-Huffman hot path for gfx950 (order 2: N4).
 //   hist_o1_kernel     256x256 conditional histogram, LDS-resident packed counters (+ slab reduce)   (a1)
 //   hist_o0_kernel     256-bin histogram                                                            (a2)
-//   hist_o2_kernel     65536 x 256 counters in HBM behind an LDS tag cache (extension, parity unpinned)
+//   (order 2: mh_hist2.hip)
 // All integer work: no MFMA.  Waves are 64 wide; workgroups never wait for each other.
 #include "mh_dev.hpp"
 
@@ -31,31 +31,7 @@ hipError_t launch_set_word(uint32_t *d_word, uint32_t v, hipStream_t st) {
 // test_histogram_guard_bit_fixups_many_per_workgroup caught it losing 8 x 32768 counts on 64 MiB of zeros.
 
 
-// cross (region mode): the workgroup's list of crossings, [0] = count, then the slots — with the slab it gives
-// the workgroup's own exact pair counts (field + 16384 per listed crossing), which is what lets the encoder
-// price its region without a length pass (enc_region_kernel)
-// GUARD = counter bits of a 16-bit field: 14 (two guard bits, the product) or 15 (one guard bit: round 1's
-// version, which loses counts on runs of one pair — kept ONLY as MH_DEBUG_HIST_GUARD1=1, so that a test can watch
-// the conservation check of hist_reduce_kernel catch a spill)
-template <int GUARD>
-__device__ __forceinline__ void hist_fixup(uint32_t *h, unsigned long long *counts, uint32_t slot, uint32_t *cross, uint32_t cross_cap) {
-    atomicSub(&h[slot & 0x7FFFu], (slot >> 15) ? (GUARD < 16 ? (0x10000u << (GUARD & 15)) : 0u) : (1u << GUARD));
-    atomicAdd(&counts[hist_slot_prev(slot) * 256u + (slot >> 8)], (unsigned long long)(1u << GUARD));
-    if (cross) {
-        const uint32_t i = atomicAdd(&cross[0], 1u);
-        if (i < cross_cap) cross[1u + i] = slot;
-    }
-}
-
-template <int GUARD>
-__device__ __forceinline__ void hist_add(uint32_t *h, unsigned long long *counts, uint32_t prev, uint32_t sym, uint32_t *cross,
-                                         uint32_t cross_cap) {
-    constexpr uint32_t CROSS = ((0x10000u - (1u << GUARD)) & 0xFFFFu) * 0x10001u;   // 0xC000C000 for 14 bits
-    const uint32_t slot = hist_slot(prev, sym);
-    const uint32_t inc = (slot >> 15) ? 0x10000u : 1u;
-    const uint32_t old = atomicAdd(&h[slot & 0x7FFFu], inc);
-    if (((old + inc) ^ old) & CROSS) hist_fixup<GUARD>(h, counts, slot, cross, cross_cap);
-}
+// (hist_fixup / hist_add: mh_dev.hpp — the order-2 bucket kernel counts with the same fields)
 
 // slab: when not null, every workgroup stores its 32768 LDS words there (plain coalesced stores) and
 // hist_reduce_kernel sums the slabs afterwards; 16.7 M device-scope 64-bit atomics on the same 512 KiB
@@ -249,127 +225,6 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_o0_kernel(const uint8_t *__
 }
 
 
-// ---- histogram: counts[ctx * 256 + sym] (64-bit, HBM).  A workgroup keeps 16384 (key, count) slots in LDS,
-// an open-addressed table with linear probing: the first key to claim a slot owns it for the whole launch
-// (tags never change once set, so a claim is one compare-and-swap and there is no eviction race); every
-// later occurrence of that key is one LDS add.  A key that finds no slot within its probe limit goes
-// straight to a 64-bit global atomic.  The probing matters more than it looks: text-like sources have a
-// few thousand live keys, and ONE frequent key that loses its slot to an earlier one sends ~1 % of the
-// stream to a single HBM address, where memory-side atomics serialise (first version, no probing: 83 ms
-// per 4 GiB of text with 1.5 % of the symbols on 31 such addresses).  Flat sources (millions of live keys)
-// fill the table at once; from 3/4 occupancy on a key gets two probes, so the misses stay cheap and the
-// kernel degrades to the global-atomic rate over many addresses.
-constexpr int H2_THREADS = 1024;
-constexpr uint32_t H2_SLOTS = 16384;
-constexpr uint32_t H2_EMPTY = 0xFFFFFFFFu;
-constexpr int H2_LDS_BYTES = int(H2_SLOTS) * 8 + 64 * 4 + 16;     // tags, counters + one dummy word per lane, the claim counter
-constexpr uint32_t H2_PROBES = 8, H2_PROBES_FULL = 2, H2_FULL = H2_SLOTS * 3 / 4;
-
-// the two slots a key may own without probing: 14 bits each of one 32-bit product
-__device__ __forceinline__ void hist2_slots(uint32_t key, uint32_t &s1, uint32_t &s2) {
-    const uint32_t h = key * 0x9E3779B1u;
-    s1 = h >> 18;
-    s2 = (h >> 4) & (H2_SLOTS - 1u);
-}
-// the whole story for one key: its first slot, its second, then linear probing behind the first, then memory
-__device__ __forceinline__ void hist2_add(uint32_t *tag, uint32_t *cnt, uint32_t *used, unsigned long long *counts, uint32_t key,
-                                          uint32_t probes) {
-    uint32_t s1, s2;
-    hist2_slots(key, s1, s2);
-    uint32_t slot = s1;
-    for (uint32_t p = 0; p < probes + 1u; ++p) {
-        // a plain read first: once its tag is set (tags never change) a key costs one read, which the LDS broadcasts
-        // to all the lanes that ask for the same slot, and one add — not a compare-and-swap that serialises them
-        uint32_t t = __hip_atomic_load(&tag[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (t == H2_EMPTY) {
-            t = atomicCAS(&tag[slot], H2_EMPTY, key);
-            if (t == H2_EMPTY) { atomicAdd(used, 1u); t = key; }
-        }
-        if (t == key) { atomicAdd(&cnt[slot], 1u); return; }
-        slot = p == 0 ? s2 : ((p == 1 ? s1 : slot) + 1u) & (H2_SLOTS - 1u);
-    }
-    atomicAdd(&counts[key], 1ull);
-}
-
-__global__ __launch_bounds__(H2_THREADS) void hist_o2_kernel(const uint8_t *__restrict__ data, uint64_t n, uint32_t ctx0,
-                                                             unsigned long long *counts) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *tag = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *cnt = tag + H2_SLOTS;                              // (+ 64 dummy words behind the slots)
-    uint32_t *used = cnt + H2_SLOTS + 64;                        // slots claimed so far
-    for (uint32_t i = threadIdx.x; i < H2_SLOTS; i += H2_THREADS) { tag[i] = H2_EMPTY; cnt[i] = 0; }
-    if (threadIdx.x == 0) *used = 0;
-    __syncthreads();
-    const uint64_t nvec = n >> 4;
-    const uint4 *vdata = reinterpret_cast<const uint4 *>(data);
-    // whole waves stay in the loop together (the neighbour's bytes come by shuffle)
-    const uint64_t nvec_up = (nvec + 63) & ~uint64_t(63);
-    const uint64_t vstep = uint64_t(gridDim.x) * H2_THREADS;
-    const uint32_t dummy = H2_SLOTS + (threadIdx.x & 63u);       // where a lane's add goes when the slot it read is not its key's
-    uint64_t v = uint64_t(blockIdx.x) * H2_THREADS + threadIdx.x;
-    uint4 ahead = v < nvec ? vdata[v] : make_uint4(0, 0, 0, 0);
-    for (; v < nvec_up; v += vstep) {
-        const bool live = v < nvec;
-        const uint4 x4 = ahead;
-        if (v + vstep < nvec) ahead = vdata[v + vstep];
-        const uint32_t up = __shfl_up(x4.w >> 16, 1);
-        uint32_t ctx = ((up & 255u) << 8) | (up >> 8);
-        if ((threadIdx.x & 63u) == 0) ctx = live ? ctx_before(data, n, v << 4, ctx0) : ctx0;
-        if (!live) continue;
-        const uint32_t ctx_in = ctx;
-        const uint32_t x[4] = {x4.x, x4.y, x4.z, x4.w};
-        // The usual case without a branch: all sixteen tags are read at once, a key that finds its own tag adds to its slot,
-        // any other adds to a dummy word of the lane.  (The counters said what the symbol-by-symbol form below was waiting
-        // for: 30 scalar instructions and 8.5 branches per symbol, the exec-mask bookkeeping of sixteen divergent probe
-        // loops in a row, with the LDS 25 % and the vector ALU 29 % busy.)  Keys that miss — every key once per workgroup,
-        // and what the table cannot hold — go through hist2_add afterwards.
-        uint32_t key[16], sa[16], sb[16], ta[16], tb[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            key[j] = (ctx << 8) | ((x[j >> 2] >> (8 * (j & 3))) & 255u);
-            ctx = key[j] & 0xFFFFu;
-            hist2_slots(key[j], sa[j], sb[j]);
-            ta[j] = __hip_atomic_load(&tag[sa[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            tb[j] = __hip_atomic_load(&tag[sb[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        uint32_t missed = 0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const bool ha = ta[j] == key[j], hb = tb[j] == key[j];
-            atomicAdd(&cnt[ha ? sa[j] : hb ? sb[j] : dummy], 1u);
-            missed |= (ha || hb) ? 0u : (1u << j);
-        }
-        if (missed) {                                            // (divergent, rare once the table is warm)
-            const uint32_t probes = *used < H2_FULL ? H2_PROBES : H2_PROBES_FULL;
-            // every lane takes ITS next missed symbol per trip: as many trips as the worst lane has misses, not sixteen
-            const uint64_t xlo = uint64_t(x4.x) | uint64_t(x4.y) << 32, xhi = uint64_t(x4.z) | uint64_t(x4.w) << 32;
-            while (missed) {
-                const uint32_t j = uint32_t(__builtin_ctz(missed));
-                missed &= missed - 1u;
-                // bytes j - 2, j - 1, j of the lane's stream: the incoming context supplies what lies before byte 0
-                const uint32_t b0 = uint32_t(((j < 8u ? xlo : xhi) >> (8u * (j & 7u))) & 255u);
-                const uint32_t j1 = j - 1u, j2 = j - 2u;
-                const uint32_t b1 = j >= 1u ? uint32_t(((j1 < 8u ? xlo : xhi) >> (8u * (j1 & 7u))) & 255u) : (ctx_in & 255u);
-                const uint32_t b2 = j >= 2u ? uint32_t(((j2 < 8u ? xlo : xhi) >> (8u * (j2 & 7u))) & 255u) : j == 1u ? (ctx_in & 255u) : (ctx_in >> 8);
-                hist2_add(tag, cnt, used, counts, (b2 << 16) | (b1 << 8) | b0, probes);
-            }
-        }
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {                   // ragged tail (< 16 bytes)
-        uint64_t i = nvec << 4;
-        uint32_t ctx = ctx_before(data, n, i, ctx0);
-        for (; i < n; ++i) {
-            const uint32_t key = (ctx << 8) | data[i];
-            atomicAdd(&counts[key], 1ull);
-            ctx = key & 0xFFFFu;
-        }
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < H2_SLOTS; i += H2_THREADS)
-        if (tag[i] != H2_EMPTY && cnt[i]) atomicAdd(&counts[tag[i]], (unsigned long long)cnt[i]);
-}
-
-
 size_t hist_workspace_bytes(uint64_t n) { return region_geom(n).total; }
 
 hipError_t launch_hist_o1(const uint8_t *d_data, uint64_t n, uint32_t prev0, unsigned long long *d_counts, void *d_ws, size_t ws_bytes,
@@ -447,19 +302,6 @@ hipError_t launch_hist_o0(const uint8_t *d_data, uint64_t n, unsigned long long 
     hipLaunchKernelGGL(hist_o0_kernel, dim3(grid), dim3(HIST_THREADS), 0, st, d_data, n, d_counts);
     return hipGetLastError();
 }
-
-hipError_t launch_hist_o2(const uint8_t *d_data, uint64_t n, uint32_t ctx0, unsigned long long *d_counts, hipStream_t st) {
-    hipError_t e = hipMemsetAsync(d_counts, 0, (size_t(1) << 24) * sizeof(unsigned long long), st);
-    if (e != hipSuccess || n == 0) return e;
-    e = once_per_device(&DeviceState::hist2_ready, [] { return allow_lds(reinterpret_cast<const void *>(hist_o2_kernel), H2_LDS_BYTES); });
-    if (e != hipSuccess) return e;
-    const uint64_t nvec = n >> 4;
-    const uint64_t want = (nvec + H2_THREADS - 1) / H2_THREADS;
-    const int grid = int(want < 1 ? 1 : (want > uint64_t(cu_count()) ? uint64_t(cu_count()) : want));
-    hipLaunchKernelGGL(hist_o2_kernel, dim3(grid), dim3(H2_THREADS), H2_LDS_BYTES, st, d_data, n, ctx0, d_counts);
-    return hipGetLastError();
-}
-
 
 // workspace: [0,64) status | wt_bits u32[nwt] | wt_start u64[nwt] | blk_sum u64[nblk + 1]
 

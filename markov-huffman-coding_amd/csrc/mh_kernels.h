@@ -243,7 +243,12 @@ size_t hist_workspace_bytes(uint64_t n);
 hipError_t launch_hist_o1(const uint8_t *d_data, uint64_t n, uint32_t prev0, unsigned long long *d_counts, void *d_ws, size_t ws_bytes,
                           hipStream_t st);
 hipError_t launch_hist_o0(const uint8_t *d_data, uint64_t n, unsigned long long *d_counts, hipStream_t st);
-hipError_t launch_hist_o2(const uint8_t *d_data, uint64_t n, uint32_t ctx0, unsigned long long *d_counts, hipStream_t st);
+// order 2: d_ws (256-byte aligned, hist2_workspace_bytes(n)) lets sources with millions of live keys take the partition path;
+// without it everything goes through the tag cache.  The workspace's first words afterwards: [0] status, [2] the choices made
+// (bit 0: a slab stayed in the tag cache, bit 1: a slab was partitioned).
+size_t hist2_workspace_bytes(uint64_t n);
+hipError_t launch_hist_o2(const uint8_t *d_data, uint64_t n, uint32_t ctx0, unsigned long long *d_counts, void *d_ws, size_t ws_bytes,
+                          hipStream_t st);
 size_t encode_workspace_bytes(uint64_t n);
 hipError_t launch_encode(const EncodeArgs &a, void *d_ws, hipStream_t st);
 hipError_t launch_encode_regions(const EncodeArgs &a, const void *d_hist_ws, size_t hist_ws_bytes, void *d_ws, hipStream_t st);

@@ -294,7 +294,8 @@ class HipBackend:
         self.use_fine = bool(use_fine) and not (order == 1 and two_pass_encode)
         self.fine_symbols = int(os.environ.get("MH_FINE_SYMBOLS", "64"))        # (an experimental library build may use 32)
         self.fine = torch.empty(max((n + self.fine_symbols - 1) // self.fine_symbols, 1), dtype=torch.int32, device=dev) if self.use_fine else None
-        self.hist_ws_bytes = int(self.lib.mh_dev_histogram_workspace(n))
+        # order 1: the region histogram the encoder prices from; order 2: room for the partition path (flat sources)
+        self.hist_ws_bytes = int(self.lib.mh_dev_histogram_o2_workspace(n) if order == 2 else self.lib.mh_dev_histogram_workspace(n))
         self.hist_ws = torch.empty(max(self.hist_ws_bytes, 64), dtype=torch.uint8, device=dev)
         self.enc_ws_bytes = int(self.lib.mh_dev_encode_workspace(n))
         self.enc_ws = torch.empty(self.enc_ws_bytes + 64, dtype=torch.uint8, device=dev)
@@ -328,7 +329,8 @@ class HipBackend:
             raise ValueError("shard of %d bytes, buffers for %d" % (n, self.n))
         self.n_now = n
         if self.order == 2:         # extension (parity unpinned): 65536 two-byte contexts, counts in HBM; prev0: 16-bit context
-            self._check(self.lib.mh_dev_histogram_o2(shard.data_ptr(), n, prev0, self.counts.data_ptr(), self._stream()), "mh_dev_histogram_o2")
+            self._check(self.lib.mh_dev_histogram_o2_ws(shard.data_ptr(), n, prev0, self.counts.data_ptr(),
+                                                        self.hist_ws.data_ptr(), self.hist_ws_bytes, self._stream()), "mh_dev_histogram_o2_ws")
         else:                       # region mode: the regions' own pair counts stay in hist_ws for the encoder
             self._check(self.lib.mh_dev_histogram_o1(shard.data_ptr(), n, prev0, self.counts.data_ptr(),
                                                      self.hist_ws.data_ptr(), self.hist_ws_bytes, self._stream()), "mh_dev_histogram_o1")
