@@ -178,7 +178,7 @@ int mh_dev_histogram_o2(const uint8_t *d_data, size_t n, uint16_t ctx0, uint64_t
  * most 4 GiB, + 34 to 97 MiB of tables): sources with millions of live (context, symbol) keys — Zipf or uniform bytes — overflow the kernel's LDS tag
  * cache and would count at the rate of 64-bit global atomics (36 ms per GiB); with the workspace such a slab of the input is
  * partitioned by the context's high byte and every bucket counted in LDS like an order-1 histogram.  The choice is made on
- * the device per 2 GiB slab, from the cache misses of the slab's first 8 MiB; mh_dev_index_path(d_ws) afterwards says what
+ * the device per 2 GiB slab, from the cache misses of the slab's first 4 MiB; mh_dev_index_path(d_ws) afterwards says what
  * was chosen (bit 0: a slab stayed in the tag cache, bit 1: a slab was partitioned).  Without a workspace (or below 32 MiB) everything goes through the tag cache. */
 size_t mh_dev_histogram_o2_workspace(size_t n);
 int mh_dev_histogram_o2_ws(const uint8_t *d_data, size_t n, uint16_t ctx0, uint64_t *d_counts /* 1 << 24 */,

@@ -8,7 +8,7 @@
 //                       context's high byte — 256 buckets of (previous byte, symbol) pairs, two bytes per position, staged
 //                       through LDS so that every bucket is written in runs — and each bucket is then an order-1 problem:
 //                       65 536 packed counters in LDS (the order-1 kernel's two-guard-bit fields), flushed once per chunk.
-// Which one runs is decided on the device, per slab of the input, from the cache misses of the slab's first 8 MiB
+// Which one runs is decided on the device, per slab of the input, from the cache misses of the slab's first 4 MiB
 // (which are counted either way): no host round trip.  All integer work, 64-wide waves, no workgroup waits for another.
 #include "mh_dev.hpp"
 
@@ -177,7 +177,7 @@ constexpr int H2P_G = 256;
 constexpr uint32_t H2P_TILE = 65536;                             // bytes = positions per tile: 64 per thread
 constexpr uint32_t H2P_CHUNK = 1u << 22;                         // pairs per work item of the bucket kernel
 constexpr uint64_t H2P_PAD_PAIRS = 256ull * H2P_G * 8;                // room for the padding of every (workgroup, bucket) share
-constexpr uint64_t H2P_SAMPLE = 8ull << 20;                      // bytes of a slab that go through the tag cache to choose the path
+constexpr uint64_t H2P_SAMPLE = 4ull << 20;                      // bytes of a slab that go through the tag cache to choose the path
 constexpr uint64_t H2P_MIN = 32ull << 20;                        // slabs shorter than this are not worth four more launches
 constexpr uint64_t H2P_SLAB = 2ull << 30;                        // bytes per slab: a 4 GiB pair buffer at most
 
@@ -198,16 +198,21 @@ static inline H2Geom hist2_geom(uint64_t n, uint64_t slab) {
     return g;
 }
 
+// 64 private copies of the 256 counters per workgroup — four per wave, chosen by the lane, 257 words apart so that the four
+// land in different banks: a frequent byte value (Zipf: one in six) would otherwise make ten lanes of every add queue up on
+// one LDS word (1.5 ms per 2 GiB of Zipf bytes against 0.63 of uniform ones with one copy per wave).
+constexpr int H2P_COUNT_STRIDE = 257, H2P_COUNT_LDS = 64 * H2P_COUNT_STRIDE * 4;
 __global__ __launch_bounds__(1024) void hist2_count_kernel(const uint8_t *__restrict__ base, uint64_t n_total, uint64_t lo, uint32_t ntiles,
                                                            uint32_t ctx0, uint32_t *cnt, const uint32_t *ctl) {
     if (ctl[1] != H2_SEL_PARTITION) return;
-    __shared__ uint32_t h[16][256];
-    for (int i = threadIdx.x; i < 16 * 256; i += 1024) (&h[0][0])[i] = 0;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *h = reinterpret_cast<uint32_t *>(smem);
+    for (int i = threadIdx.x; i < 64 * H2P_COUNT_STRIDE; i += 1024) h[i] = 0;
     __syncthreads();
     const uint32_t per = (ntiles + H2P_G - 1) / H2P_G;
     const uint32_t t0 = blockIdx.x * per < ntiles ? blockIdx.x * per : ntiles;
     const uint32_t t1 = t0 + per < ntiles ? t0 + per : ntiles;
-    uint32_t *mine = h[threadIdx.x >> 6];
+    uint32_t *mine = h + ((threadIdx.x >> 6) * 4u + (threadIdx.x & 3u)) * H2P_COUNT_STRIDE;
     const uint64_t b0 = lo + uint64_t(t0) * H2P_TILE, b1 = lo + uint64_t(t1) * H2P_TILE;
     const uint4 *vdata = reinterpret_cast<const uint4 *>(base);
     for (uint64_t v = (b0 >> 4) + threadIdx.x; v < (b1 >> 4); v += 1024) {
@@ -225,15 +230,15 @@ __global__ __launch_bounds__(1024) void hist2_count_kernel(const uint8_t *__rest
     // the buckets are the bytes two places EARLIER: the two bytes in front of the range come in, its last two go out
     if (threadIdx.x == 0 && t1 > t0) {
         const uint32_t c = ctx_before(base, n_total, b0, ctx0);
-        atomicAdd(&h[0][c >> 8], 1u);
-        atomicAdd(&h[0][c & 255u], 1u);
-        atomicSub(&h[0][base[b1 - 2]], 1u);
-        atomicSub(&h[0][base[b1 - 1]], 1u);
+        atomicAdd(&h[c >> 8], 1u);
+        atomicAdd(&h[c & 255u], 1u);
+        atomicSub(&h[base[b1 - 2]], 1u);
+        atomicSub(&h[base[b1 - 1]], 1u);
     }
     __syncthreads();
     if (threadIdx.x < 256) {
         uint32_t s = 0;
-        for (int w = 0; w < 16; ++w) s += h[w][threadIdx.x];
+        for (int w = 0; w < 64; ++w) s += h[w * H2P_COUNT_STRIDE + threadIdx.x];
         cnt[threadIdx.x * H2P_G + blockIdx.x] = s;
     }
 }
@@ -285,11 +290,12 @@ __global__ __launch_bounds__(1024) void hist2_offsets_kernel(const uint32_t *__r
 
 // LDS of the scatter kernel: the stage in units of eight pairs (a bucket's slot starts on a unit: the pairs carried over from
 // the tile before, then this tile's), and per bucket: the carried unit, stage-to-memory unit offset, next free unit in memory,
-// this tile's count, slot start, first free pair, whole units to write, pairs carried
+// this tile's count, slot start, first free pair, end of the slot's whole units, pairs carried; and the bucket of every unit
 constexpr uint32_t H2P_STAGE_UNITS = (H2P_TILE + 256u * 14u) / 8u;
 constexpr int H2P_L_CARRY = int(H2P_STAGE_UNITS) * 16, H2P_L_GUN = H2P_L_CARRY + 256 * 16, H2P_L_CURSOR = H2P_L_GUN + 256 * 8,
               H2P_L_COUNT = H2P_L_CURSOR + 256 * 8, H2P_L_SU = H2P_L_COUNT + 256 * 4, H2P_L_LBASE = H2P_L_SU + 260 * 4,
-              H2P_L_NUN = H2P_L_LBASE + 256 * 4, H2P_L_CARRYN = H2P_L_NUN + 256 * 4, H2P_SCATTER_LDS = H2P_L_CARRYN + 256 * 4;
+              H2P_L_UEND = H2P_L_LBASE + 256 * 4, H2P_L_CARRYN = H2P_L_UEND + 256 * 4, H2P_L_UOWN = H2P_L_CARRYN + 256 * 4,
+              H2P_SCATTER_LDS = H2P_L_UOWN + int(H2P_STAGE_UNITS);
 
 __global__ __launch_bounds__(1024) void hist2_scatter_kernel(const uint8_t *__restrict__ base, uint64_t n_total, uint64_t lo, uint32_t ntiles,
                                                              uint32_t ctx0, const unsigned long long *__restrict__ off, uint4 *pairs,
@@ -304,8 +310,9 @@ __global__ __launch_bounds__(1024) void hist2_scatter_kernel(const uint8_t *__re
     uint32_t *lcount = reinterpret_cast<uint32_t *>(smem + H2P_L_COUNT);
     uint32_t *su = reinterpret_cast<uint32_t *>(smem + H2P_L_SU);
     uint32_t *lbase = reinterpret_cast<uint32_t *>(smem + H2P_L_LBASE);
-    uint32_t *nun = reinterpret_cast<uint32_t *>(smem + H2P_L_NUN);
+    uint32_t *uend = reinterpret_cast<uint32_t *>(smem + H2P_L_UEND);
     uint32_t *carryn = reinterpret_cast<uint32_t *>(smem + H2P_L_CARRYN);
+    uint8_t *uown = smem + H2P_L_UOWN;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t per = (ntiles + H2P_G - 1) / H2P_G;
     const uint32_t t0 = blockIdx.x * per < ntiles ? blockIdx.x * per : ntiles;
@@ -361,21 +368,21 @@ __global__ __launch_bounds__(1024) void hist2_scatter_kernel(const uint8_t *__re
 #pragma unroll
             for (int i = 0; i < 4; ++i) s += (k[i] + c[i] + 7u) >> 3;
             uint32_t u = wave_inclusive_sum(s) - s;
-            uint32_t lb[4], nu[4], kn[4];
+            uint32_t lb[4], ue[4], kn[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const uint32_t a = 4u * lane + uint32_t(i), tot = k[i] + c[i];
                 su[a] = u;
-                lb[i] = u * 8u + k[i]; nu[i] = tot >> 3; kn[i] = tot & 7u;
+                lb[i] = u * 8u + k[i]; ue[i] = u + (tot >> 3); kn[i] = tot & 7u;
                 const unsigned long long cur = cursor[a];
                 gun[a] = cur - u;
-                cursor[a] = cur + nu[i];
+                cursor[a] = cur + (tot >> 3);
                 if (k[i]) stage[u] = carry[a];                   // what the tile before left over leads the slot
                 u += (tot + 7u) >> 3;
             }
             if (lane == 63) su[256] = u;
             reinterpret_cast<uint4 *>(lbase)[lane] = make_uint4(lb[0], lb[1], lb[2], lb[3]);
-            reinterpret_cast<uint4 *>(nun)[lane] = make_uint4(nu[0], nu[1], nu[2], nu[3]);
+            reinterpret_cast<uint4 *>(uend)[lane] = make_uint4(ue[0], ue[1], ue[2], ue[3]);
             reinterpret_cast<uint4 *>(carryn)[lane] = make_uint4(kn[0], kn[1], kn[2], kn[3]);
             reinterpret_cast<uint4 *>(lcount)[lane] = make_uint4(0, 0, 0, 0);
         }
@@ -390,37 +397,27 @@ __global__ __launch_bounds__(1024) void hist2_scatter_kernel(const uint8_t *__re
                 const uint32_t t = H2P_TRIPLE(y, k, j);
                 const int i = 16 * k + j;
                 const uint32_t r = (i & 1) ? (rk[i >> 1] >> 16) : (rk[i >> 1] & 0xFFFFu);
-                stage16[lbase[t & 255u] + r] = uint16_t(((t >> 8) & 255u) << 8 | ((t >> 16) & 255u));
+                stage16[lbase[t & 255u] + r] = uint16_t(t >> 8);                     // the pair: previous byte | symbol << 8
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        // whose slot every unit of the stage is (a wave marks sixteen buckets, 64 units per trip)
+#pragma unroll 1
+        for (uint32_t a = wave * 16u; a < wave * 16u + 16u; ++a) {
+            const uint32_t b1 = su[a + 1];
+            for (uint32_t u = su[a] + lane; u < b1; u += 64u) uown[u] = uint8_t(a);
+        }
         __syncthreads();
-        // copy-out: the waves share the stage's units evenly, whatever the skew; within its share a wave goes slot by slot and
-        // copies the slot's WHOLE units, 16 bytes per lane, to where the bucket continues in memory
+        // copy-out: a thread per unit; a slot's WHOLE units go, 16 bytes each, to where the bucket continues in memory (what
+        // is left of the slot, under eight pairs, is carried into the next tile)
         {
-            const uint32_t total = __builtin_amdgcn_readfirstlane(su[256]);
-            const uint32_t span = (total + 15u) >> 4;
-            const uint32_t s0 = wave * span, s1 = s0 + span < total ? s0 + span : total;
-            if (s0 < s1) {
-                uint32_t a = 0;
-#pragma unroll
-                for (uint32_t step = 128; step; step >>= 1)
-                    if (su[a + step] <= s0) a += step;
-                a = __builtin_amdgcn_readfirstlane(a);
-                while (a < 256u) {
-                    const uint32_t r0 = __builtin_amdgcn_readfirstlane(su[a]);
-                    if (r0 >= s1) break;
-                    const uint32_t re = r0 + __builtin_amdgcn_readfirstlane(nun[a]);
-                    const uint32_t ub = r0 > s0 ? r0 : s0, ue = re < s1 ? re : s1;
-                    if (ue > ub) {
-                        const unsigned long long g = gun[a];
-                        for (uint32_t u = ub + lane; u < ue; u += 64u) pairs[g + u] = stage[u];
-                    }
-                    ++a;
-                }
+            const uint32_t total = su[256];
+            for (uint32_t u = threadIdx.x; u < total; u += 1024u) {
+                const uint32_t a = uown[u];
+                if (u < uend[a]) pairs[gun[a] + u] = stage[u];
             }
         }
-        if (threadIdx.x < 256 && carryn[threadIdx.x]) carry[threadIdx.x] = stage[su[threadIdx.x] + nun[threadIdx.x]];
+        if (threadIdx.x < 256 && carryn[threadIdx.x]) carry[threadIdx.x] = stage[uend[threadIdx.x]];
         // (no barrier here: the next tile's ranks go to lcount, which wave 0 cleared before the second barrier above, and
         // nobody writes the stage or the bucket tables again before every wave has passed the next tile's first barrier)
     }
@@ -447,20 +444,20 @@ __device__ __forceinline__ void h2p_fixup(uint32_t *h, unsigned long long *mine,
     const uint32_t prev = slot >> 8, sym = (slot & 255u) ^ hist_mix(prev);
     atomicAdd(&mine[prev * 256u + sym], 16384ull);
 }
-// eight pairs of one vector: a dword holds two pairs, each symbol | previous << 8
+// eight pairs of one vector: a dword holds two pairs, each previous byte | symbol << 8
 __device__ __forceinline__ void h2p_add8(uint32_t *h, unsigned long long *mine, const uint4 &x4) {
     const uint32_t x[4] = {x4.x, x4.y, x4.z, x4.w};
     uint32_t slot[8], old[8], inc[8];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const uint32_t m = x[k] ^ ((x[k] << 3) & 0xF8F8F8F8u);                    // every byte ^ itself << 3
-        const uint32_t y = x[k] ^ (m >> 8);                                       // bytes 0 and 2: symbol ^ mix(previous)
+        const uint32_t y = x[k] ^ (m << 8);                                       // bytes 1 and 3: symbol ^ mix(previous)
         const uint32_t xm = x[k] & 0x7F7F7F7Fu;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int i = 2 * k + j;
-            slot[i] = __builtin_amdgcn_perm(xm, y, j ? 0x0C0C0702u : 0x0C0C0500u);   // (previous & 0x7F) << 8 | mixed byte
-            asm("v_mad_u32_u24 %0, %1, %2, 1" : "=v"(inc[i]) : "v"(__builtin_amdgcn_ubfe(x[k], 16 * j + 15, 1)), "s"(0xFFFFu));
+            slot[i] = __builtin_amdgcn_perm(xm, y, j ? 0x0C0C0603u : 0x0C0C0401u);   // (previous & 0x7F) << 8 | mixed byte
+            asm("v_mad_u32_u24 %0, %1, %2, 1" : "=v"(inc[i]) : "v"(__builtin_amdgcn_ubfe(x[k], 16 * j + 7, 1)), "s"(0xFFFFu));
             old[i] = atomicAdd(&h[slot[i]], inc[i]);
         }
     }
@@ -542,7 +539,8 @@ static hipError_t launch_tag(const uint8_t *base, uint64_t n_total, uint64_t lo,
     if (hi <= lo) return hipSuccess;
     const uint64_t nvec = (hi - lo) >> 4;
     const uint64_t want = (nvec + H2_THREADS - 1) / H2_THREADS;
-    const int grid = int(want < 1 ? 1 : (want > uint64_t(cu_count()) ? uint64_t(cu_count()) : want));
+    int grid = int(want < 1 ? 1 : (want > uint64_t(cu_count()) ? uint64_t(cu_count()) : want));
+    if (mode == H2_MODE_SAMPLE && grid > 64) grid = 64;      // 64 KiB per workgroup says enough, and every workgroup flushes a whole table
     hipLaunchKernelGGL(hist_o2_kernel, dim3(grid), dim3(H2_THREADS), H2_LDS_BYTES, st, base, n_total, lo, hi, ctx0, d_counts, ctl, mode);
     return hipGetLastError();
 }
@@ -558,6 +556,7 @@ hipError_t launch_hist_o2(const uint8_t *d_data, uint64_t n, uint32_t ctx0, unsi
     e = once_per_device(&DeviceState::hist2_ready, [] {
         hipError_t r = allow_lds(reinterpret_cast<const void *>(hist_o2_kernel), H2_LDS_BYTES);
         if (r == hipSuccess) r = allow_lds(reinterpret_cast<const void *>(hist2_scatter_kernel), H2P_SCATTER_LDS);
+        if (r == hipSuccess) r = allow_lds(reinterpret_cast<const void *>(hist2_count_kernel), H2P_COUNT_LDS);
         if (r == hipSuccess) r = allow_lds(reinterpret_cast<const void *>(hist2_bucket_kernel), HIST_LDS_BYTES);
         return r;
     });
@@ -598,7 +597,7 @@ hipError_t launch_hist_o2(const uint8_t *d_data, uint64_t n, uint32_t ctx0, unsi
         const uint64_t mid = hi - lo < H2P_MIN ? lo : lo + H2P_SAMPLE;
         const uint32_t ntiles = uint32_t((hi - mid) / H2P_TILE);
         if (ntiles) {
-            hipLaunchKernelGGL(hist2_count_kernel, dim3(H2P_G), dim3(1024), 0, st, d_data, n, mid, ntiles, ctx0, cnt, ctl);
+            hipLaunchKernelGGL(hist2_count_kernel, dim3(H2P_G), dim3(1024), H2P_COUNT_LDS, st, d_data, n, mid, ntiles, ctx0, cnt, ctl);
             hipLaunchKernelGGL(hist2_offsets_kernel, dim3(1), dim3(1024), 0, st, cnt, off, bstart, items, holes, ctl);
             hipLaunchKernelGGL(hist2_scatter_kernel, dim3(H2P_G), dim3(1024), H2P_SCATTER_LDS, st, d_data, n, mid, ntiles, ctx0, off, pairs, holes, ctl);
             const uint32_t grid = uint32_t((uint64_t(ntiles) * H2P_TILE + H2P_PAD_PAIRS + H2P_CHUNK - 1) / H2P_CHUNK) + 256u;     // <= g.max_items

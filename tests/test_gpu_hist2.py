@@ -95,7 +95,7 @@ def test_workspace_size_is_bounded(mhc):
 def test_uniform_bytes_take_the_partition_path_parity_unpinned(mhc, oracle, extra):
     data = uniform((48 << 20) + extra, 11 + extra)
     got, paths = run(mhc, mhc.lib(), data)
-    assert paths == PARTITION                                    # (the slab's first 8 MiB, the sample, always go through the cache)
+    assert paths == PARTITION                                    # (the slab's first 4 MiB, the sample, always go through the cache)
     assert np.array_equal(got, expect(oracle, data))
 
 
