@@ -117,6 +117,17 @@ def test_argument_errors(mhc):
         assert lib.mh_model_from_counts(big.ctypes.data, 2, ctypes.byref(h)) == mhc.MH_ERR_NO_DEVICE
 
 
+def test_order2_histogram_workspace_is_plain_arithmetic(mhc):
+    """mh_dev_histogram_o2_workspace needs no device: nothing below 32 MiB (tag cache only), then two bytes per input byte
+    of a slab (2 GiB at most) plus the bucket images and tables — bounded whatever the input size."""
+    lib = mhc.lib()
+    assert lib.mh_dev_histogram_o2_workspace(0) == 64 and lib.mh_dev_histogram_o2_workspace((32 << 20) - 1) == 64
+    small, big, huge = (lib.mh_dev_histogram_o2_workspace(n) for n in (32 << 20, 2 << 30, 1 << 40))
+    assert (64 << 20) < small < (64 << 20) + (40 << 20)
+    assert (4 << 30) < big < (4 << 30) + (100 << 20) and huge == big
+    assert small % 256 == 0 and big % 256 == 0
+
+
 def test_compute_refuses_without_gpu(mhc):
     """No CPU fallback: without a device every compute call reports MH_ERR_NO_DEVICE."""
     if mhc.device_count() > 0:
