@@ -171,3 +171,28 @@ def test_forced_cache_equals_forced_partition(mhc, diag):
             del os.environ["MH_HIST2_FORCE"]
         assert paths == int(force)
     assert np.array_equal(got["1"], got["2"]) and int(got["1"].sum()) == data.size
+
+
+@pytest.mark.parametrize("seed", [101, 202, 303, 404])
+def test_partition_path_random_mixtures_parity_unpinned(mhc, diag, oracle, seed):
+    """Random sizes and mixtures of sources, the partition path forced (so that skewed pieces go through it too) and slabs of
+    32 MiB: every slab boundary, tile boundary and carried remainder lands somewhere else each time."""
+    rng = np.random.default_rng(seed)
+    parts, left = [], int(rng.integers(33 << 20, 90 << 20)) + int(rng.integers(0, 65536))
+    while left > 0:
+        n = min(left, int(rng.integers(1, 24 << 20)))
+        kind = int(rng.integers(0, 5))
+        parts.append(uniform(n, seed + len(parts)) if kind == 0 else zipf(n, seed + len(parts), s=float(rng.uniform(0.5, 2.0))) if kind == 1
+                     else text_like(n, seed + len(parts)) if kind == 2 else np.full(n, int(rng.integers(0, 256)), dtype=np.uint8) if kind == 3
+                     else (uniform(n, seed + len(parts)) & np.uint8(rng.integers(1, 256))))
+        left -= n
+    data = np.concatenate(parts)
+    ctx0 = int(rng.integers(0, 65536))
+    os.environ["MH_HIST2_FORCE"] = "2"
+    os.environ["MH_HIST2_SLAB"] = str(32 << 20)
+    try:
+        got, paths = run(mhc, diag, data, ctx0=ctx0)
+    finally:
+        del os.environ["MH_HIST2_FORCE"], os.environ["MH_HIST2_SLAB"]
+    assert paths == PARTITION
+    assert np.array_equal(got, expect(oracle, data, ctx0))
