@@ -334,6 +334,10 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
                         const uint32_t idx2 = (e[k] << (H + 1)) | ((win[k] >> (P - 1)) & ((2u << H) - 2u));   // byte offset of the entry
 #if defined(MH_TILE_PROBE_NOGATHER)                 /* diagnostic build: no second level at all (output wrong) */
                         e2[k] = idx2 & 0u;
+#elif defined(MH_TILE_PROBE_GATHER23)               /* diagnostic build (output wrong): two of three gathers — is the time linear in their number? */
+                        e2[k] = (j % 3 == 2) ? (idx2 & 0u) : uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(sec_rsrc, int(idx2), 0, 0)));
+#elif defined(MH_TILE_PROBE_GATHER12)               /* ... every second gather */
+                        e2[k] = (j & 1) ? (idx2 & 0u) : uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(sec_rsrc, int(idx2), 0, 0)));
 #elif defined(MH_TILE_SKIPGATHER)                   /* probe: the gather only when some lane of the wave has an inner entry */
                         e2[k] = 0u;
                         if (__any(!(e[k] & DEC16_LEAF))) e2[k] = uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(sec_rsrc, int(idx2), 0, 0)));
