@@ -196,3 +196,15 @@ def test_partition_path_random_mixtures_parity_unpinned(mhc, diag, oracle, seed)
         del os.environ["MH_HIST2_FORCE"], os.environ["MH_HIST2_SLAB"]
     assert paths == PARTITION
     assert np.array_equal(got, expect(oracle, data, ctx0))
+
+
+def test_host_call_in_segments_parity_unpinned(mhc, oracle):
+    """mh_histogram_o2 stages a large input through HBM in segments (MH_SEGMENT_BYTES): 40 MiB segments over 100 MiB of uniform
+    bytes — every segment takes the partition path on its own, the two-byte context is carried across the seams."""
+    data = uniform((100 << 20) + 1234, 77)
+    os.environ["MH_SEGMENT_BYTES"] = str(40 << 20)
+    try:
+        got = mhc.histogram_o2(data.tobytes())
+    finally:
+        del os.environ["MH_SEGMENT_BYTES"]
+    assert np.array_equal(got, oracle.histogram_o2(data))
