@@ -334,6 +334,19 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
                         const uint32_t idx2 = (e[k] << (H + 1)) | ((win[k] >> (P - 1)) & ((2u << H) - 2u));   // byte offset of the entry
 #if defined(MH_TILE_PROBE_NOGATHER)                 /* diagnostic build: no second level at all (output wrong) */
                         e2[k] = idx2 & 0u;
+#elif defined(MH_TILE_PROBE_GATHER2X)                /* diagnostic build (output right): a second gather per step, at an index past the end (answered with 0, no cache access): how much room does the texture path have? */
+                        {
+                            const uint32_t g1 = uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(sec_rsrc, int(idx2), 0, 0)));
+                            const uint32_t g2 = uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(sec_rsrc, int(idx2 | 0x40000000u), 0, 0)));
+                            e2[k] = g1 | g2;
+                        }
+#elif defined(MH_TILE_PROBE_GATHER2L)                /* ... the second one a real trip to L2 (the neighbouring entry; its value is masked out after the wait) */
+                        {
+                            const uint32_t g1 = uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(sec_rsrc, int(idx2), 0, 0)));
+                            uint32_t g2 = uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(sec_rsrc, int(idx2 ^ 2u), 0, 0)));
+                            asm volatile("v_and_b32 %0, 0, %0" : "+v"(g2));
+                            e2[k] = g1 | g2;
+                        }
 #elif defined(MH_TILE_PROBE_GATHER23)               /* diagnostic build (output wrong): two of three gathers — is the time linear in their number? */
                         e2[k] = (j % 3 == 2) ? (idx2 & 0u) : uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(sec_rsrc, int(idx2), 0, 0)));
 #elif defined(MH_TILE_PROBE_GATHER12)               /* ... every second gather */
