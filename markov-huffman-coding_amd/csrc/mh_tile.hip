@@ -331,7 +331,11 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
                         const uint32_t idx2 = (e[k] << (H + 2)) | ((win[k] >> (P - 2)) & ((4u << H) - 4u));
                         e2[k] = uint32_t(__builtin_amdgcn_raw_buffer_load_b32(sec_rsrc, int(idx2), 0, 0));
                     } else {
+#if defined(MH_TILE_PROBE_HOTSEC)                    /* diagnostic build (output wrong): every inner entry points into the first 32 second-level tables — what would a second level that always hits the L1 be worth? */
+                        const uint32_t idx2 = (((e[k] & DEC16_LEAF) ? e[k] : (e[k] & 31u)) << (H + 1)) | ((win[k] >> (P - 1)) & ((2u << H) - 2u));
+#else
                         const uint32_t idx2 = (e[k] << (H + 1)) | ((win[k] >> (P - 1)) & ((2u << H) - 2u));   // byte offset of the entry
+#endif
 #if defined(MH_TILE_PROBE_NOGATHER)                 /* diagnostic build: no second level at all (output wrong) */
                         e2[k] = idx2 & 0u;
 #elif defined(MH_TILE_PROBE_GATHER2X)                /* diagnostic build (output right): a second gather per step, at an index past the end (answered with 0, no cache access): how much room does the texture path have? */
