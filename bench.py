@@ -427,21 +427,9 @@ def main():
         # traffic per launch, and the secondary bounds — share of the kernel's time its vector ALUs issue, its LDS is
         # busy, its texture-address units are busy — because every kernel of this path is issue-/LDS-bound long before
         # HBM (tools/make_traffic_json.py writes both files from gpurun_out/<pmc run>)
-        traffic, secondary, counters_from = None, None, {}
-        for fname, key in (("traffic.json", "traffic"), ("secondary.json", "secondary")):
-            fpath = os.path.join(ROOT, "profiles", fname)
-            if os.path.exists(fpath):
-                try:
-                    blob = json.load(open(fpath))
-                    v = blob.get("%s:%d" % (dom, n))
-                    if v is not None:                 # where the figure comes from: a committed counter run, NOT this run
-                        counters_from[key] = "profiles/%s <- %s (rocprofv3 --pmc, committed; not collected in this run)" % (fname, blob.get("_counters"))
-                except Exception:
-                    v = None
-                if key == "traffic":
-                    traffic = v
-                else:
-                    secondary = v
+        # ... and each figure is tied to the sources of its kernel: one collected on other sources is dropped (provenance.py)
+        provenance = importlib.import_module("mhc_amd.provenance")
+        traffic, secondary, counters_from = provenance.counters_for(dom, n, os.path.join(ROOT, "profiles"))
         ach = kernels[dom][0] / (kernels[dom][1] * 1e-3) / 1e9
         kname = {"zipf": "Zipf(s=1.1)", "uniform": "uniform", "text": "Lorem-Ipsum-style ASCII"}[kind]
         if mode == "weak":

@@ -97,12 +97,20 @@ __device__ __forceinline__ uint32_t tile_put_byte(uint32_t d, uint32_t e, int j)
     return __builtin_amdgcn_perm(e, d, sel);
 }
 
+#ifdef MH_EXP_PROBES
+#include "mh_tile_probes.hpp"
+#else
+__host__ __device__ constexpr uint32_t tile_probe_reserve(int) { return 0u; }
+#endif
+
 // K tiles per wave, PC = first-level width (compile time), HC = second-level height (0: read p.H)
 // OUT: how a stream's 64 bytes leave (A/B, MH_TILE_OUT): 0 = a 16-byte store per 16 symbols (adjacent lanes 64 bytes apart),
 // 1 = four such stores back to back at the end of the tile, 2 = through the wave's LDS region, transposed, so that every
 // store instruction writes one contiguous KiB
 // O2: order-2 tables of the live contexts (TileParams): 32-bit entries whose high half is the next context's slot
-template <int K, int PC, int HC, int OUT, int WIN, int STAMP = 0, int O2 = 0>
+// G: how the second level is reached.  0 = the shipped form (every lane of every stream gathers); any other value exists
+// only in the diagnostic library (mh_tile_probes.hpp: cost probes and the round-5 candidates, see profiles/r05/)
+template <int K, int PC, int HC, int OUT, int WIN, int STAMP = 0, int O2 = 0, int G = 0>
 __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr uint32_t P = PC;
@@ -117,7 +125,8 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
         reinterpret_cast<uint4 *>(lut)[i] = reinterpret_cast<const uint4 *>(p.prim)[i];
     __syncthreads();
     const uint64_t nsub = (p.n + T_SUB - 1) >> T_SUB_SHIFT;
-    const uint32_t free_bytes = uint32_t(T_LDS_BYTES) - PRIM_BYTES;
+    constexpr uint32_t RESERVE = tile_probe_reserve(G);           // (0 in the shipped kernel)
+    const uint32_t free_bytes = uint32_t(T_LDS_BYTES) - PRIM_BYTES - RESERVE;
     // ---- [r4] geometry, per workgroup: the largest piece any of ITS waves will stage.  The workgroup owns blocks of T_WAVES
     // consecutive wave pieces (block B = blockIdx.x + m * gridDim.x), whatever the number of waves it keeps, so the set is
     // known before the regions are sized (a kernel of its own did this for the whole stream: 0.11 ms per 16 GiB, 1 % of a
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
     // for the whole workgroup is worth more than the chunk decoder costs on under 1 % of it.
     uint32_t maxb;
     {
-        uint32_t *s_max = reinterpret_cast<uint32_t *>(smem + PRIM_BYTES);       // (the first region: not in use yet)
+        uint32_t *s_max = reinterpret_cast<uint32_t *>(smem + PRIM_BYTES + RESERVE);       // (the first region: not in use yet)
         if (tid < 2) s_max[tid] = 0;
         __syncthreads();
         const uint32_t cap_bytes = free_bytes - 32u;
@@ -168,7 +177,7 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
         for (uint64_t c = c_first + lane; c < p.nchunks; c += 64) p.redo[1u + atomicAdd(p.redo, 1u)] = uint32_t(c);
     }
     if (wave >= nw) return;                                       // no barrier below this line
-    unsigned char *reg = smem + PRIM_BYTES + wave * region;
+    unsigned char *reg = smem + PRIM_BYTES + RESERVE + wave * region;
     if (lds_addr_of(smem) != 0u) {                                // the first-level table is addressed from LDS address 0
         if (tid == 0) atomicExch(p.status, MHK_STATUS_CORRUPT);
         return;
@@ -317,59 +326,22 @@ __global__ __launch_bounds__(T_THREADS) void decode_tile_kernel(TileParams p) {
                     } else {
                         const uint32_t csh = P == 7 ? __builtin_amdgcn_perm(0u, cf[k], 0x0C0C000Cu)       // byte 0 -> byte 1
                                                     : (cf[k] & 255u) << (P + 1);
-#ifdef MH_TILE_SWIZZLE
-                        e[k] = *lds_ptr<uint16_t>((((win[k] ^ ((cf[k] & 255u) * 0x9Du)) << 1) & ((2u << P) - 2u)) | csh);
-#else
                         e[k] = *lds_ptr<uint16_t>(((win[k] << 1) & ((2u << P) - 2u)) | csh);
-#endif
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#ifdef MH_EXP_PROBES
+                if (G != 0 && !O2) tile_second_probe<K, G, PC>(e, win, cf, H, sec_rsrc, lane, e2);
+                else
+#endif
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     if (O2) {      // (a leaf carries bit 15: shifted by H + 2 it lies past the (nslots << P) << H entries whatever its high half holds)
                         const uint32_t idx2 = (e[k] << (H + 2)) | ((win[k] >> (P - 2)) & ((4u << H) - 4u));
                         e2[k] = uint32_t(__builtin_amdgcn_raw_buffer_load_b32(sec_rsrc, int(idx2), 0, 0));
                     } else {
-#if defined(MH_TILE_PROBE_HOTSEC)                    /* diagnostic build (output wrong): every inner entry points into the first 32 second-level tables — what would a second level that always hits the L1 be worth? */
-                        const uint32_t idx2 = (((e[k] & DEC16_LEAF) ? e[k] : (e[k] & 31u)) << (H + 1)) | ((win[k] >> (P - 1)) & ((2u << H) - 2u));
-#else
                         const uint32_t idx2 = (e[k] << (H + 1)) | ((win[k] >> (P - 1)) & ((2u << H) - 2u));   // byte offset of the entry
-#endif
-#if defined(MH_TILE_PROBE_NOGATHER)                 /* diagnostic build: no second level at all (output wrong) */
-                        e2[k] = idx2 & 0u;
-#elif defined(MH_TILE_PROBE_GATHER2X)                /* diagnostic build (output right): a second gather per step, at an index past the end (answered with 0, no cache access): how much room does the texture path have? */
-                        {
-                            const uint32_t g1 = uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(sec_rsrc, int(idx2), 0, 0)));
-                            const uint32_t g2 = uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(sec_rsrc, int(idx2 | 0x40000000u), 0, 0)));
-                            e2[k] = g1 | g2;
-                        }
-#elif defined(MH_TILE_PROBE_GATHER2L)                /* ... the second one a real trip to L2 (the neighbouring entry; its value is masked out after the wait) */
-                        {
-                            const uint32_t g1 = uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(sec_rsrc, int(idx2), 0, 0)));
-                            uint32_t g2 = uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(sec_rsrc, int(idx2 ^ 2u), 0, 0)));
-                            asm volatile("v_and_b32 %0, 0, %0" : "+v"(g2));
-                            e2[k] = g1 | g2;
-                        }
-#elif defined(MH_TILE_PROBE_GATHER23)               /* diagnostic build (output wrong): two of three gathers — is the time linear in their number? */
-                        e2[k] = (j % 3 == 2) ? (idx2 & 0u) : uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(sec_rsrc, int(idx2), 0, 0)));
-#elif defined(MH_TILE_PROBE_GATHER12)               /* ... every second gather */
-                        e2[k] = (j & 1) ? (idx2 & 0u) : uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(sec_rsrc, int(idx2), 0, 0)));
-#elif defined(MH_TILE_SKIPGATHER)                   /* probe: the gather only when some lane of the wave has an inner entry */
-                        e2[k] = 0u;
-                        if (__any(!(e[k] & DEC16_LEAF))) e2[k] = uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(sec_rsrc, int(idx2), 0, 0)));
-#elif defined(MH_TILE_GLOBAL_CLAMP)                 /* probe: a plain global load at a clamped index (leaves all read one zero entry) */
-                        {
-                            const uint32_t lim = p.nsec * 2u;          /* the entries behind the tables are zero (8 spare) */
-                            const uint32_t off = idx2 < lim ? idx2 : lim;
-                            e2[k] = uint32_t(*reinterpret_cast<const uint16_t *>(reinterpret_cast<const unsigned char *>(p.sec) + off));
-                        }
-#elif defined(MH_TILE_EXECMASK)                     /* only the lanes whose entry is an inner node issue the gather */
-                        e2[k] = 0u;
-                        if (!(e[k] & DEC16_LEAF)) e2[k] = uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(sec_rsrc, int(idx2), 0, 0)));
-#else
                         e2[k] = uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(sec_rsrc, int(idx2), 0, 0)));
-#endif
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -755,6 +727,16 @@ hipError_t launch_decode_tile(TileParams p, const DecParams &legacy, void *d_ws,
             if (p.P != 7) return hipErrorInvalidValue;
             return launch_tile_with<2>(ks, p, legacy, d_ws, st);
         }
+    }
+    if (const char *eg = getenv("MH_TILE_G")) {                  // mh_tile_probes.hpp: other ways to the second level (P = 7 only)
+        const int g = atoi(eg), w = getenv("MH_TILE_WIN") ? atoi(getenv("MH_TILE_WIN")) : 0;
+        if (g && p.P != 7) return hipErrorInvalidValue;
+        void (*kg)(TileParams) = nullptr;
+#define MH_G_CASE(GV) case GV: kg = k == 1 ? (w ? decode_tile_kernel<1, 7, 0, 2, 1, 0, 0, GV> : decode_tile_kernel<1, 7, 0, 2, 0, 0, 0, GV>) \
+                                           : (w ? decode_tile_kernel<2, 7, 0, 2, 1, 0, 0, GV> : decode_tile_kernel<2, 7, 0, 2, 0, 0, 0, GV>); break;
+        switch (g) { MH_G_CASE(1) MH_G_CASE(2) MH_G_CASE(3) MH_G_CASE(4) MH_G_CASE(5) MH_G_CASE(6) MH_G_CASE(7) default: break; }
+#undef MH_G_CASE
+        if (kg) return k == 1 ? launch_tile_with<1>(kg, p, legacy, d_ws, st) : launch_tile_with<2>(kg, p, legacy, d_ws, st);
     }
     const char *ew = getenv("MH_TILE_WIN");                       // 1: the register-window variant
     if (ew && atoi(ew) == 1) return k == 4 ? launch_tile_k<4, 2, 1>(p, legacy, d_ws, st) : k == 3 ? launch_tile_k<3, 2, 1>(p, legacy, d_ws, st) : launch_tile_k<2, 2, 1>(p, legacy, d_ws, st);

@@ -479,11 +479,7 @@ __device__ __forceinline__ void tree_pack_body(const TreePackArgs &a, const uint
         if (left[node] == NONE) e = uint16_t(DEC16_LEAF | (depth << 8) | sym[node]);      // a leaf reached at depth <= P fills its whole range
         else if (a.direct) e = uint16_t((base >> a.H) + (off >> a.H));
         else e = uint16_t(((h - 1) << 12) | off);
-#ifdef MH_TILE_SWIZZLE                               /* probe: the tile tables' first-level column permuted by the context */
-        a.prim[(c << P) | (a.lsb ? (tid ^ ((c * 0x9Du) & (nprim - 1u))) : tid)] = e;
-#else
         a.prim[(c << P) | tid] = e;
-#endif
         // second level: this thread fills its own table
         for (uint32_t x = 0; x < tabsize; ++x) {
             uint32_t n2 = node, d2 = 0;

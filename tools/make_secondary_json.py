@@ -12,8 +12,15 @@ The secondary bounds of every kernel — what the integer kernels of this path a
 kernel cycles = GRBM_GUI_ACTIVE / 8 (the counter sums the 8 XCDs).  Peak used for valu_frac: 256 CUs x 4 SIMDs, one
 wave-instruction per 4 cycles each = 256 x 4 x 16 lanes x 2.4 GHz = 3.9e13 lane-operations per second."""
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import __graft_entry__ as entry  # noqa: E402
+import importlib  # noqa: E402
+entry.load_package()
+provenance = importlib.import_module("mhc_amd.provenance")
 
 src, size, cite = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 CUS = 256
@@ -41,5 +48,5 @@ for k, v in sorted(c.items()):
     key = "%s:%d" % (name, size)
     if key not in out or out[key]["kernel_cycles"] < e["kernel_cycles"]:
         out[key] = e
-json.dump(out, sys.stdout, indent=1)
+json.dump(provenance.stamp(out), sys.stdout, indent=1)    # + the hash of every kernel's sources as they are NOW: run this right after the counter run
 print()

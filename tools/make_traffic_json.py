@@ -4,8 +4,15 @@
 read bytes = TCC_EA0_RDREQ_sum x 128 B when every request was a 128-byte one (checked), else the split
 sum; write bytes = WRITE_SIZE x 1024 (MI355X_MICROARCH.md, HBM/rocprofv3 section)."""
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import __graft_entry__ as entry  # noqa: E402
+import importlib  # noqa: E402
+entry.load_package()
+provenance = importlib.import_module("mhc_amd.provenance")
 
 src, size, cite = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 c = json.load(open(src))
@@ -22,11 +29,14 @@ for k, v in c.items():
     r32 = v.get("TCC_EA0_RDREQ_32B_sum", 0.0)
     read = r128 * 128 + r32 * 32 + max(rd - r128 - r32, 0.0) * 64
     write = v.get("WRITE_SIZE", 0.0) * 1024
-    a = agg.setdefault(name, [0.0, 0.0])
+    a = agg.setdefault(name, [0.0, 0.0, 0.0, ""])
     a[0] += read
     a[1] += write
-for name, (r, w) in sorted(agg.items()):
+    if read + write >= a[2]:                    # the instantiation that moved the most bytes names the entry
+        a[2], a[3] = read + write, k
+for name, (r, w, _, inst) in sorted(agg.items()):
     out["%s:%d" % (name, size)] = int(r + w)
+    out["%s:%d:instantiation" % (name, size)] = inst
     out["%s:%d:read" % (name, size)] = int(r)
     out["%s:%d:write" % (name, size)] = int(w)
 # the encode stage = every kernel of whichever encoder ran (region path, or length pass + scans + emit)
@@ -34,5 +44,5 @@ enc = ("enc_region_kernel", "region_bits_kernel", "region_scan_kernel",
        "enc_len_kernel", "enc_emit_kernel", "scan_local_kernel", "scan_top_kernel", "scan_apply_kernel")
 if any("%s:%d" % (k, size) in out for k in enc):
     out["encode_kernel:%d" % size] = sum(out.get("%s:%d" % (k, size), 0) for k in enc)
-json.dump(out, sys.stdout, indent=1)
+json.dump(provenance.stamp(out), sys.stdout, indent=1)    # + the hash of every kernel's sources as they are NOW: run this right after the counter run
 print()
