@@ -251,8 +251,9 @@ def main():
     ap.add_argument("--size", type=int, default=None, help="bytes per GPU, weak scaling (default 16 GiB)")
     ap.add_argument("--total-size", type=int, default=None,
                     help="strong scaling: ONE stream of this many bytes split into N contiguous shards (e.g. 17179869184)")
-    ap.add_argument("--config", type=int, default=3, choices=[3, 4],
-                    help="BASELINE.json configs[]: 3 (default) = 16 GiB Zipf(1.1) per GPU; 4 = uniform random, 8 GiB per GPU (64 GiB on 8)")
+    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4],
+                    help="BASELINE.json configs[]: 3 (default) = 16 GiB Zipf(1.1) per GPU; 4 = uniform random, 8 GiB per GPU (64 GiB on 8); "
+                         "2 = 256 MiB of Lorem-Ipsum-style ASCII on one GPU (the reference's own benchmark size, README.md:174)")
     ap.add_argument("--kind", default=None, choices=["zipf", "uniform", "text"])
     ap.add_argument("--order", type=int, default=1, choices=[1, 2],
                     help="2 = order-2 contexts (BASELINE configs[4]; extension the reference does not have: parity unpinned; 1 GPU)")
@@ -297,7 +298,7 @@ def main():
     mhc.lib()                      # fails loudly if libmhc.so is missing: there is no fallback path
     import importlib
     sharded = importlib.import_module("mhc_amd.sharded")
-    kind = args.kind or ("uniform" if args.config == 4 else "zipf")
+    kind = args.kind or {2: "text", 3: "zipf", 4: "uniform"}[args.config]
     # ---- what each rank holds: bytes [first, first + n) of ONE seeded stream
     if args.total_size is None and args.size is None and world > 1 and args.config == 3 and args.order == 1:
         # BASELINE.json's metric is ONE 16 GB stream at 1/2/4/8 GPUs: with no size given, N > 1 splits that stream
@@ -309,7 +310,7 @@ def main():
         n = hi - first
     else:
         mode = "weak"
-        n = args.size if args.size is not None else ((8 << 30) if args.config == 4 else (16 << 30))
+        n = args.size if args.size is not None else {2: 256 << 20, 3: 16 << 30, 4: 8 << 30}[args.config]
         first, total = rank * n, n * world
     global CHUNK
     if CHUNK == 0:
@@ -466,6 +467,11 @@ def main():
             # what that fraction can reach at all: the encoder moves (1 + r) bytes per input byte, and a plain copy reaches
             # 6.29 of the 8.0 TB/s (MI355X_MICROARCH.md): 1 / (1 + r) x 6.29 / 8.0 — the north star's 0.50 lies above it
             "encode_read_ceiling": round(1.0 / (1.0 + r) * COPY_CEILING_GBS / HBM_PEAK_GBS, 4),
+            # what does not shrink with the stream: the tree stage (256 contexts whatever n is), the collective, and whatever of the
+            # step is not inside a stage (launch gaps, the model build's one host wait).  At 16 GiB a few per cent; at config 2's
+            # 256 MiB a large part of the step
+            "fixed_cost_share": round((ms["tree"] + ms["allreduce"] + max(elapsed / K * 1e3 - sum(ms.values()), 0.0)) / (elapsed / K * 1e3), 4),
+            "gap_ms": round(max(elapsed / K * 1e3 - sum(ms.values()), 0.0), 4),
             "compressed_ratio": round(r, 5), "total_payload_bits": int(tot_bits.item()), "round_trip_bit_exact": round_trip_all,
             # out-of-band bytes the decoder is handed beside the payload: the sidecar chunk index (8 B per chunk) and the
             # device-only fine index (4 B per 64 symbols); traffic of both kernels, never credit

@@ -1521,7 +1521,17 @@ static int histogram_host(const uint8_t *data, size_t n, uint8_t prev0, uint64_t
     HIP_TRY(d_counts.alloc(nc * 8));
     const size_t hws = order == 1 && n >= (size_t(1) << 20) ? mh_dev_histogram_workspace(n)   // pays from about a megabyte on
                        : order == 2 ? mh_dev_histogram_o2_workspace(n < seg ? n : seg) : 0;  // (order 2: room for the partition path)
-    if (hws) HIP_TRY(d_hws.alloc(hws));
+    size_t hws_have = hws;
+    if (hws) {
+        const hipError_t he = d_hws.alloc(hws);
+        if (he != hipSuccess) {
+            // order 2's partition workspace is optional (about 2 bytes per segment byte): without it launch_hist_o2 keeps
+            // everything in the tag cache — slower on flat sources, same counts.  Order 1's is small: an error.
+            if (order != 2) HIP_TRY(he);
+            (void)hipGetLastError();
+            hws_have = 0;
+        }
+    }
     std::vector<uint64_t> part(nc);
     for (size_t i = 0; i < nc; ++i) counts[i] = 0;
     for (size_t off = 0; off < n || off == 0; off += seg) {
@@ -1530,7 +1540,7 @@ static int histogram_host(const uint8_t *data, size_t n, uint8_t prev0, uint64_t
         if (len) HIP_TRY(stage_h2d(d_seg, data + off, len, nullptr));
         const uint8_t p0 = off ? data[off - 1] : prev0;            // context carried across the seam (src/main.cpp:32,36)
         const uint16_t c0 = off ? uint16_t(data[off - 2] << 8 | data[off - 1]) : uint16_t(prev0 << 8 | prev0);   // segments are >= 8 KiB
-        int rc = order == 2 ? mh_dev_histogram_o2_ws(d_seg, len, c0, d_counts.as<uint64_t>(), d_hws.p, hws, nullptr)
+        int rc = order == 2 ? mh_dev_histogram_o2_ws(d_seg, len, c0, d_counts.as<uint64_t>(), hws_have ? d_hws.p : nullptr, hws_have, nullptr)
                  : order ? mh_dev_histogram_o1(d_seg, len, p0, d_counts.as<uint64_t>(), hws ? d_hws.p : nullptr, hws, nullptr)
                          : mh_dev_histogram_o0(d_seg, len, d_counts.as<uint64_t>(), nullptr, 0, nullptr);
         if (rc != MH_OK) return rc;

@@ -532,6 +532,41 @@ __global__ __launch_bounds__(1024) void hist2_reduce_kernel(const uint32_t *__re
     if (hi) mine[p1 * 256u + (low ^ hist_mix(p1))] += hi;
 }
 
+// Conservation (order 1 has the same in hist_reduce_kernel): whatever path each slab took, the 2^24 counters must
+// add up to the n positions counted (src/main.cpp:176-178: the reference's counts add up to the file size).  A unit the scatter
+// lost, a packed field that spilled into its neighbour, a wrong hole correction or a key dropped by the tag cache all change
+// the total.  One pass over 128 MiB of counters (~40 us), the last block compares and sets the workspace's status word.
+// ctl[8..9] = running total, ctl[10] = blocks done (the 64-byte control block is zeroed at the start of every call).
+__global__ __launch_bounds__(1024) void hist2_total_kernel(const unsigned long long *__restrict__ counts, unsigned long long n, uint32_t *ctl) {
+    __shared__ unsigned long long part[16];
+    unsigned long long s = 0;
+    const ulonglong2 *c2 = reinterpret_cast<const ulonglong2 *>(counts);
+    for (size_t i = size_t(blockIdx.x) * 1024u + threadIdx.x; i < (size_t(1) << 23); i += size_t(gridDim.x) * 1024u) {
+        const ulonglong2 v = c2[i];
+        s += v.x + v.y;
+    }
+#pragma unroll
+    for (int d = 32; d; d >>= 1) s += __shfl_down(s, d);
+    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int i = 0; i < 16; ++i) t += part[i];
+        unsigned long long *acc = reinterpret_cast<unsigned long long *>(ctl + 8);
+        atomicAdd(acc, t);
+        __threadfence();
+        if (atomicAdd(ctl + 10, 1u) == gridDim.x - 1) {
+            __threadfence();
+            if (atomicAdd(acc, 0ull) != n) atomicExch(reinterpret_cast<int *>(ctl), MHK_STATUS_CORRUPT);
+        }
+    }
+}
+static hipError_t launch_hist2_total(const unsigned long long *d_counts, uint64_t n, uint32_t *ctl, hipStream_t st) {
+    if (!ctl) return hipSuccess;                               // (no workspace: nowhere to report to)
+    hipLaunchKernelGGL(hist2_total_kernel, dim3(512), dim3(1024), 0, st, d_counts, (unsigned long long)n, ctl);
+    return hipGetLastError();
+}
+
 size_t hist2_workspace_bytes(uint64_t n) { return n < H2P_MIN ? 64 : hist2_geom(n, H2P_SLAB).total; }
 
 static hipError_t launch_tag(const uint8_t *base, uint64_t n_total, uint64_t lo, uint64_t hi, uint32_t ctx0, unsigned long long *d_counts,
@@ -571,6 +606,7 @@ hipError_t launch_hist_o2(const uint8_t *d_data, uint64_t n, uint32_t ctx0, unsi
     if (!ws_ok || ws_bytes < g.total || n < H2P_MIN) {
         e = launch_tag(d_data, n, 0, n, ctx0, d_counts, ctl, H2_MODE_PLAIN, st);
         if (e == hipSuccess && ctl) e = launch_set_word(ctl + 2, H2_SEL_CACHE, st);
+        if (e == hipSuccess) e = launch_hist2_total(d_counts, n, ctl, st);
         return e;
     }
     unsigned char *ws = static_cast<unsigned char *>(d_ws);
@@ -607,7 +643,7 @@ hipError_t launch_hist_o2(const uint8_t *d_data, uint64_t n, uint32_t ctx0, unsi
         e = launch_tag(d_data, n, mid + uint64_t(ntiles) * H2P_TILE, hi, ctx0, d_counts, ctl, H2_MODE_IF_PARTITION, st);
         if (e != hipSuccess) return e;
     }
-    return hipGetLastError();
+    return launch_hist2_total(d_counts, n, ctl, st);
 }
 
 }  // namespace mhk

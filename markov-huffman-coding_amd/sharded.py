@@ -234,8 +234,9 @@ def compress_step(backend, shard, prev0, group=None, distributed=None, mark=None
 
 
 def compress_shard(backend, shard, last_byte, group=None):
-    """One rank's part of a sharded compress, results on the host.  Returns dict(model, payload, nbits, index, prev0,
-    start_bit, total_bits): `payload` holds the shard's codes from bit (start_bit % 8) of its first
+    """One rank's part of a sharded compress.  Returns dict(model, payload, nbits, index, prev0, start_bit, total_bits);
+    `payload` and `index` are whatever backend.finish() hands out — for HipBackend VIEWS of its device buffers, overwritten
+    by the backend's next step: copy them (`.cpu()`, `.clone()`) before calling again.  `payload` holds the shard's codes from bit (start_bit % 8) of its first
     byte on (zero bits before), `nbits` counts the shard's own payload bits."""
     n = backend.length(shard)
     prev0 = exchange_prev0(last_byte, n > 0, group)
@@ -245,6 +246,7 @@ def compress_shard(backend, shard, last_byte, group=None):
     payload, end_bits, index = backend.finish(r["encoded"])
     if end_bits != (start & 7) + nbits:
         raise RuntimeError("shard payload is %d bits, its histogram predicted %d" % (end_bits - (start & 7), nbits))
+    # payload / index are views of the backend's buffers: valid until its next histogram() / encode() (HipBackend.finish)
     return {"model": r["model"], "payload": payload, "nbits": nbits, "index": index, "prev0": prev0,
             "start_bit": start, "total_bits": total}
 
@@ -390,7 +392,10 @@ class HipBackend:
         return self.decoded[:self.n_now]
 
     def finish(self, encoded):
-        """Host view of an encode: (payload tensor, bits in it counted from bit 0 of its first byte, chunk index)."""
+        """Host view of an encode: (payload tensor, bits in it counted from bit 0 of its first byte, chunk index).
+        The tensors are VIEWS of this backend's buffers (as are the counts histogram() returns): they hold the step's
+        results until the next histogram() / encode() on this backend overwrites them — clone what must outlive that."""
+        self._check(self.lib.mh_dev_status(self.hist_ws.data_ptr(), self._stream()), "histogram status")   # counts add up to n
         self._check(self.lib.mh_dev_status(self.enc_ws.data_ptr(), self._stream()), "encode status")
         nb = int(self.nbits[0].item())
         self.nbits_hint = nb
@@ -400,7 +405,7 @@ class HipBackend:
         """(encode, decode, histogram) status words of the last step (0 = fine); synchronises."""
         st = self._stream()
         return (self.lib.mh_dev_status(self.enc_ws.data_ptr(), st), self.lib.mh_dev_status(self.dec_ws.data_ptr(), st),
-                self.lib.mh_dev_status(self.hist_ws.data_ptr(), st) if self.order == 1 else 0)
+                self.lib.mh_dev_status(self.hist_ws.data_ptr(), st))     # (order 2: hist2_total_kernel's verdict)
 
     def paths(self):
         """(encoder, decoder) that ran last on this backend's workspaces (codes of mh_dev_encode_path / mh_dev_decode_path)."""
