@@ -186,19 +186,51 @@ def cpu_baseline(mhc, table_bytes, sample, gpu_payload_prefix_check):
 
 def index_free_decode(mhc, codec, model, data, nbits, prev0, reps=2):
     """The real drop-in decode: the reference's `.cm` carries no index (src/coding.cpp:35-59), so the
-    payload the bench just wrote is decoded again with NO index handed in — mh_dev_build_index_fine rebuilds chunk index and
-    fine index from the bits alone, mh_dev_decode_fine decodes from them.  Outside the timed loop, like cpu_baseline;
-    HIP events on the launch stream.  (The index builder waits for the device between its batches of passes.)"""
+    payload the bench just wrote is decoded again with NO index handed in.  [r5] Two passes over the payload:
+    mh_dev_decode_stream_states (every 288-bit segment's entry state and symbol count) and mh_dev_decode_stream_emit (the
+    segment decoder writes the bytes) — no index is built.  `via_index` = the round-4 way beside it (mh_dev_build_index_fine
+    rebuilds chunk index and fine index, mh_dev_decode_fine decodes from them: three passes).  Outside the timed loop, like
+    cpu_baseline; HIP events on the launch stream.  (The states pass waits for the device between its sub-passes.)"""
     lib, n, dev = codec.lib, codec.n_now, codec.device
     wsb = int(lib.mh_dev_build_index_workspace(nbits))
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-    index = torch.zeros(nbits // codec.chunk + 2, dtype=torch.int64, device=dev)   # sized as a caller that does not know n must
-    fine_cap = nbits // 64 + 2
-    fine = torch.zeros(fine_cap, dtype=torch.int32, device=dev)
     nsym = torch.zeros(1, dtype=torch.int64, device=dev)
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    out = {}
+    # ---- two passes, no index
+    codec.decoded.zero_()
+    t_a = t_b = 0.0
+    path = 0
+    for rep in range(reps + 1):
+        e = [ev() for _ in range(3)]
+        e[0].record()
+        codec.check(lib.mh_dev_decode_stream_states(model.handle, codec.payload.data_ptr(), nbits, prev0, nsym.data_ptr(), ws.data_ptr(), wsb,
+                                                    codec.stream()), "mh_dev_decode_stream_states")
+        e[1].record()
+        path = int(lib.mh_dev_index_path(ws.data_ptr(), codec.stream()))
+        if path != 6:
+            break
+        codec.check(lib.mh_dev_decode_stream_emit(model.handle, codec.payload.data_ptr(), nbits, prev0, codec.decoded.data_ptr(), n, ws.data_ptr(), wsb,
+                                                  codec.stream()), "mh_dev_decode_stream_emit")
+        e[2].record()
+        torch.cuda.synchronize()
+        if rep:                                        # (the first repetition warms up)
+            t_a += e[0].elapsed_time(e[1])
+            t_b += e[1].elapsed_time(e[2])
+    if path == 6:
+        t_a, t_b = t_a / reps, t_b / reps
+        ok = (int(nsym.item()) == n and lib.mh_dev_status(ws.data_ptr(), codec.stream()) == 0 and torch.equal(codec.decoded[:n], data))
+        out = {"states_ms": round(t_a, 3), "emit_ms": round(t_b, 3), "total_ms": round(t_a + t_b, 3),
+               "GBps": round(n / ((t_a + t_b) * 1e-3) / 1e9, 2) if t_a + t_b > 0 else None,
+               "passes_over_the_payload": 2, "path": path, "workspace_bytes": wsb, "bit_exact": bool(ok)}
+    else:
+        out = {"path": path, "note": "this stream does not take the two-pass path (see include/mh.h); via_index is what decodes it"}
+    # ---- the round-4 way: both indices, then the tile decoder
+    index = torch.zeros(nbits // codec.chunk + 2, dtype=torch.int64, device=dev)   # sized as a caller that does not know n must
+    fine_cap = nbits // max(model.min_code_len, 1) // 64 + 2     # (a code has at least min_code_len bits)
+    fine = torch.zeros(fine_cap, dtype=torch.int32, device=dev)
     codec.decoded.zero_()
     t_idx = t_dec = 0.0
-    ev = lambda: torch.cuda.Event(enable_timing=True)
     for rep in range(reps + 1):
         e = [ev() for _ in range(3)]
         e[0].record()
@@ -209,17 +241,21 @@ def index_free_decode(mhc, codec, model, data, nbits, prev0, reps=2):
                                            fine.data_ptr(), codec.dec_ws.data_ptr(), codec.dec_ws_bytes, codec.stream()), "mh_dev_decode_fine")
         e[2].record()
         torch.cuda.synchronize()
-        if rep:                                        # (the first repetition warms up)
+        if rep:
             t_idx += e[0].elapsed_time(e[1])
             t_dec += e[1].elapsed_time(e[2])
     t_idx, t_dec = t_idx / reps, t_dec / reps
     ok = (int(nsym.item()) == n and lib.mh_dev_status(ws.data_ptr(), codec.stream()) == 0 and lib.mh_dev_status(codec.dec_ws.data_ptr(), codec.stream()) == 0
           and torch.equal(codec.decoded[:n], data) and torch.equal(index[:codec.nidx], codec.index[:codec.nidx]))
-    return {"index_build_ms": round(t_idx, 3), "decode_ms": round(t_dec, 3), "total_ms": round(t_idx + t_dec, 3),
-            "GBps": round(n / ((t_idx + t_dec) * 1e-3) / 1e9, 2) if t_idx + t_dec > 0 else None,
-            "index_path": int(lib.mh_dev_index_path(ws.data_ptr(), codec.stream())),       # 5 = tiles (fast path), 1 = segment iteration, ...
-            "decode_path": int(lib.mh_dev_decode_path(codec.dec_ws.data_ptr(), codec.stream())),
-            "index_workspace_bytes": wsb, "bit_exact": bool(ok)}
+    out["via_index"] = {"index_build_ms": round(t_idx, 3), "decode_ms": round(t_dec, 3), "total_ms": round(t_idx + t_dec, 3),
+                        "GBps": round(n / ((t_idx + t_dec) * 1e-3) / 1e9, 2) if t_idx + t_dec > 0 else None,
+                        "passes_over_the_payload": 3,
+                        "index_path": int(lib.mh_dev_index_path(ws.data_ptr(), codec.stream())),       # 5 = tiles (fast path), 1 = segment iteration, ...
+                        "decode_path": int(lib.mh_dev_decode_path(codec.dec_ws.data_ptr(), codec.stream())),
+                        "index_workspace_bytes": wsb, "fine_index_bytes": int(fine_cap * 4), "bit_exact": bool(ok)}
+    if "bit_exact" not in out:
+        out["bit_exact"] = bool(ok)
+    return out
 
 
 def self_launch(n_gpus):

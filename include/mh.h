@@ -119,6 +119,9 @@ int mh_model_write_table(const mh_model *m, uint8_t *out, size_t cap, size_t *nb
 int mh_model_type(const mh_model *m);
 /* Longest codeword in bits (0 for an all-empty model). */
 int mh_model_max_code_len(const mh_model *m);
+/* The shortest code of any context (0: a model without codes).  A payload of nbits bits holds at most nbits / min symbols:
+ * the bound for index and fine-index capacities of a stream whose symbol count is not known (mh_dev_build_index_fine). */
+int mh_model_min_code_len(const mh_model *m);
 /* get_encoding(prev, c) (src/markov_huffman.cpp:52-54 -> src/huffman.cpp:71-73): *len bits,
  * *code right-aligned (valid when *len <= 64).  *len == 0: symbol has no code in this context. */
 int mh_model_get_code(const mh_model *m, int prev, int sym, int *len, uint64_t *code);
@@ -406,6 +409,28 @@ int mh_dev_build_index_fine(const mh_model *m, const uint8_t *d_payload, uint64_
                             uint64_t *d_index, uint64_t index_cap, uint32_t chunk_symbols,
                             uint32_t *d_fine, uint64_t fine_cap,
                             uint64_t *d_n_symbols, void *d_ws, size_t ws_bytes, void *stream);
+/*
+ * STREAMS WITHOUT AN INDEX IN TWO PASSES OVER THE PAYLOAD (round 5) — what i_coding_provider::decompress is handed
+ * (src/coding.cpp:96-160: a `.cm` carries nothing but the header byte and the bits).  Building both indices and then decoding
+ * reads the payload three times; these two calls read it twice and write no index at all:
+ *   mh_dev_decode_stream_states  pass 1: the payload is cut into 288-bit segments, every segment is decoded from a guessed
+ *       state after a short warm-up, the segments whose guess was wrong are decoded again from their predecessor's end state
+ *       until none is left (the fixed point of mh_dev_build_index), a prefix sum of the segments' symbol counts gives every
+ *       segment its output offset; *d_n_symbols = the decoded size.  Synchronises `stream` between its passes.
+ *       mh_dev_index_path(d_ws) afterwards: 6 = the workspace holds the states, mh_dev_decode_stream_emit may follow;
+ *       0 = this model / stream does not take this path (an order-2 model, no tile tables, a code-length lattice, a code
+ *       longer than the tile tables resolve, under a megabit, or segments that do not synchronise): build an index
+ *       (mh_dev_build_index_fine) and decode from it instead.
+ *   mh_dev_decode_stream_emit    pass 2: every segment is decoded once more from its true state and its bytes are written
+ *       to d_out[offset of its first symbol ...); nothing is written at or beyond out_cap (MH_ERR_CAPACITY via mh_dev_status).
+ *       End state and count of every segment must come out as converged and the stream must end exactly at nbits
+ *       (src/coding.cpp:124,158): MH_ERR_CORRUPT otherwise.  No allocation, no synchronisation.
+ * Workspace for both: mh_dev_build_index_workspace(nbits), the same buffer, untouched in between.
+ */
+int mh_dev_decode_stream_states(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, uint8_t prev0,
+                                uint64_t *d_n_symbols, void *d_ws, size_t ws_bytes, void *stream);
+int mh_dev_decode_stream_emit(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, uint8_t prev0,
+                              uint8_t *d_out, uint64_t out_cap, void *d_ws, size_t ws_bytes, void *stream);
 /* Diagnostic: how the last mh_dev_build_index on this workspace arrived at the index — 1 the segment iteration
  * converged, 2 per-group context maps (fixed-length codes), 3 per-group state maps (mixed lengths), 4 the one-lane
  * walk, 0 nothing ran.  Synchronises `stream`. */

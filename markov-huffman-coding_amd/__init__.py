@@ -31,7 +31,7 @@ EXPORTS = [
     "mh_dev_malloc", "mh_dev_free", "mh_dev_upload", "mh_dev_download",
     "mh_model_from_counts", "mh_dev_model_from_counts", "mh_dev_model_workspace", "mh_dev_model_from_counts_ws",
     "mh_model_from_table_bits", "mh_model_write_table",
-    "mh_model_type", "mh_model_max_code_len", "mh_model_get_code", "mh_model_get_lut", "mh_model_decode_layout", "mh_model_tile_layout",
+    "mh_model_type", "mh_model_max_code_len", "mh_model_min_code_len", "mh_model_get_code", "mh_model_get_lut", "mh_model_decode_layout", "mh_model_tile_layout",
     "mh_model_image", "mh_model_free",
     "mh_set_input_residency", "mh_histogram_o1", "mh_histogram_o0", "mh_histogram_o2", "mh_dev_histogram_o2", "mh_dev_histogram_o2_ws", "mh_dev_histogram_o2_workspace", "mh_encode", "mh_encode_bound", "mh_stream_header",
     "mh_stream_parse_header", "mh_decode",
@@ -39,7 +39,7 @@ EXPORTS = [
     "mh_decode_to", "mh_model_payload_bits", "mh_dev_encode_workspace", "mh_dev_encode", "mh_dev_payload_bits", "mh_dev_encode_at", "mh_dev_encode_ctx", "mh_dev_encode_hist", "mh_dev_decode_workspace", "mh_dev_decode", "mh_dev_decode_dn",
     "mh_dev_build_index_workspace", "mh_dev_build_index", "mh_dev_status",
     "mh_dev_model2_workspace", "mh_dev_model2_array", "mh_dev_model2_build_slice", "mh_dev_model2_finish",
-    "mh_dev_encode_fine", "mh_dev_encode_ctx_fine", "mh_dev_decode_fine", "mh_dev_build_index_fine", "mh_dev_index_path", "mh_dev_encode_path", "mh_dev_decode_path",
+    "mh_dev_encode_fine", "mh_dev_encode_ctx_fine", "mh_dev_decode_fine", "mh_dev_build_index_fine", "mh_dev_decode_stream_states", "mh_dev_decode_stream_emit", "mh_dev_index_path", "mh_dev_encode_path", "mh_dev_decode_path",
 ]
 
 
@@ -79,6 +79,7 @@ def lib():
         l.mh_model_write_table.argtypes = [vp, vp, sz, psz]
         l.mh_model_type.argtypes = [vp]
         l.mh_model_max_code_len.argtypes = [vp]
+        l.mh_model_min_code_len.argtypes = [vp]
         l.mh_model_get_code.argtypes = [vp, i32, i32, pi, pu64]
         l.mh_model_get_lut.argtypes = [vp, i32, i32, pi, pi, pi, pi]
         l.mh_model_decode_layout.argtypes = [vp, pi, pi, pi]
@@ -128,6 +129,8 @@ def lib():
         l.mh_dev_encode_ctx_fine.argtypes = [vp, vp, sz, u32, vp, vp, sz, vp, vp, u32, vp, vp, sz, vp]
         l.mh_dev_decode_fine.argtypes = [vp, vp, u64, vp, vp, u64, vp, u32, vp, vp, sz, vp]
         l.mh_dev_build_index_fine.argtypes = [vp, vp, u64, u8, vp, u64, u32, vp, u64, vp, vp, sz, vp]
+        l.mh_dev_decode_stream_states.argtypes = [vp, vp, u64, u8, vp, vp, sz, vp]
+        l.mh_dev_decode_stream_emit.argtypes = [vp, vp, u64, u8, vp, u64, vp, sz, vp]
         l.mh_dev_index_path.argtypes = [vp, vp]
         l.mh_dev_encode_path.argtypes = [vp, vp]
         l.mh_dev_decode_path.argtypes = [vp, vp]
@@ -256,6 +259,10 @@ class Model:
     @property
     def max_code_len(self):
         return lib().mh_model_max_code_len(self._h)
+
+    @property
+    def min_code_len(self):
+        return lib().mh_model_min_code_len(self._h)
 
     def decode_layout(self):
         """(primary_bits, secondary_entries, in_lds) of the device decode tables."""

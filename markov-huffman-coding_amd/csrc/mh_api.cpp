@@ -27,6 +27,7 @@ struct mh_model {
     uint32_t nctx = 256;         // contexts the device tables are laid out for (65536 for type 2)
     std::vector<uint8_t> table2; // type 2 loaded from a table file: the file itself (write_table returns it)
     uint32_t len_gcd = 0;        // gcd of all code lengths (index builder: segment length is a multiple of it)
+    int min_len = 0;             // the shortest code of any context (0: no codes at all): a stream of nbits holds at most nbits / min_len symbols
     bool dec_lds = true, dec_direct = false;
     uint32_t nsec = 0;
     // device build: node arrays stay on the device until somebody asks for the mirror
@@ -121,6 +122,15 @@ int status_from_device(int s) {
 }
 
 // RAII device buffer for the host-buffer convenience calls
+// the shortest code of a device-built context from its meta record (mh_kernels.h, TB_META_STRIDE): mt[15] has bit l - 1 set
+// for every code length l in use, and is 0 for a one-symbol context, whose only code is one bit long (mt[2] = 1)
+static void note_min_len(mh_model *m, const uint32_t *mt) {
+    int l = 0;
+    if (mt[15]) l = __builtin_ctz(mt[15]) + 1;
+    else if (mt[2] >= 1) l = 1;
+    if (l && (m->min_len == 0 || l < m->min_len)) m->min_len = l;
+}
+
 struct DevBuf {
     void *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
@@ -299,6 +309,10 @@ int upload_model(mh_model *m) {
     m->nsec = uint32_t(m->packed.dec_sec.size());
     // gcd of the code lengths, the 1-bit code of one-symbol contexts aside (src/huffman.cpp:154-162: such a
     // context shifts the stream's phase once, it does not take the stream off the lattice of the others)
+    for (size_t i = 0; i < size_t(256) * 256; ++i) {
+        const int l = m->packed.len8[i];
+        if (l && (m->min_len == 0 || l < m->min_len)) m->min_len = l;
+    }
     for (int c = 0; c < 256; ++c) {
         int live = 0;
         for (int sy = 0; sy < 256; ++sy) live += m->packed.len8[size_t(c) * 256 + sy] != 0;
@@ -545,6 +559,7 @@ int dev_model_build(const uint64_t *d_counts, void *d_ws, size_t ws_bytes, hipSt
     for (int c = 0; c < 256; ++c) {
         const uint32_t *mt = &meta[size_t(c) * mhk::TB_META_STRIDE];
         m->max_len = std::max(m->max_len, int(mt[2]));
+        note_min_len(m, mt);
         // mt[15]: bit l-1 = a code of l bits exists (bit 31: 32 or more); one-symbol contexts aside, as in upload_model()
         for (uint32_t l = 1; l <= 32; ++l)
             if (mt[15] & (1u << (l - 1))) m->len_gcd = gcd_u32(m->len_gcd, l == 32 ? 1u : l);
@@ -795,6 +810,7 @@ int build2_finish(unsigned char *b, bool owned, hipStream_t st, mh_model **out) 
     for (uint32_t c = 0; c < O2_CTX; ++c) {
         const uint32_t *mt = &meta[size_t(c) * mhk::TB_META_STRIDE];
         m->max_len = std::max(m->max_len, int(mt[2]));
+        note_min_len(m, mt);
         lenmask |= mt[15];
         sec_base[c] = uint32_t(nsec);
         nsec += mt[4 + 8];                                        // tables under the depth-8 nodes, heights capped at O2_HCAP
@@ -888,6 +904,7 @@ int model2_from_table(const uint8_t *bytes, size_t n, mh_model **out) {
                 len8[size_t(c) * 256 + sy] = uint8_t(std::min(cd.len, 255));
                 code64[size_t(c) * 256 + sy] = cd.len <= 64 ? cd.right_aligned() : 0;
                 live += cd.len != 0;
+                if (cd.len && (m->min_len == 0 || cd.len < m->min_len)) m->min_len = cd.len;
             }
             m->max_len = std::max(m->max_len, cc.max_len());
             if (live >= 2) for (int sy = 0; sy < 256; ++sy) m->len_gcd = gcd_u32(m->len_gcd, len8[size_t(c) * 256 + sy]);
@@ -1037,6 +1054,7 @@ int mh_model_write_table(const mh_model *m, uint8_t *out, size_t cap, size_t *nb
 int mh_model_type(const mh_model *m) { return m ? m->type : MH_ERR_ARG; }
 
 int mh_model_max_code_len(const mh_model *m) { return m ? m->max_len : MH_ERR_ARG; }
+int mh_model_min_code_len(const mh_model *m) { return m ? m->min_len : MH_ERR_ARG; }
 
 int mh_model_get_code(const mh_model *m, int prev, int sym, int *len, uint64_t *code) {
     if (!m || !len || !code) return MH_ERR_ARG;
@@ -1374,32 +1392,66 @@ int mh_dev_decode_dn(const mh_model *m, const uint8_t *d_payload, const uint64_t
     return dev_decode(m, d_payload, nbits_hint, d_nbits, d_out, n_symbols, d_index, chunk_symbols, d_ws, ws_bytes, stream);
 }
 
-static int dev_build_index(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, uint8_t prev0, uint64_t *d_index,
-                           uint64_t index_cap, uint32_t chunk_symbols, uint64_t *d_n_symbols, void *d_ws, size_t ws_bytes, void *stream,
-                           uint32_t *d_fine, uint64_t fine_cap) {
-    if (!m || !d_index || !d_n_symbols || !d_ws || (!d_payload && nbits)) return MH_ERR_ARG;
-    if (ws_bytes < mhk::build_index_workspace_bytes(nbits)) return MH_ERR_CAPACITY;
+// the model's and the stream's part of an index-builder / stream-decoder launch
+static int idx_params(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, uint8_t prev0, uint32_t chunk_symbols, uint64_t *d_n_symbols,
+                      mhk::IdxParams &p) {
     int shift = chunk_shift_of(chunk_symbols);
     if (shift < 0 || !aligned16(d_payload)) return MH_ERR_ARG;
     if (m->max_len > mh::MAX_CODE_BITS) return MH_ERR_CODE_TOO_LONG;
     if (!m->d_prim) return MH_ERR_NO_DEVICE;
-    mhk::IdxParams p{};
+    p = mhk::IdxParams{};
     p.payload = d_payload; p.payload_bytes = (nbits + 7) / 8; p.nbits = nbits;
     p.order = m->type == 2 ? 2 : 1;
     p.prev0 = ctx_of_prev0(m, prev0); p.chunk_shift = uint32_t(shift);
-    p.index = reinterpret_cast<unsigned long long *>(d_index); p.index_cap = index_cap;
     p.n_symbols = reinterpret_cast<unsigned long long *>(d_n_symbols);
     p.prim = m->d_prim; p.sec = m->d_sec; p.sec_base = m->d_sec_base; p.tree = m->d_tree;
     p.P = uint32_t(m->dec_bits);
     p.direct = m->dec_direct ? 1u : 0u; p.H = uint32_t(m->dec_h);
     p.len_gcd = m->len_gcd;
     p.max_len = uint32_t(m->max_len > 0 ? m->max_len : 1);
-    p.fine = m->type == 2 ? nullptr : d_fine;
-    p.fine_cap = fine_cap;
     if (m->type != 2 && m->tile_p) {                         // the tile decoder's tables: the index builder's fast path
         p.tprim = m->d_tprim; p.tsec = m->d_tsec; p.tP = uint32_t(m->tile_p); p.tH = uint32_t(m->tile_h); p.tnsec = m->tile_nsec;
     }
+    return MH_OK;
+}
+
+static int dev_build_index(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, uint8_t prev0, uint64_t *d_index,
+                           uint64_t index_cap, uint32_t chunk_symbols, uint64_t *d_n_symbols, void *d_ws, size_t ws_bytes, void *stream,
+                           uint32_t *d_fine, uint64_t fine_cap) {
+    if (!m || !d_index || !d_n_symbols || !d_ws || (!d_payload && nbits)) return MH_ERR_ARG;
+    if (ws_bytes < mhk::build_index_workspace_bytes(nbits)) return MH_ERR_CAPACITY;
+    mhk::IdxParams p;
+    const int rc = idx_params(m, d_payload, nbits, prev0, chunk_symbols, d_n_symbols, p);
+    if (rc != MH_OK) return rc;
+    p.index = reinterpret_cast<unsigned long long *>(d_index); p.index_cap = index_cap;
+    p.fine = m->type == 2 ? nullptr : d_fine;
+    p.fine_cap = fine_cap;
     HIP_TRY(mhk::launch_build_index(p, d_ws, static_cast<hipStream_t>(stream)));
+    return MH_OK;
+}
+
+// Streams without an index in two passes over the payload (mh.h): states and counts, then the segment decoder.
+int mh_dev_decode_stream_states(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, uint8_t prev0, uint64_t *d_n_symbols,
+                                void *d_ws, size_t ws_bytes, void *stream) {
+    if (!m || !d_n_symbols || !d_ws || (!d_payload && nbits)) return MH_ERR_ARG;
+    if (ws_bytes < mhk::build_index_workspace_bytes(nbits)) return MH_ERR_CAPACITY;
+    mhk::IdxParams p;
+    const int rc = idx_params(m, d_payload, nbits, prev0, MH_CHUNK_DEFAULT, d_n_symbols, p);
+    if (rc != MH_OK) return rc;
+    HIP_TRY(mhk::launch_stream_states(p, d_ws, static_cast<hipStream_t>(stream)));
+    return MH_OK;
+}
+
+int mh_dev_decode_stream_emit(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, uint8_t prev0, uint8_t *d_out, uint64_t out_cap,
+                              void *d_ws, size_t ws_bytes, void *stream) {
+    if (!m || !d_ws || (!d_payload && nbits) || (!d_out && out_cap)) return MH_ERR_ARG;
+    if (ws_bytes < mhk::build_index_workspace_bytes(nbits)) return MH_ERR_CAPACITY;
+    if (nbits == 0) return MH_OK;
+    if (mh_dev_index_path(d_ws, stream) != mhk::IDX_PATH_STATES) return MH_ERR_ARG;      // (no states in this workspace)
+    mhk::IdxParams p;
+    const int rc = idx_params(m, d_payload, nbits, prev0, MH_CHUNK_DEFAULT, nullptr, p);
+    if (rc != MH_OK) return rc;
+    HIP_TRY(mhk::launch_stream_emit(p, d_ws, d_out, out_cap, static_cast<hipStream_t>(stream)));
     return MH_OK;
 }
 
@@ -1742,16 +1794,49 @@ int mh_decode_to(const mh_model *m, const uint8_t *payload, uint64_t nbits, uint
     DevBuf d_payload, d_index, d_ws, d_nsym, d_out;
     HIP_TRY(d_payload.alloc(pbytes));
     if (pbytes) HIP_TRY(stage_h2d(d_payload.p, payload, pbytes, st));
+    HIP_TRY(d_nsym.alloc(8));
+    // [r5] two passes over the payload and no index at all (mh_dev_decode_stream_states / _emit): the segments' states, then the
+    // bytes.  Streams and models that do not take that path — and cards without room for the whole output at once — build
+    // both indices and decode from them, as before.
+    if (m->type != 2 && !getenv("MH_DECODE_NO_STREAM")) {
+        DevBuf d_iws, d_all;
+        const size_t iws = mh_dev_build_index_workspace(nbits);
+        HIP_TRY(d_iws.alloc(iws));
+        int rc = mh_dev_decode_stream_states(m, d_payload.as<uint8_t>(), nbits, prev0, d_nsym.as<uint64_t>(), d_iws.p, iws, st);
+        if (rc != MH_OK) return rc;
+        rc = mh_dev_status(d_iws.p, st);
+        if (rc != MH_OK) return rc;
+        if (mh_dev_index_path(d_iws.p, st) == mhk::IDX_PATH_STATES) {
+            HIP_TRY(hipMemcpy(&n_symbols, d_nsym.p, 8, hipMemcpyDeviceToHost));
+            if (d_all.alloc(size_t(n_symbols)) == hipSuccess) {
+                *nbytes = size_t(n_symbols);
+                out = get_out(ctx, size_t(n_symbols));           // the size is known only now
+                if (!out && n_symbols) return MH_ERR_CAPACITY;
+                rc = mh_dev_decode_stream_emit(m, d_payload.as<uint8_t>(), nbits, prev0, d_all.as<uint8_t>(), n_symbols, d_iws.p, iws, st);
+                if (rc != MH_OK) return rc;
+                rc = mh_dev_status(d_iws.p, st);
+                if (rc != MH_OK) return rc;
+                g_last_index_path = mhk::IDX_PATH_STATES;
+                const size_t seg = segment_bytes();
+                for (uint64_t off = 0; off < n_symbols; off += seg) {
+                    const size_t len = n_symbols - off < seg ? size_t(n_symbols - off) : seg;
+                    HIP_TRY(stage_d2h(out + off, d_all.as<uint8_t>() + off, len, st));
+                }
+                return MH_OK;
+            }
+            (void)hipGetLastError();                             // no room for the whole output: the indexed way, segment by segment
+        }
+    }
     // every code is at least one bit: the stream holds at most nbits symbols
     const uint64_t idx_cap = nbits / chunk_symbols + 2;
     HIP_TRY(d_index.alloc(size_t(idx_cap) * 8));
-    HIP_TRY(d_nsym.alloc(8));
     // the fill pass of the index builder also writes the fine index (one uint32 per 64 symbols): the stream then
     // decodes with the tile decoder although it came without any index
     DevBuf d_fine;
     // (nbits / 64 entries = half the payload's size again: a bound for 1-bit codes.  The fine index only buys speed, so a
     // card that cannot spare it decodes with the chunk decoder instead of failing — ADVICE r03)
-    uint64_t fine_cap = m->type == 2 ? 0 : nbits / MH_FINE_SYMBOLS + 2;
+    // (a code has at least min_len bits: nbits / min_len symbols at most — ADVICE r03 / VERDICT r04)
+    uint64_t fine_cap = m->type == 2 ? 0 : nbits / uint64_t(m->min_len > 0 ? m->min_len : 1) / MH_FINE_SYMBOLS + 2;
     if (fine_cap && d_fine.alloc(size_t(fine_cap) * 4) != hipSuccess) {
         (void)hipGetLastError();
         fine_cap = 0;

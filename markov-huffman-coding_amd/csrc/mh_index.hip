@@ -442,6 +442,87 @@ static void note_index_path(unsigned char *ws, uint32_t path, hipStream_t st) {
     (void)launch_set_word(reinterpret_cast<uint32_t *>(ws + 8), path, st);
 }
 
+// ---- the fast path's first pass (index_tile_kernel mode 0 + repairs + prefix sums), shared by the index builder and the
+// segment decoder [r5]: on success (*ok) q holds the workspace's arrays — e16 / c16 = every segment's converged end state
+// and symbol count, tile_base = the number of the first symbol of every tile, *p.n_symbols = the stream's symbol count.
+// Eligible: order 1, tile tables with P = 7, no code-length lattice (g == 1), a stream worth a launch of 256 workgroups.
+// Given up (*ok false, nothing else changed but the status block) when more than a quarter of the segments did not
+// synchronise within their warm-up, or the repairs do not die out.  Synchronises `st` between passes.
+static bool index_tiles_eligible(const IdxParams &p, const IdxWs &L, uint32_t g) {
+    return p.order != 2 && p.tprim && p.tP == 7 && p.max_len <= p.tP + p.tH && g == 1 && p.nbits >= (1ull << 20) && L.nseg5 < 0xFFFFFFFFull && !getenv("MH_INDEX_NO_TILES");
+}
+static hipError_t index_tile_states(const IdxParams &p, const IdxWs &L, unsigned char *ws, hipStream_t st, IdxParams &q, bool *ok_out) {
+    hipError_t e = hipSuccess;
+    q = p;
+    q.e16 = reinterpret_cast<uint16_t *>(ws + L.off_e16);
+    q.s16 = reinterpret_cast<uint16_t *>(ws + L.off_s16);
+    q.c16 = reinterpret_cast<uint16_t *>(ws + L.off_c16);
+    q.tile_cnt = reinterpret_cast<uint32_t *>(ws + L.off_tcnt);
+    q.tile_base = reinterpret_cast<unsigned long long *>(ws + L.off_tbase);
+    q.nseg5 = L.nseg5; q.ntile5 = L.ntile5;
+    // The warm-up is short: streams of an iid-like source re-synchronise within a few symbols (4 GiB of Zipf: 256 bits leave
+    // one segment in 10^5 for the repairs), text, whose decode depends on the context at every step, leaves one in seven —
+    // listed and repaired one thread each, which costs a fraction of a pass either way.  More than a quarter to repair:
+    // once more with the longest warm-up; still more: the stream does not synchronise this way.
+    q.dirty_list = reinterpret_cast<uint32_t *>(ws + L.off_dirty);
+    q.dirty_cap = uint32_t(L.dirty_cap < 0xFFFFFFFFull ? L.dirty_cap : 0xFFFFFFFFull);
+    const uint64_t dwant = (q.nseg5 + 255) / 256;
+    const unsigned dgrid = unsigned(dwant < 2048 ? dwant : 2048);
+    bool ok = false;
+    uint32_t it = 0;
+    q.warm_bits = 256;
+    if (const char *wv = getenv("MH_INDEX_WARM_BITS")) { const int v = atoi(wv); if (v >= 16 && v <= int(IX_WARM_BITS_MAX)) q.warm_bits = uint32_t(v); }
+    else if (q.ntile5 >= 16384) {
+        // how long a warm-up this stream needs is a property of the source: a sample (the first 1/256 of the tiles, one tile
+        // per wave of the card at least) with 128 bits tells — where that leaves under 2 % of the segments to repair the
+        // short warm-up serves the whole stream (the pass decodes warm-up + segment: 1.44 instead of 1.89 segment lengths)
+        IdxParams sq = q;
+        sq.ntile5 = q.ntile5 / 256 > 4096 ? q.ntile5 / 256 : 4096;
+        sq.nseg5 = sq.ntile5 * IX_TILE_SEGS;
+        sq.warm_bits = 128;
+        sq.iter = it;
+        e = launch_index_tile(sq, 0, st);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(index_tile_dirty_kernel, dim3(256), dim3(256), 0, st, sq);
+        unsigned int dirty = ~0u;
+        e = hipMemcpyAsync(&dirty, q.changed + it, 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return e;
+        ++it;
+        if (uint64_t(dirty) * 50u < sq.nseg5) q.warm_bits = 128;
+    }
+    for (int attempt = 0; attempt < 2 && !ok; ++attempt) {
+        e = launch_index_tile(q, 0, st);
+        if (e != hipSuccess) return e;
+        unsigned int prev_dirty = ~0u;
+        bool hopeless = false;
+        for (const uint32_t it_end = it + 24u; it < it_end && !ok && !hopeless; ++it) {
+            q.iter = it;
+            hipLaunchKernelGGL(index_tile_dirty_kernel, dim3(dgrid), dim3(256), 0, st, q);
+            unsigned int dirty = 1;
+            e = hipMemcpyAsync(&dirty, q.changed + it, 4, hipMemcpyDeviceToHost, st);
+            if (e != hipSuccess) return e;
+            e = hipStreamSynchronize(st);
+            if (e != hipSuccess) return e;
+            ok = dirty == 0;
+            // too many to list, or repairs that do not die out (fewer than a quarter fewer per pass)
+            hopeless = dirty > q.dirty_cap || (dirty > 4096u && prev_dirty != ~0u && uint64_t(dirty) * 4u > uint64_t(prev_dirty) * 3u);
+            prev_dirty = dirty;
+            if (!ok && !hopeless) hipLaunchKernelGGL(index_tile_repair_kernel, dim3((dirty + 255u) / 256u), dim3(256), 0, st, q, dirty);
+        }
+        if (!ok && q.warm_bits < IX_WARM_BITS_MAX) q.warm_bits = IX_WARM_BITS_MAX; else break;
+    }
+    *ok_out = ok;
+    if (ok) {
+        unsigned long long *tblk = reinterpret_cast<unsigned long long *>(ws + L.off_tblk);
+        hipLaunchKernelGGL(index_tile_count_kernel, dim3(unsigned((q.ntile5 + 3) / 4)), dim3(256), 0, st, q);
+        (void)launch_scan_local(q.tile_cnt, q.ntile5, q.tile_base, tblk, st);
+        (void)launch_scan_top(tblk, L.ntblk, nullptr, st);
+        hipLaunchKernelGGL(index_scan_add_kernel, dim3(unsigned(L.ntblk)), dim3(SCAN_THREADS), 0, st, q.tile_base, tblk, q.ntile5, L.ntblk, q.n_symbols);
+    }
+    return hipGetLastError();
+}
+
 // Synchronises `st` between batches of passes (the pass count depends on the data).
 hipError_t launch_build_index(IdxParams p, void *d_ws, hipStream_t st) {
     unsigned char *ws = static_cast<unsigned char *>(d_ws);
@@ -462,76 +543,14 @@ hipError_t launch_build_index(IdxParams p, void *d_ws, hipStream_t st) {
     e = once_per_device(&DeviceState::index_ready, [] { return allow_lds(reinterpret_cast<const void *>(build_index_kernel<1>), 131072); });
     if (e != hipSuccess) return e;
     if (p.P > 8) return hipErrorInvalidValue;
-    // ---- the fast path: order 1, every code within the tile decoder's two table levels, no code-length lattice (g == 1),
-    // a stream worth a launch of 256 workgroups.  Given up (and the segment iteration below started from scratch) when more
-    // than an eighth of the segments did not synchronise within their warm-up, or the repairs do not die out.
-    if (p.order != 2 && p.tprim && p.tP == 7 && p.max_len <= p.tP + p.tH && g == 1 && p.nbits >= (1ull << 20) && L.nseg5 < 0xFFFFFFFFull && !getenv("MH_INDEX_NO_TILES")) {
-        IdxParams q = p;
-        q.e16 = reinterpret_cast<uint16_t *>(ws + L.off_e16);
-        q.s16 = reinterpret_cast<uint16_t *>(ws + L.off_s16);
-        q.c16 = reinterpret_cast<uint16_t *>(ws + L.off_c16);
-        q.tile_cnt = reinterpret_cast<uint32_t *>(ws + L.off_tcnt);
-        q.tile_base = reinterpret_cast<unsigned long long *>(ws + L.off_tbase);
-        q.nseg5 = L.nseg5; q.ntile5 = L.ntile5;
-        // The warm-up is short: streams of an iid-like source re-synchronise within a few symbols (4 GiB of Zipf: 256 bits leave
-        // one segment in 10^5 for the repairs), text, whose decode depends on the context at every step, leaves one in seven —
-        // listed and repaired one thread each, which costs a fraction of a pass either way.  More than a quarter to repair:
-        // once more with the longest warm-up; still more: the stream does not synchronise this way.
-        q.dirty_list = reinterpret_cast<uint32_t *>(ws + L.off_dirty);
-        q.dirty_cap = uint32_t(L.dirty_cap < 0xFFFFFFFFull ? L.dirty_cap : 0xFFFFFFFFull);
-        const uint64_t dwant = (q.nseg5 + 255) / 256;
-        const unsigned dgrid = unsigned(dwant < 2048 ? dwant : 2048);
+    // ---- the fast path (index_tile_states above); when it gives up the segment iteration below starts from scratch
+    if (index_tiles_eligible(p, L, g)) {
+        IdxParams q;
         bool ok = false;
-        uint32_t it = 0;
-        q.warm_bits = 256;
-        if (const char *wv = getenv("MH_INDEX_WARM_BITS")) { const int v = atoi(wv); if (v >= 16 && v <= int(IX_WARM_BITS_MAX)) q.warm_bits = uint32_t(v); }
-        else if (q.ntile5 >= 16384) {
-            // how long a warm-up this stream needs is a property of the source: a sample (the first 1/256 of the tiles, one tile
-            // per wave of the card at least) with 128 bits tells — where that leaves under 2 % of the segments to repair the
-            // short warm-up serves the whole stream (the pass decodes warm-up + segment: 1.44 instead of 1.89 segment lengths)
-            IdxParams sq = q;
-            sq.ntile5 = q.ntile5 / 256 > 4096 ? q.ntile5 / 256 : 4096;
-            sq.nseg5 = sq.ntile5 * IX_TILE_SEGS;
-            sq.warm_bits = 128;
-            sq.iter = it;
-            e = launch_index_tile(sq, 0, st);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(index_tile_dirty_kernel, dim3(256), dim3(256), 0, st, sq);
-            unsigned int dirty = ~0u;
-            e = hipMemcpyAsync(&dirty, q.changed + it, 4, hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess) e = hipStreamSynchronize(st);
-            if (e != hipSuccess) return e;
-            ++it;
-            if (uint64_t(dirty) * 50u < sq.nseg5) q.warm_bits = 128;
-        }
-        for (int attempt = 0; attempt < 2 && !ok; ++attempt) {
-            e = launch_index_tile(q, 0, st);
-            if (e != hipSuccess) return e;
-            unsigned int prev_dirty = ~0u;
-            bool hopeless = false;
-            for (const uint32_t it_end = it + 24u; it < it_end && !ok && !hopeless; ++it) {
-                q.iter = it;
-                hipLaunchKernelGGL(index_tile_dirty_kernel, dim3(dgrid), dim3(256), 0, st, q);
-                unsigned int dirty = 1;
-                e = hipMemcpyAsync(&dirty, q.changed + it, 4, hipMemcpyDeviceToHost, st);
-                if (e != hipSuccess) return e;
-                e = hipStreamSynchronize(st);
-                if (e != hipSuccess) return e;
-                ok = dirty == 0;
-                // too many to list, or repairs that do not die out (fewer than a quarter fewer per pass)
-                hopeless = dirty > q.dirty_cap || (dirty > 4096u && prev_dirty != ~0u && uint64_t(dirty) * 4u > uint64_t(prev_dirty) * 3u);
-                prev_dirty = dirty;
-                if (!ok && !hopeless) hipLaunchKernelGGL(index_tile_repair_kernel, dim3((dirty + 255u) / 256u), dim3(256), 0, st, q, dirty);
-            }
-            if (!ok && q.warm_bits < IX_WARM_BITS_MAX) q.warm_bits = IX_WARM_BITS_MAX; else break;
-        }
+        e = index_tile_states(p, L, ws, st, q, &ok);
+        if (e != hipSuccess) return e;
         if (ok) {
             note_index_path(ws, IDX_PATH_TILES, st);
-            unsigned long long *tblk = reinterpret_cast<unsigned long long *>(ws + L.off_tblk);
-            hipLaunchKernelGGL(index_tile_count_kernel, dim3(unsigned((q.ntile5 + 3) / 4)), dim3(256), 0, st, q);
-            (void)launch_scan_local(q.tile_cnt, q.ntile5, q.tile_base, tblk, st);
-            (void)launch_scan_top(tblk, L.ntblk, nullptr, st);
-            hipLaunchKernelGGL(index_scan_add_kernel, dim3(unsigned(L.ntblk)), dim3(SCAN_THREADS), 0, st, q.tile_base, tblk, q.ntile5, L.ntblk, q.n_symbols);
             return launch_index_tile(q, 1, st);
         }
         e = hipMemsetAsync(ws, 0, L.off_end, st);                     // (status and the pass counters: the iteration starts clean)
@@ -688,5 +707,43 @@ hipError_t launch_build_index(IdxParams p, void *d_ws, hipStream_t st) {
     return hipGetLastError();
 }
 
+
+// ---- streams without an index in TWO passes over the payload [r5]: states (above), then the segment decoder (mh_tile.hip)
+// launch_stream_states: status block bytes 8..11 = IDX_PATH_STATES when the workspace is ready for launch_stream_emit,
+// IDX_PATH_NONE when this stream / model does not take the fast path (the caller then builds an index as before).
+static void stream_params(IdxParams &p, unsigned char *ws, const IdxWs &L) {
+    p.status = reinterpret_cast<int *>(ws);
+    p.changed = reinterpret_cast<unsigned int *>(ws + L.off_changed);
+}
+hipError_t launch_stream_states(IdxParams p, void *d_ws, hipStream_t st) {
+    unsigned char *ws = static_cast<unsigned char *>(d_ws);
+    const IdxWs L = idx_ws_layout(p.nbits);
+    stream_params(p, ws, L);
+    hipError_t e = hipMemsetAsync(ws, 0, L.off_end, st);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(p.n_symbols, 0, 8, st);
+    if (e != hipSuccess || p.nbits == 0) return e;
+    const uint32_t g = p.len_gcd >= 1 && p.len_gcd <= 64 ? p.len_gcd : 1;
+    if (!index_tiles_eligible(p, L, g)) return hipSuccess;
+    IdxParams q;
+    bool ok = false;
+    e = index_tile_states(p, L, ws, st, q, &ok);
+    if (e != hipSuccess) return e;
+    if (ok) note_index_path(ws, IDX_PATH_STATES, st);
+    else e = hipMemsetAsync(ws, 0, L.off_end, st);
+    return e;
+}
+hipError_t launch_stream_emit(IdxParams p, void *d_ws, uint8_t *d_out, uint64_t out_cap, hipStream_t st) {
+    unsigned char *ws = static_cast<unsigned char *>(d_ws);
+    const IdxWs L = idx_ws_layout(p.nbits);
+    stream_params(p, ws, L);
+    p.e16 = reinterpret_cast<uint16_t *>(ws + L.off_e16);
+    p.s16 = reinterpret_cast<uint16_t *>(ws + L.off_s16);
+    p.c16 = reinterpret_cast<uint16_t *>(ws + L.off_c16);
+    p.tile_cnt = reinterpret_cast<uint32_t *>(ws + L.off_tcnt);
+    p.tile_base = reinterpret_cast<unsigned long long *>(ws + L.off_tbase);
+    p.nseg5 = L.nseg5; p.ntile5 = L.ntile5;
+    return launch_segment_decode(p, d_out, out_cap, st);
+}
 
 }  // namespace mhk

@@ -188,13 +188,19 @@ struct IdxParams {
 constexpr uint32_t IX_SEG_BITS = 288, IX_TILE_SEGS = 128, IX_TILE_BITS = IX_TILE_SEGS * IX_SEG_BITS, IX_WARM_BITS_MAX = 512;
 constexpr uint16_t IX_INVALID = 0xFFFF;
 hipError_t launch_index_tile(const IdxParams &p, int mode, hipStream_t st);   // mode 0: states and counts, 1: the index entries
+// [r5] the segment decoder: the second pass over a stream without an index emits the bytes itself (e16 / c16 / tile_base set)
+hipError_t launch_segment_decode(const IdxParams &p, uint8_t *d_out, uint64_t out_cap, hipStream_t st);
+// streams without an index in two passes: states + counts (synchronises between its passes), then the bytes
+hipError_t launch_stream_states(IdxParams p, void *d_ws, hipStream_t st);
+hipError_t launch_stream_emit(IdxParams p, void *d_ws, uint8_t *d_out, uint64_t out_cap, hipStream_t st);
 // which encoder a launch_encode* call used (its workspace's status block, bytes 8..11)
 // which decoder ran (status block of the decode workspace, bytes 40..43; mh_dev_decode_path)
 enum { DEC_PATH_NONE = 0, DEC_PATH_TILE = 1, DEC_PATH_CHUNK = 2 };
 hipError_t launch_set_word(uint32_t *d_word, uint32_t v, hipStream_t st);
 enum { ENC_PATH_NONE = 0, ENC_PATH_REGIONS = 1, ENC_PATH_LENGTH_PASS = 2, ENC_PATH_REGIONS_ESCAPES = 3, ENC_PATH_CHAIN = 4 };
 // how launch_build_index arrived at the index (status block bytes 8..11)
-enum { IDX_PATH_NONE = 0, IDX_PATH_SEGMENTS = 1, IDX_PATH_GROUP_MAPS = 2, IDX_PATH_STATE_MAPS = 3, IDX_PATH_WALK = 4, IDX_PATH_TILES = 5 };
+enum { IDX_PATH_NONE = 0, IDX_PATH_SEGMENTS = 1, IDX_PATH_GROUP_MAPS = 2, IDX_PATH_STATE_MAPS = 3, IDX_PATH_WALK = 4, IDX_PATH_TILES = 5,
+       IDX_PATH_STATES = 6 };   // 6: launch_stream_states left the segments' states for launch_stream_emit (no index was built)
 
 // ---- device tree build (mh_tree.hip)
 constexpr int TB_NODE_STRIDE = 520;   // >= 513 nodes per context

@@ -552,8 +552,10 @@ __global__ __launch_bounds__(T_THREADS) void index_tile_kernel(IdxParams p) {
         }
         uint32_t overflow = 0;
 #pragma unroll 1
-        for (uint32_t it = 0; it < IX_SEG_BITS + IX_WARM_BITS_MAX + 64u; ++it) {  // (a symbol takes at least one bit)
-            if (!__any(q[0] < qe0[0] || q[1] < qe0[1])) break;
+        for (uint32_t it = 0; it < IX_SEG_BITS + IX_WARM_BITS_MAX + 64u; it += 4u) {  // (a symbol takes at least one bit)
+            if (!__any(q[0] < qe0[0] || q[1] < qe0[1])) break;       // [r5] asked once per four steps: a finished stream stands still
+#pragma unroll
+          for (int sub = 0; sub < 4; ++sub) {
             if (MODE == 1) {
 #pragma unroll
                 for (int j = 0; j < K; ++j) {
@@ -601,6 +603,7 @@ __global__ __launch_bounds__(T_THREADS) void index_tile_kernel(IdxParams p) {
                 q[j] += go ? (ok ? len : 1u) : 0u;
                 k[j] += (in && go) ? 1u : 0u;
             }
+          }
         }
 #pragma unroll
         for (int j = 0; j < K; ++j) {
@@ -620,6 +623,230 @@ __global__ __launch_bounds__(T_THREADS) void index_tile_kernel(IdxParams p) {
         }
         if (MODE == 1 && overflow) atomicExch(p.status, MHK_STATUS_CAPACITY);
     }
+}
+
+// ---- the segment decoder [r5] -----------------------------------------------------
+// A stream that came without any index used to be decoded THREE times: index_tile_kernel<0> (states), <1> (index entries),
+// then the tile decoder.  After the states pass and its repairs every 288-bit segment's entry state and symbol count are
+// known, so a prefix sum gives the output offset of its first symbol and the second pass can emit the bytes itself: same
+// staging, same two streams per lane, same tables; a lane keeps the symbols of a round of 64 steps in registers (byte j of
+// the round = step j in every lane: static register indices) and writes its run to out[first symbol of the segment + 64
+// round ...) — no fine index is written or read and the payload is decoded twice, not three times.  End state and count of
+// every segment must come out as converged, the stream must end exactly at nbits (src/coding.cpp:124,158), and nothing is
+// written beyond out_cap (MHK_STATUS_CAPACITY).
+constexpr uint32_t SD_REGION = IX_TILE_BYTES + 48u;            // the tile + what a code past its end and a window read may touch + a zero vector
+static_assert(SD_REGION % 16 == 0, "16-byte staging stores");
+typedef uint32_t u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
+typedef uint32_t u32x2_unaligned __attribute__((ext_vector_type(2), aligned(1)));
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+typedef uint16_t u16_unaligned __attribute__((aligned(1)));
+
+// m <= 64 bytes of a lane's round (Qk[g] = bytes 16 g ..) to d, any alignment: whole 16-byte groups, then 8 / 4 / 2 / 1
+__device__ __forceinline__ void seg_store_run(uint8_t *d, const uint4 (&Qk)[4], uint32_t m) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        if (m >= 16u * uint32_t(g + 1)) *reinterpret_cast<u32x4_unaligned *>(d + 16 * g) = u32x4_unaligned{Qk[g].x, Qk[g].y, Qk[g].z, Qk[g].w};
+    const uint32_t gt = m >> 4, t = m & 15u;
+    if (gt >= 4u || t == 0u) return;
+    // the group the run ends in, by selects on plain values (a select between array ELEMENTS is turned into an indexed load,
+    // and the whole array then lives in scratch memory)
+    uint32_t c[4][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        c[g][0] = Qk[g].x; c[g][1] = Qk[g].y; c[g][2] = Qk[g].z; c[g][3] = Qk[g].w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm("" : "+v"(c[g][i]));
+    }
+    uint4 T;
+    T.x = gt == 0u ? c[0][0] : gt == 1u ? c[1][0] : gt == 2u ? c[2][0] : c[3][0];
+    T.y = gt == 0u ? c[0][1] : gt == 1u ? c[1][1] : gt == 2u ? c[2][1] : c[3][1];
+    T.z = gt == 0u ? c[0][2] : gt == 1u ? c[1][2] : gt == 2u ? c[2][2] : c[3][2];
+    T.w = gt == 0u ? c[0][3] : gt == 1u ? c[1][3] : gt == 2u ? c[2][3] : c[3][3];
+    uint8_t *dt = d + 16u * gt;
+    if (t & 8u) { *reinterpret_cast<u32x2_unaligned *>(dt) = u32x2_unaligned{T.x, T.y}; T.x = T.z; T.y = T.w; dt += 8; }
+    if (t & 4u) { *reinterpret_cast<u32_unaligned *>(dt) = T.x; T.x = T.y; dt += 4; }
+    if (t & 2u) { *reinterpret_cast<u16_unaligned *>(dt) = uint16_t(T.x); T.x >>= 16; dt += 2; }
+    if (t & 1u) *dt = uint8_t(T.x);
+}
+
+template <int PC>
+__global__ __launch_bounds__(T_THREADS) void segment_decode_kernel(IdxParams p, uint8_t *out, uint64_t out_cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr uint32_t P = PC, PRIM_BYTES = (256u << P) * 2u;
+    constexpr int K = 2;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (uint32_t i = tid; i < PRIM_BYTES / 16u; i += T_THREADS)
+        reinterpret_cast<uint4 *>(smem)[i] = reinterpret_cast<const uint4 *>(p.tprim)[i];
+    __syncthreads();
+    constexpr uint32_t NW = (uint32_t(T_LDS_BYTES) - PRIM_BYTES) / SD_REGION < uint32_t(T_WAVES) ? (uint32_t(T_LDS_BYTES) - PRIM_BYTES) / SD_REGION : uint32_t(T_WAVES);
+    if (wave >= NW) return;                                       // no barrier below this line
+    if (lds_addr_of(smem) != 0u) {                                // the first-level table is addressed from LDS address 0
+        if (tid == 0) atomicExch(p.status, MHK_STATUS_CORRUPT);
+        return;
+    }
+    unsigned char *reg = smem + PRIM_BYTES + wave * SD_REGION;
+    const uint32_t reg_bit0 = lds_addr_of(reg) * 8u;
+    const uint32_t H = p.tH;
+    const __amdgpu_buffer_rsrc_t sec_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.tsec), 0, p.tnsec ? int((p.tnsec + 8u) * 2u) : 0, 0x00020000);
+    const uint64_t vec_total = (p.payload_bytes + 15u) >> 4;     // (the payload is readable up to the next 64-byte boundary: mh.h)
+
+    for (uint64_t t = uint64_t(blockIdx.x) * NW + wave; t < p.ntile5; t += uint64_t(gridDim.x) * NW) {
+        const uint64_t sb = t * IX_TILE_BYTES;                    // first staged payload byte (16-byte aligned)
+        {
+            const uint4 *src = reinterpret_cast<const uint4 *>(p.payload + sb);
+            const uint64_t left = vec_total - (sb >> 4);
+            const uint32_t nvec = left < (IX_TILE_BYTES + 32u) / 16u ? uint32_t(left) : (IX_TILE_BYTES + 32u) / 16u;
+            for (uint32_t i = lane; i < SD_REGION / 16u; i += 64u) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (i < nvec) {
+                    v = src[i];
+                    v.x = __builtin_bswap32(__builtin_bitreverse32(v.x));
+                    v.y = __builtin_bswap32(__builtin_bitreverse32(v.y));
+                    v.z = __builtin_bswap32(__builtin_bitreverse32(v.z));
+                    v.w = __builtin_bswap32(__builtin_bitreverse32(v.w));
+                }
+                *reinterpret_cast<uint4 *>(reg + i * 16u) = v;
+            }
+        }
+        // LDS operations of one wave execute in order: the reads below see the writes above
+        uint64_t seg[K], base[K];
+        uint32_t qe0[K], q[K], ctx[K], k[K], want_e[K], want_c[K], unres[K];
+        bool active[K], last[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            seg[j] = t * IX_TILE_SEGS + uint32_t(j) * 64u + lane;
+            const uint64_t b0 = seg[j] * IX_SEG_BITS;
+            active[j] = b0 < p.nbits;
+            const uint64_t e0 = b0 + IX_SEG_BITS < p.nbits ? b0 + IX_SEG_BITS : p.nbits;
+            last[j] = active[j] && e0 == p.nbits;
+            const uint32_t qb0 = reg_bit0 + uint32_t(b0 - sb * 8u);
+            qe0[j] = active[j] ? reg_bit0 + uint32_t(e0 - sb * 8u) : qb0;          // (not active: done at once)
+            uint32_t pe = p.prev0 << 8;                          // true start state: the end state of the segment in front
+            if (active[j] && seg[j]) pe = p.e16[seg[j] - 1];
+            ctx[j] = pe >> 8;
+            q[j] = active[j] ? qb0 + (pe & 255u) : qb0;
+            want_e[j] = active[j] ? p.e16[seg[j]] : 0u;
+            want_c[j] = active[j] ? p.c16[seg[j]] : 0u;
+            k[j] = 0; unres[j] = 0;
+        }
+        // output offsets: the tile's base + the counts of the segments in front
+        bool fits = true;
+        {
+            uint64_t run = p.tile_base[t];
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                uint32_t inc = want_c[j];
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if (lane >= uint32_t(d)) inc += o; }
+                base[j] = run + (inc - want_c[j]);
+                run += __shfl(inc, 63);
+                fits = fits && base[j] + want_c[j] <= out_cap;
+            }
+        }
+        if (!__all(fits)) {                                       // the caller's buffer is too small: nothing of this tile is written
+            if (lane == 0) atomicExch(p.status, MHK_STATUS_CAPACITY);
+            continue;
+        }
+#pragma unroll 1
+        for (uint32_t r = 0; r < (IX_SEG_BITS + 63u) / 64u + 1u; ++r) {          // rounds of 64 steps (a symbol takes at least one bit)
+            uint4 Q[K][4];
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) Q[j][g] = make_uint4(0, 0, 0, 0);
+            uint32_t ug = 0;
+#pragma unroll 1
+            for (; ug < 4u; ++ug) {
+                if (!__any(q[0] < qe0[0] || q[1] < qe0[1])) break;
+                uint32_t w4[K][4];
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) {
+                    uint32_t w0[K], w1[K], win[K], e[K], e2[K];
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        const lds_u32 *wp = lds_ptr<uint32_t>((q[j] >> 3) & ~3u);
+                        w0[j] = wp[0];
+                        w1[j] = wp[1];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        win[j] = __builtin_amdgcn_alignbit(w1[j], w0[j], q[j]);
+                        e[j] = *lds_ptr<uint16_t>(((win[j] << 1) & ((2u << P) - 2u)) | (ctx[j] << (P + 1)));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        const uint32_t idx2 = (e[j] << (H + 1)) | ((win[j] >> (P - 1)) & ((2u << H) - 2u));
+                        e2[j] = uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(sec_rsrc, int(idx2), 0, 0)));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        const bool go = q[j] < qe0[j];                    // still decoding (a finished stream stands still)
+                        const uint32_t ef = e[j] > e2[j] ? e[j] : e2[j];
+                        const uint32_t len = __builtin_amdgcn_ubfe(ef, 8, 5);
+                        unres[j] |= go ? ~ef : 0u;                        // (bit 15 set: some symbol neither level resolved)
+                        ctx[j] = go ? (ef & 255u) : ctx[j];
+                        q[j] += go ? len : 0u;
+                        k[j] += go ? 1u : 0u;
+                        w4[j][jj >> 2] = (jj & 3) == 0 ? (ef & 255u) : tile_put_byte(w4[j][jj >> 2], ef, jj & 3);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    Q[j][0] = Q[j][1]; Q[j][1] = Q[j][2]; Q[j][2] = Q[j][3];
+                    Q[j][3] = make_uint4(w4[j][0], w4[j][1], w4[j][2], w4[j][3]);
+                }
+            }
+            if (ug == 0u) break;                                  // (wave-uniform: every stream of the tile has finished)
+            for (uint32_t i = ug; i < 4u; ++i) {                  // the round's first group to Q[0]
+#pragma unroll
+                for (int j = 0; j < K; ++j) { Q[j][0] = Q[j][1]; Q[j][1] = Q[j][2]; Q[j][2] = Q[j][3]; }
+            }
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                // bytes of this round that are the segment's: never past its converged count (a stream that does not belong
+                // to the table is reported below; it must not write into its neighbour's bytes)
+                const uint32_t have = k[j] < want_c[j] ? k[j] : want_c[j];
+                const uint32_t m = have > 64u * r ? (have - 64u * r < 64u ? have - 64u * r : 64u) : 0u;
+                if (m) seg_store_run(out + base[j] + 64u * r, Q[j], m);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            if (!active[j]) continue;
+            const bool done = q[j] >= qe0[j];
+            const uint32_t E = (ctx[j] << 8) | (q[j] - qe0[j]);
+            if ((unres[j] & DEC16_LEAF) || !done || E != want_e[j] || k[j] != want_c[j] || (last[j] && (E & 255u) != 0u)) atomicExch(p.status, MHK_STATUS_CORRUPT);
+        }
+    }
+}
+
+hipError_t launch_segment_decode(const IdxParams &p, uint8_t *d_out, uint64_t out_cap, hipStream_t st) {
+    if (p.tP != 7 || !p.tprim || p.order == 2 || !p.e16 || !p.c16 || !p.tile_base) return hipErrorInvalidValue;
+    void (*kern)(IdxParams, uint8_t *, uint64_t) = segment_decode_kernel<7>;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    {
+        static std::mutex mu;
+        static std::vector<std::pair<const void *, int>> done;
+        std::lock_guard<std::mutex> lock(mu);
+        const std::pair<const void *, int> key(reinterpret_cast<const void *>(kern), dev);
+        if (std::find(done.begin(), done.end(), key) == done.end()) {
+            e = hipFuncSetAttribute(key.first, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
+            if (e != hipSuccess) return e;
+            done.push_back(key);
+        }
+    }
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    const uint64_t want = (p.ntile5 + T_WAVES - 1) / T_WAVES;
+    const unsigned grid = unsigned(want < 1 ? 1 : (want > uint64_t(cus) ? uint64_t(cus) : want));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(T_THREADS), T_LDS_BYTES, st, p, d_out, out_cap);
+    return hipGetLastError();
 }
 
 hipError_t launch_index_tile(const IdxParams &p, int mode, hipStream_t st) {

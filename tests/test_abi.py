@@ -62,6 +62,7 @@ def test_host_codes_and_lut_match_oracle(mhc, oracle, name):
     assert np.array_equal(lm, lo)
     assert np.array_equal(cm, co)
     assert m.max_code_len == int(lo.max())
+    assert m.min_code_len == (int(lo[lo > 0].min()) if (lo > 0).any() else 0)      # bounds the symbols a payload can hold
     for prev in (0, 0x20, ord("e"), 255):
         for w in range(0, 256, 3):
             assert m.lut(prev, w) == o.lut(prev, w)

@@ -198,11 +198,13 @@ def test_stream_without_an_index_decodes_through_the_tile_decoder(mhc, oracle):
     blob, nbits = om.compress(data.tobytes())
     m = mhc.Model.from_table(om.table_bytes())
     os.environ["MH_DECODE_PATH"] = "tile"
-    try:
+    os.environ["MH_DECODE_NO_STREAM"] = "1"                 # (round 5: by default such a stream is decoded without any index,
+    try:                                                    #  tests/test_gpu_stream.py; this test is about the index + tile decoder way)
         out = m.decompress(blob)
     finally:
         del os.environ["MH_DECODE_PATH"]
-    assert mhc.lib().mh_last_index_path() == 5              # the index builder's fast path (tiles of 512-bit segments)
+        del os.environ["MH_DECODE_NO_STREAM"]
+    assert mhc.lib().mh_last_index_path() == 5              # the index builder's fast path (tiles of 288-bit segments)
     assert out == data.tobytes()
     # device level: the fine index the builder wrote equals the one the encoder writes
     lib = mhc.lib()
