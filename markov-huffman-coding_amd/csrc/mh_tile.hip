@@ -522,7 +522,7 @@ __global__ __launch_bounds__(T_THREADS) void index_tile_kernel(IdxParams p) {
             last[j] = active[j] && e0 == p.nbits;
             qb0[j] = reg_bit0 + uint32_t(b0 - sb * 8u);
             qe0[j] = active[j] ? reg_bit0 + uint32_t(e0 - sb * 8u) : qb0[j];       // (not active: done at once)
-            k[j] = 0; S[j] = IX_INVALID; badv[j] = 0; base[j] = 0; want_e[j] = want_c[j] = next_entry[j] = 0;
+            k[j] = 0; S[j] = IX_INVALID; badv[j] = DEC16_LEAF; base[j] = 0; want_e[j] = want_c[j] = next_entry[j] = 0;   // (badv: bit 15 stays set while every symbol resolved)
             if (MODE == 0) {
                 const bool exact = seg[j] == 0;
                 ctx[j] = exact ? p.prev0 : 0x20u;
@@ -551,11 +551,11 @@ __global__ __launch_bounds__(T_THREADS) void index_tile_kernel(IdxParams p) {
             }
         }
         uint32_t overflow = 0;
-#pragma unroll 1
-        for (uint32_t it = 0; it < IX_SEG_BITS + IX_WARM_BITS_MAX + 64u; it += 4u) {  // (a symbol takes at least one bit)
-            if (!__any(q[0] < qe0[0] || q[1] < qe0[1])) break;       // [r5] asked once per four steps: a finished stream stands still
-#pragma unroll
-          for (int sub = 0; sub < 4; ++sub) {
+        // One symbol step of both streams.  ENTERED: every stream of the wave is inside its segment (always so with true start
+        // states; in the states pass from the moment the last lane has finished its warm-up) — no "entered?" test, no entry
+        // state to catch: 22 instead of 30 vector instructions per stream step [r5].
+        auto step = [&](auto entered_c) __attribute__((always_inline)) {
+            constexpr bool ENTERED = decltype(entered_c)::value;
             if (MODE == 1) {
 #pragma unroll
                 for (int j = 0; j < K; ++j) {
@@ -593,17 +593,49 @@ __global__ __launch_bounds__(T_THREADS) void index_tile_kernel(IdxParams p) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < K; ++j) {
-                const bool in = q[j] >= qb0[j], go = q[j] < qe0[j];     // inside its segment (or past it); still decoding
-                if (MODE == 0) S[j] = (in && S[j] == IX_INVALID) ? ((ctx[j] << 8) | (q[j] - qb0[j])) : S[j];
+                const bool go = q[j] < qe0[j];                            // still decoding (a finished stream stands still)
                 const uint32_t ef = e[j] > e2[j] ? e[j] : e2[j];
-                const uint32_t len = __builtin_amdgcn_ubfe(ef, 8, 5);
-                const bool ok = (ef & DEC16_LEAF) && len != 0;            // (no: an empty context's null entry — a guess may run into one)
-                badv[j] |= (in && go && !ok) ? 1u : 0u;
-                ctx[j] = (ok && go) ? (ef & 255u) : ctx[j];
-                q[j] += go ? (ok ? len : 1u) : 0u;
-                k[j] += (in && go) ? 1u : 0u;
+                if (ENTERED) {
+                    // a finished stream "decodes" a leaf of no bits that yields its own context: no selects on position and context.
+                    // An entry that is no leaf (an empty context's null entry — a guess may run into one —, a code neither table
+                    // level resolves) clears bit 15 of the accumulator; whatever its bits then do to the stream, the segment is
+                    // marked and decoded again (states pass) or reported (entries pass), and the loop is bounded.
+                    const uint32_t efm = go ? ef : (DEC16_LEAF | ctx[j]);
+                    badv[j] &= efm;
+                    q[j] += __builtin_amdgcn_ubfe(efm, 8, 5);
+                    ctx[j] = efm & 255u;
+                    k[j] += go ? 1u : 0u;
+                } else {
+                    const bool in = q[j] >= qb0[j];                       // inside its segment (or past it)
+                    if (MODE == 0) S[j] = (in && S[j] == IX_INVALID) ? ((ctx[j] << 8) | (q[j] - qb0[j])) : S[j];
+                    const uint32_t len = __builtin_amdgcn_ubfe(ef, 8, 5);
+                    const bool ok = (ef & DEC16_LEAF) != 0u;              // (a leaf's length is at least one bit)
+                    badv[j] &= (in && go && !ok) ? 0u : ~0u;
+                    ctx[j] = (ok && go) ? (ef & 255u) : ctx[j];
+                    q[j] += go ? (ok ? len : 1u) : 0u;
+                    k[j] += (in && go) ? 1u : 0u;
+                }
             }
-          }
+        };
+        uint32_t it = 0;
+        if (MODE == 0) {
+            // the warm-up phase: until every stream of the wave has entered its segment (a stream in its warm-up moves on by at least
+            // one bit per step, so this ends within warm_bits steps; inactive streams stand at their segment's start)
+#pragma unroll 1
+            for (; it < IX_WARM_BITS_MAX + 64u; it += 4u) {
+                if (__all(q[0] >= qb0[0] && q[1] >= qb0[1])) break;
+#pragma unroll
+                for (int sub = 0; sub < 4; ++sub) step(std::false_type{});
+            }
+#pragma unroll
+            for (int j = 0; j < K; ++j)                           // a stream that entered with the phase's last step: its entry state
+                S[j] = (q[j] >= qb0[j] && S[j] == IX_INVALID) ? ((ctx[j] << 8) | (q[j] - qb0[j])) : S[j];
+        }
+#pragma unroll 1
+        for (; it < IX_SEG_BITS + IX_WARM_BITS_MAX + 64u; it += 4u) {  // (a symbol takes at least one bit)
+            if (!__any(q[0] < qe0[0] || q[1] < qe0[1])) break;       // [r5] asked once per four steps: a finished stream stands still
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub) step(std::true_type{});
         }
 #pragma unroll
         for (int j = 0; j < K; ++j) {
@@ -612,13 +644,13 @@ __global__ __launch_bounds__(T_THREADS) void index_tile_kernel(IdxParams p) {
             const uint32_t E = (ctx[j] << 8) | (q[j] - qe0[j]);
             if (MODE == 0) {
                 if (S[j] == IX_INVALID && done) S[j] = E;         // (a code that spans the whole segment: entered and left at once)
-                p.s16[seg[j]] = uint16_t(badv[j] || !done ? IX_INVALID : S[j]);
+                p.s16[seg[j]] = uint16_t(!(badv[j] & DEC16_LEAF) || !done ? IX_INVALID : S[j]);
                 p.e16[seg[j]] = uint16_t(done ? E : IX_INVALID);
                 p.c16[seg[j]] = uint16_t(k[j]);
             } else {
                 // with true start states a null entry, an end state or a count that differs from the converged ones, or a stream
                 // that does not end exactly at nbits (src/coding.cpp:124,158) means the stream does not belong to this table
-                if (badv[j] || !done || E != want_e[j] || k[j] != want_c[j] || (last[j] && (E & 255u) != 0u)) atomicExch(p.status, MHK_STATUS_CORRUPT);
+                if (!(badv[j] & DEC16_LEAF) || !done || E != want_e[j] || k[j] != want_c[j] || (last[j] && (E & 255u) != 0u)) atomicExch(p.status, MHK_STATUS_CORRUPT);
             }
         }
         if (MODE == 1 && overflow) atomicExch(p.status, MHK_STATUS_CAPACITY);
@@ -728,7 +760,7 @@ __global__ __launch_bounds__(T_THREADS) void segment_decode_kernel(IdxParams p, 
             q[j] = active[j] ? qb0 + (pe & 255u) : qb0;
             want_e[j] = active[j] ? p.e16[seg[j]] : 0u;
             want_c[j] = active[j] ? p.c16[seg[j]] : 0u;
-            k[j] = 0; unres[j] = 0;
+            k[j] = 0; unres[j] = DEC16_LEAF;
         }
         // output offsets: the tile's base + the counts of the segments in front
         bool fits = true;
@@ -784,14 +816,15 @@ __global__ __launch_bounds__(T_THREADS) void segment_decode_kernel(IdxParams p, 
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int j = 0; j < K; ++j) {
-                        const bool go = q[j] < qe0[j];                    // still decoding (a finished stream stands still)
+                        const bool go = q[j] < qe0[j];                    // still decoding
                         const uint32_t ef = e[j] > e2[j] ? e[j] : e2[j];
-                        const uint32_t len = __builtin_amdgcn_ubfe(ef, 8, 5);
-                        unres[j] |= go ? ~ef : 0u;                        // (bit 15 set: some symbol neither level resolved)
-                        ctx[j] = go ? (ef & 255u) : ctx[j];
-                        q[j] += go ? len : 0u;
+                        // a finished stream "decodes" a leaf of no bits that yields its own context (index_tile_kernel's step)
+                        const uint32_t efm = go ? ef : (DEC16_LEAF | ctx[j]);
+                        unres[j] &= efm;                                  // (bit 15 cleared: some symbol neither level resolved)
+                        q[j] += __builtin_amdgcn_ubfe(efm, 8, 5);
+                        ctx[j] = efm & 255u;
                         k[j] += go ? 1u : 0u;
-                        w4[j][jj >> 2] = (jj & 3) == 0 ? (ef & 255u) : tile_put_byte(w4[j][jj >> 2], ef, jj & 3);
+                        w4[j][jj >> 2] = (jj & 3) == 0 ? ctx[j] : tile_put_byte(w4[j][jj >> 2], efm, jj & 3);
                     }
                 }
 #pragma unroll
@@ -811,6 +844,9 @@ __global__ __launch_bounds__(T_THREADS) void segment_decode_kernel(IdxParams p, 
                 // to the table is reported below; it must not write into its neighbour's bytes)
                 const uint32_t have = k[j] < want_c[j] ? k[j] : want_c[j];
                 const uint32_t m = have > 64u * r ? (have - 64u * r < 64u ? have - 64u * r : 64u) : 0u;
+#ifdef MH_EXP_PROBES
+                if (p.iter & 1u) continue;                         // diagnostic library, MH_SEG_PROBE=1: no stores (output wrong): what the loop alone costs
+#endif
                 if (m) seg_store_run(out + base[j] + 64u * r, Q[j], m);
             }
         }
@@ -819,7 +855,7 @@ __global__ __launch_bounds__(T_THREADS) void segment_decode_kernel(IdxParams p, 
             if (!active[j]) continue;
             const bool done = q[j] >= qe0[j];
             const uint32_t E = (ctx[j] << 8) | (q[j] - qe0[j]);
-            if ((unres[j] & DEC16_LEAF) || !done || E != want_e[j] || k[j] != want_c[j] || (last[j] && (E & 255u) != 0u)) atomicExch(p.status, MHK_STATUS_CORRUPT);
+            if (!(unres[j] & DEC16_LEAF) || !done || E != want_e[j] || k[j] != want_c[j] || (last[j] && (E & 255u) != 0u)) atomicExch(p.status, MHK_STATUS_CORRUPT);
         }
     }
 }
@@ -845,6 +881,9 @@ hipError_t launch_segment_decode(const IdxParams &p, uint8_t *d_out, uint64_t ou
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     const uint64_t want = (p.ntile5 + T_WAVES - 1) / T_WAVES;
     const unsigned grid = unsigned(want < 1 ? 1 : (want > uint64_t(cus) ? uint64_t(cus) : want));
+#ifdef MH_EXP_PROBES
+    if (const char *pr = getenv("MH_SEG_PROBE")) { IdxParams pp = p; pp.iter = uint32_t(atoi(pr)); hipLaunchKernelGGL(kern, dim3(grid), dim3(T_THREADS), T_LDS_BYTES, st, pp, d_out, out_cap); return hipGetLastError(); }
+#endif
     hipLaunchKernelGGL(kern, dim3(grid), dim3(T_THREADS), T_LDS_BYTES, st, p, d_out, out_cap);
     return hipGetLastError();
 }
