@@ -187,7 +187,7 @@ def cpu_baseline(mhc, table_bytes, sample, gpu_payload_prefix_check):
 def index_free_decode(mhc, codec, model, data, nbits, prev0, reps=2):
     """The real drop-in decode: the reference's `.cm` carries no index (src/coding.cpp:35-59), so the
     payload the bench just wrote is decoded again with NO index handed in.  [r5] Two passes over the payload:
-    mh_dev_decode_stream_states (every 288-bit segment's entry state and symbol count) and mh_dev_decode_stream_emit (the
+    mh_dev_decode_stream_states (every 352-bit segment's entry state and symbol count) and mh_dev_decode_stream_emit (the
     segment decoder writes the bytes) — no index is built.  `via_index` = the round-4 way beside it (mh_dev_build_index_fine
     rebuilds chunk index and fine index, mh_dev_decode_fine decodes from them: three passes).  Outside the timed loop, like
     cpu_baseline; HIP events on the launch stream.  (The states pass waits for the device between its sub-passes.)"""

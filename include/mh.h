@@ -413,7 +413,7 @@ int mh_dev_build_index_fine(const mh_model *m, const uint8_t *d_payload, uint64_
  * STREAMS WITHOUT AN INDEX IN TWO PASSES OVER THE PAYLOAD (round 5) — what i_coding_provider::decompress is handed
  * (src/coding.cpp:96-160: a `.cm` carries nothing but the header byte and the bits).  Building both indices and then decoding
  * reads the payload three times; these two calls read it twice and write no index at all:
- *   mh_dev_decode_stream_states  pass 1: the payload is cut into 288-bit segments, every segment is decoded from a guessed
+ *   mh_dev_decode_stream_states  pass 1: the payload is cut into 352-bit segments, every segment is decoded from a guessed
  *       state after a short warm-up, the segments whose guess was wrong are decoded again from their predecessor's end state
  *       until none is left (the fixed point of mh_dev_build_index), a prefix sum of the segments' symbol counts gives every
  *       segment its output offset; *d_n_symbols = the decoded size.  Synchronises `stream` between its passes.

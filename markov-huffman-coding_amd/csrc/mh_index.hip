@@ -474,12 +474,13 @@ static hipError_t index_tile_states(const IdxParams &p, const IdxWs &L, unsigned
     if (const char *wv = getenv("MH_INDEX_WARM_BITS")) { const int v = atoi(wv); if (v >= 16 && v <= int(IX_WARM_BITS_MAX)) q.warm_bits = uint32_t(v); }
     else if (q.ntile5 >= 16384) {
         // how long a warm-up this stream needs is a property of the source: a sample (the first 1/256 of the tiles, one tile
-        // per wave of the card at least) with 128 bits tells — where that leaves under 2 % of the segments to repair the
-        // short warm-up serves the whole stream (the pass decodes warm-up + segment: 1.44 instead of 1.89 segment lengths)
+        // per wave of the card at least) with 96 bits tells — under 2.5 % of the segments to repair: 96 bits serve the whole
+        // stream (the pass decodes warm-up + segment); under 10 %: 128; else the default 256 (text, whose decode depends on the
+        // context at every step).  [r5] 4 GiB of Zipf(1.1), ms per states pass: 64 bits 8.4 (5 % to repair), 96 7.95, 128 8.1, 256 9.4
         IdxParams sq = q;
         sq.ntile5 = q.ntile5 / 256 > 4096 ? q.ntile5 / 256 : 4096;
         sq.nseg5 = sq.ntile5 * IX_TILE_SEGS;
-        sq.warm_bits = 128;
+        sq.warm_bits = 96;
         sq.iter = it;
         e = launch_index_tile(sq, 0, st);
         if (e != hipSuccess) return e;
@@ -489,7 +490,8 @@ static hipError_t index_tile_states(const IdxParams &p, const IdxWs &L, unsigned
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) return e;
         ++it;
-        if (uint64_t(dirty) * 50u < sq.nseg5) q.warm_bits = 128;
+        if (uint64_t(dirty) * 40u < sq.nseg5) q.warm_bits = 96;
+        else if (uint64_t(dirty) * 10u < sq.nseg5) q.warm_bits = 128;
     }
     for (int attempt = 0; attempt < 2 && !ok; ++attempt) {
         e = launch_index_tile(q, 0, st);

@@ -181,11 +181,17 @@ struct IdxParams {
     uint32_t dirty_cap;
     uint32_t iter;                // the pass counter (changed[iter]) the listed segments are counted in
 };
-// segments of the fast index path: 288 bits each, 128 of them (two per lane) a tile = 4.5 KiB of payload; a lane that does
-// not know its start state warms up over the bits in front of its segment (IdxParams::warm_bits).  288 bits = NINE dwords:
-// the lanes of a wave stand at about the same offset in their segments, and with a stride of eight dwords (256 bits) their
-// window reads met on 4 of the 32 LDS banks (measured: 81 % of the LDS cycles were bank conflicts, the LDS 72 % busy).
-constexpr uint32_t IX_SEG_BITS = 288, IX_TILE_SEGS = 128, IX_TILE_BITS = IX_TILE_SEGS * IX_SEG_BITS, IX_WARM_BITS_MAX = 512;
+// segments of the fast index path / of the segment decoder: 128 of them (two per lane) make a wave's tile; a lane that does not
+// know its start state warms up over the bits in front of its segment (IdxParams::warm_bits).  A segment is an ODD number of
+// dwords: the lanes of a wave stand at about the same offset in their segments, and with a stride of eight dwords (256 bits)
+// their window reads met on 4 of the 32 LDS banks (measured: 81 % of the LDS cycles were bank conflicts, the LDS 72 % busy).
+// [r5] eleven dwords (352 bits, 5.5 KiB per tile: sixteen waves' tiles still fit beside the 64 KiB first level) instead of
+// nine: a states pass decodes warm-up + segment, and the longer segment spreads the warm-up over more symbols.
+#ifndef MH_IX_SEG_DWORDS
+#define MH_IX_SEG_DWORDS 11
+#endif
+static_assert(MH_IX_SEG_DWORDS % 2 == 1 && MH_IX_SEG_DWORDS >= 5 && MH_IX_SEG_DWORDS <= 11, "an odd number of dwords; sixteen tiles must fit 96 KiB");
+constexpr uint32_t IX_SEG_BITS = 32u * MH_IX_SEG_DWORDS, IX_TILE_SEGS = 128, IX_TILE_BITS = IX_TILE_SEGS * IX_SEG_BITS, IX_WARM_BITS_MAX = 512;
 constexpr uint16_t IX_INVALID = 0xFFFF;
 hipError_t launch_index_tile(const IdxParams &p, int mode, hipStream_t st);   // mode 0: states and counts, 1: the index entries
 // [r5] the segment decoder: the second pass over a stream without an index emits the bytes itself (e16 / c16 / tile_base set)

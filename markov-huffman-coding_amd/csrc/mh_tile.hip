@@ -673,32 +673,37 @@ typedef uint32_t u32x2_unaligned __attribute__((ext_vector_type(2), aligned(1)))
 typedef uint32_t u32_unaligned __attribute__((aligned(1)));
 typedef uint16_t u16_unaligned __attribute__((aligned(1)));
 
-// m <= 64 bytes of a lane's round (Qk[g] = bytes 16 g ..) to d, any alignment: whole 16-byte groups, then 8 / 4 / 2 / 1
-__device__ __forceinline__ void seg_store_run(uint8_t *d, const uint4 (&Qk)[4], uint32_t m) {
+// A round = SD_GROUPS groups of 16 steps: the symbols of a round stay in registers (byte j of the round = step j in every lane)
+constexpr int SD_GROUPS = 5;
+constexpr uint32_t SD_ROUND = 16u * SD_GROUPS;
+// m <= SD_ROUND bytes of a lane's round (Qk[g] = bytes 16 g ..) to d, any alignment: whole 16-byte groups, then 8 / 4 / 2 / 1
+__device__ __forceinline__ void seg_store_run(uint8_t *d, const uint4 (&Qk)[SD_GROUPS], uint32_t m) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int g = 0; g < SD_GROUPS; ++g)
         if (m >= 16u * uint32_t(g + 1)) *reinterpret_cast<u32x4_unaligned *>(d + 16 * g) = u32x4_unaligned{Qk[g].x, Qk[g].y, Qk[g].z, Qk[g].w};
     const uint32_t gt = m >> 4, t = m & 15u;
-    if (gt >= 4u || t == 0u) return;
+    if (gt >= uint32_t(SD_GROUPS) || t == 0u) return;
     // the group the run ends in, by selects on plain values (a select between array ELEMENTS is turned into an indexed load,
     // and the whole array then lives in scratch memory)
-    uint32_t c[4][4];
+    uint32_t c[SD_GROUPS][4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    for (int g = 0; g < SD_GROUPS; ++g) {
         c[g][0] = Qk[g].x; c[g][1] = Qk[g].y; c[g][2] = Qk[g].z; c[g][3] = Qk[g].w;
 #pragma unroll
         for (int i = 0; i < 4; ++i) asm("" : "+v"(c[g][i]));
     }
-    uint4 T;
-    T.x = gt == 0u ? c[0][0] : gt == 1u ? c[1][0] : gt == 2u ? c[2][0] : c[3][0];
-    T.y = gt == 0u ? c[0][1] : gt == 1u ? c[1][1] : gt == 2u ? c[2][1] : c[3][1];
-    T.z = gt == 0u ? c[0][2] : gt == 1u ? c[1][2] : gt == 2u ? c[2][2] : c[3][2];
-    T.w = gt == 0u ? c[0][3] : gt == 1u ? c[1][3] : gt == 2u ? c[2][3] : c[3][3];
+    uint32_t T[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        T[i] = c[SD_GROUPS - 1][i];
+#pragma unroll
+        for (int g = SD_GROUPS - 2; g >= 0; --g) T[i] = gt == uint32_t(g) ? c[g][i] : T[i];
+    }
     uint8_t *dt = d + 16u * gt;
-    if (t & 8u) { *reinterpret_cast<u32x2_unaligned *>(dt) = u32x2_unaligned{T.x, T.y}; T.x = T.z; T.y = T.w; dt += 8; }
-    if (t & 4u) { *reinterpret_cast<u32_unaligned *>(dt) = T.x; T.x = T.y; dt += 4; }
-    if (t & 2u) { *reinterpret_cast<u16_unaligned *>(dt) = uint16_t(T.x); T.x >>= 16; dt += 2; }
-    if (t & 1u) *dt = uint8_t(T.x);
+    if (t & 8u) { *reinterpret_cast<u32x2_unaligned *>(dt) = u32x2_unaligned{T[0], T[1]}; T[0] = T[2]; T[1] = T[3]; dt += 8; }
+    if (t & 4u) { *reinterpret_cast<u32_unaligned *>(dt) = T[0]; T[0] = T[1]; dt += 4; }
+    if (t & 2u) { *reinterpret_cast<u16_unaligned *>(dt) = uint16_t(T[0]); T[0] >>= 16; dt += 2; }
+    if (t & 1u) *dt = uint8_t(T[0]);
 }
 
 template <int PC>
@@ -781,73 +786,83 @@ __global__ __launch_bounds__(T_THREADS) void segment_decode_kernel(IdxParams p, 
             continue;
         }
 #pragma unroll 1
-        for (uint32_t r = 0; r < (IX_SEG_BITS + 63u) / 64u + 1u; ++r) {          // rounds of 64 steps (a symbol takes at least one bit)
-            uint4 Q[K][4];
+        for (uint32_t r = 0; r < (IX_SEG_BITS + SD_ROUND - 1u) / SD_ROUND + 1u; ++r) {   // rounds of SD_ROUND steps (a symbol takes at least one bit)
+            uint4 Q[K][SD_GROUPS];
 #pragma unroll
             for (int j = 0; j < K; ++j)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) Q[j][g] = make_uint4(0, 0, 0, 0);
+                for (int g = 0; g < SD_GROUPS; ++g) Q[j][g] = make_uint4(0, 0, 0, 0);
             uint32_t ug = 0;
 #pragma unroll 1
-            for (; ug < 4u; ++ug) {
+            for (; ug < uint32_t(SD_GROUPS); ++ug) {
                 if (!__any(q[0] < qe0[0] || q[1] < qe0[1])) break;
                 uint32_t w4[K][4];
+                auto steps8 = [&](auto half_c) __attribute__((always_inline)) {
+                    constexpr int J0 = decltype(half_c)::value * 8;
 #pragma unroll
-                for (int jj = 0; jj < 16; ++jj) {
-                    uint32_t w0[K], w1[K], win[K], e[K], e2[K];
+                    for (int jj = J0; jj < J0 + 8; ++jj) {
+                        uint32_t w0[K], w1[K], win[K], e[K], e2[K];
 #pragma unroll
-                    for (int j = 0; j < K; ++j) {
-                        const lds_u32 *wp = lds_ptr<uint32_t>((q[j] >> 3) & ~3u);
-                        w0[j] = wp[0];
-                        w1[j] = wp[1];
+                        for (int j = 0; j < K; ++j) {
+                            const lds_u32 *wp = lds_ptr<uint32_t>((q[j] >> 3) & ~3u);
+                            w0[j] = wp[0];
+                            w1[j] = wp[1];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int j = 0; j < K; ++j) {
+                            win[j] = __builtin_amdgcn_alignbit(w1[j], w0[j], q[j]);
+                            e[j] = *lds_ptr<uint16_t>(((win[j] << 1) & ((2u << P) - 2u)) | (ctx[j] << (P + 1)));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int j = 0; j < K; ++j) {
+                            const uint32_t idx2 = (e[j] << (H + 1)) | ((win[j] >> (P - 1)) & ((2u << H) - 2u));
+                            e2[j] = uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(sec_rsrc, int(idx2), 0, 0)));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int j = 0; j < K; ++j) {
+                            const bool go = q[j] < qe0[j];                    // still decoding
+                            const uint32_t ef = e[j] > e2[j] ? e[j] : e2[j];
+                            // a finished stream "decodes" a leaf of no bits that yields its own context (index_tile_kernel's step)
+                            const uint32_t efm = go ? ef : (DEC16_LEAF | ctx[j]);
+                            unres[j] &= efm;                                  // (bit 15 cleared: some symbol neither level resolved)
+                            q[j] += __builtin_amdgcn_ubfe(efm, 8, 5);
+                            ctx[j] = efm & 255u;
+                            k[j] += go ? 1u : 0u;
+                            w4[j][jj >> 2] = (jj & 3) == 0 ? ctx[j] : tile_put_byte(w4[j][jj >> 2], efm, jj & 3);
+                        }
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                };
+                steps8(std::integral_constant<int, 0>{});
 #pragma unroll
-                    for (int j = 0; j < K; ++j) {
-                        win[j] = __builtin_amdgcn_alignbit(w1[j], w0[j], q[j]);
-                        e[j] = *lds_ptr<uint16_t>(((win[j] << 1) & ((2u << P) - 2u)) | (ctx[j] << (P + 1)));
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int j = 0; j < K; ++j) {
-                        const uint32_t idx2 = (e[j] << (H + 1)) | ((win[j] >> (P - 1)) & ((2u << H) - 2u));
-                        e2[j] = uint32_t(uint16_t(__builtin_amdgcn_raw_buffer_load_b16(sec_rsrc, int(idx2), 0, 0)));
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int j = 0; j < K; ++j) {
-                        const bool go = q[j] < qe0[j];                    // still decoding
-                        const uint32_t ef = e[j] > e2[j] ? e[j] : e2[j];
-                        // a finished stream "decodes" a leaf of no bits that yields its own context (index_tile_kernel's step)
-                        const uint32_t efm = go ? ef : (DEC16_LEAF | ctx[j]);
-                        unres[j] &= efm;                                  // (bit 15 cleared: some symbol neither level resolved)
-                        q[j] += __builtin_amdgcn_ubfe(efm, 8, 5);
-                        ctx[j] = efm & 255u;
-                        k[j] += go ? 1u : 0u;
-                        w4[j][jj >> 2] = (jj & 3) == 0 ? ctx[j] : tile_put_byte(w4[j][jj >> 2], efm, jj & 3);
-                    }
-                }
+                for (int j = 0; j < K; ++j) { w4[j][2] = 0; w4[j][3] = 0; }
+                if (__any(q[0] < qe0[0] || q[1] < qe0[1])) steps8(std::integral_constant<int, 1>{});   // (asked per eight steps: the slowest lane sets the pace)
 #pragma unroll
                 for (int j = 0; j < K; ++j) {
-                    Q[j][0] = Q[j][1]; Q[j][1] = Q[j][2]; Q[j][2] = Q[j][3];
-                    Q[j][3] = make_uint4(w4[j][0], w4[j][1], w4[j][2], w4[j][3]);
+#pragma unroll
+                    for (int g = 0; g + 1 < SD_GROUPS; ++g) Q[j][g] = Q[j][g + 1];
+                    Q[j][SD_GROUPS - 1] = make_uint4(w4[j][0], w4[j][1], w4[j][2], w4[j][3]);
                 }
             }
             if (ug == 0u) break;                                  // (wave-uniform: every stream of the tile has finished)
-            for (uint32_t i = ug; i < 4u; ++i) {                  // the round's first group to Q[0]
+            for (uint32_t i = ug; i < uint32_t(SD_GROUPS); ++i) { // the round's first group to Q[0]
 #pragma unroll
-                for (int j = 0; j < K; ++j) { Q[j][0] = Q[j][1]; Q[j][1] = Q[j][2]; Q[j][2] = Q[j][3]; }
+                for (int j = 0; j < K; ++j)
+#pragma unroll
+                    for (int g = 0; g + 1 < SD_GROUPS; ++g) Q[j][g] = Q[j][g + 1];
             }
 #pragma unroll
             for (int j = 0; j < K; ++j) {
                 // bytes of this round that are the segment's: never past its converged count (a stream that does not belong
                 // to the table is reported below; it must not write into its neighbour's bytes)
                 const uint32_t have = k[j] < want_c[j] ? k[j] : want_c[j];
-                const uint32_t m = have > 64u * r ? (have - 64u * r < 64u ? have - 64u * r : 64u) : 0u;
+                const uint32_t m = have > SD_ROUND * r ? (have - SD_ROUND * r < SD_ROUND ? have - SD_ROUND * r : SD_ROUND) : 0u;
 #ifdef MH_EXP_PROBES
                 if (p.iter & 1u) continue;                         // diagnostic library, MH_SEG_PROBE=1: no stores (output wrong): what the loop alone costs
 #endif
-                if (m) seg_store_run(out + base[j] + 64u * r, Q[j], m);
+                if (m) seg_store_run(out + base[j] + SD_ROUND * r, Q[j], m);
             }
         }
 #pragma unroll

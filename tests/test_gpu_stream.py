@@ -1,6 +1,6 @@
 """Streams without an index in TWO passes over the payload (round 5; mh_dev_decode_stream_states + mh_dev_decode_stream_emit,
 csrc/mh_tile.hip segment_decode_kernel).  What the reference writes carries no index (src/coding.cpp:35-59) and is decoded by
-i_coding_provider::decompress bit by bit (src/coding.cpp:96-160); here the first pass finds every 288-bit segment's entry state
+i_coding_provider::decompress bit by bit (src/coding.cpp:96-160); here the first pass finds every 352-bit segment's entry state
 and symbol count, the second decodes the segments again and writes the bytes.  Streams and tables come from the oracle (= the
 reference's files); which way a stream went is asserted by path code (6 = states + segment decoder, 0 = not taken), never by
 the clock."""
@@ -84,16 +84,16 @@ def test_two_passes_give_the_input_back(mhc, oracle, kind, n):
 
 
 def test_segments_of_many_symbols_take_several_rounds(mhc, oracle):
-    """A source of mostly 1- and 2-bit codes: 150 to 288 symbols per 288-bit segment, i.e. up to five rounds of 64 steps per
+    """A source of mostly 1- and 2-bit codes: 180 to 352 symbols per 352-bit segment, i.e. up to five rounds of 80 steps per
     lane, the lanes of a wave finishing in different rounds."""
     rng = np.random.default_rng(11)
     n = 9 << 20
     data = rng.choice(6, size=n, p=[0.80, 0.08, 0.05, 0.04, 0.02, 0.01]).astype(np.uint8)
     data[rng.integers(0, n, 4000)] = rng.integers(6, 200, 4000).astype(np.uint8)       # a few long codes in between
-    data[1 << 20:(1 << 20) + 70000] = 0                                                # a run: 288 symbols in every segment
+    data[1 << 20:(1 << 20) + 70000] = 0                                                # a run: 352 symbols in every segment
     om = oracle.Model.from_data(data.tobytes(), 1)
     blob, nbits = om.compress(data.tobytes())
-    assert n / (nbits / 288.0) > 150
+    assert n / (nbits / 352.0) > 180
     m = mhc.Model.from_table(om.table_bytes())
     st1, path, ns, st2, out = stream_decode(mhc, m, blob[1:], nbits)
     if path != PATH_STATES:                                       # (a model whose codes the tile tables do not resolve)
