@@ -706,8 +706,7 @@ __device__ __forceinline__ void seg_store_run(uint8_t *d, const uint4 (&Qk)[SD_G
     if (t & 1u) *dt = uint8_t(T[0]);
 }
 
-// SD_DIRECT_ONLY (A/B, diagnostic library: MH_SEG_DIRECT=1): every run leaves by seg_store_run, as in the first version
-template <int PC, bool SD_DIRECT_ONLY = false>
+template <int PC>
 __global__ __launch_bounds__(T_THREADS) void segment_decode_kernel(IdxParams p, uint8_t *out, uint64_t out_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr uint32_t P = PC, PRIM_BYTES = (256u << P) * 2u;
@@ -762,7 +761,7 @@ __global__ __launch_bounds__(T_THREADS) void segment_decode_kernel(IdxParams p, 
             qe0[j] = active[j] ? reg_bit0 + uint32_t(e0 - sb * 8u) : qb0;          // (not active: done at once)
             uint32_t pe = p.prev0 << 8;                          // true start state: the end state of the segment in front
             if (active[j] && seg[j]) pe = p.e16[seg[j] - 1];
-            ctx[j] = (pe >> 8) << (P + 1);                        // the context where the first-level address wants it
+            ctx[j] = pe >> 8;
             q[j] = active[j] ? qb0 + (pe & 255u) : qb0;
             want_e[j] = active[j] ? p.e16[seg[j]] : 0u;
             want_c[j] = active[j] ? p.c16[seg[j]] : 0u;
@@ -813,7 +812,7 @@ __global__ __launch_bounds__(T_THREADS) void segment_decode_kernel(IdxParams p, 
 #pragma unroll
                         for (int j = 0; j < K; ++j) {
                             win[j] = __builtin_amdgcn_alignbit(w1[j], w0[j], q[j]);
-                            e[j] = *lds_ptr<uint16_t>(((win[j] << 1) & ((2u << P) - 2u)) | ctx[j]);
+                            e[j] = *lds_ptr<uint16_t>(((win[j] << 1) & ((2u << P) - 2u)) | (ctx[j] << (P + 1)));
                         }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -826,15 +825,13 @@ __global__ __launch_bounds__(T_THREADS) void segment_decode_kernel(IdxParams p, 
                         for (int j = 0; j < K; ++j) {
                             const bool go = q[j] < qe0[j];                    // still decoding
                             const uint32_t ef = e[j] > e2[j] ? e[j] : e2[j];
-                            // a finished stream "decodes" a leaf of no bits and symbol 0 and keeps its context: its position stands
-                            // still and the bytes it leaves in the round's registers are zero (the LDS output path ORs them in)
-                            const uint32_t efm = go ? ef : uint32_t(DEC16_LEAF);
+                            // a finished stream "decodes" a leaf of no bits that yields its own context (index_tile_kernel's step)
+                            const uint32_t efm = go ? ef : (DEC16_LEAF | ctx[j]);
                             unres[j] &= efm;                                  // (bit 15 cleared: some symbol neither level resolved)
                             q[j] += __builtin_amdgcn_ubfe(efm, 8, 5);
-                            const uint32_t csh = P == 7 ? __builtin_amdgcn_perm(0u, ef, 0x0C0C000Cu) : (ef & 255u) << (P + 1);   // byte 0 -> byte 1
-                            ctx[j] = go ? csh : ctx[j];
+                            ctx[j] = efm & 255u;
                             k[j] += go ? 1u : 0u;
-                            w4[j][jj >> 2] = (jj & 3) == 0 ? (efm & 255u) : tile_put_byte(w4[j][jj >> 2], efm, jj & 3);
+                            w4[j][jj >> 2] = (jj & 3) == 0 ? ctx[j] : tile_put_byte(w4[j][jj >> 2], efm, jj & 3);
                         }
                     }
                 };
@@ -850,61 +847,11 @@ __global__ __launch_bounds__(T_THREADS) void segment_decode_kernel(IdxParams p, 
                 }
             }
             if (ug == 0u) break;                                  // (wave-uniform: every stream of the tile has finished)
-            for (uint32_t i = ug; i < uint32_t(SD_GROUPS); ++i) { // the round's first group to Q[0], zero groups behind the last one
+            for (uint32_t i = ug; i < uint32_t(SD_GROUPS); ++i) { // the round's first group to Q[0]
 #pragma unroll
-                for (int j = 0; j < K; ++j) {
+                for (int j = 0; j < K; ++j)
 #pragma unroll
                     for (int g = 0; g + 1 < SD_GROUPS; ++g) Q[j][g] = Q[j][g + 1];
-                    Q[j][SD_GROUPS - 1] = make_uint4(0, 0, 0, 0);
-                }
-            }
-            // ---- [r5] a tile that is through after its first round — every lane's whole run sits in registers and the staged piece
-            // is used up — leaves through the wave's LDS region: per stream, the 64 runs are OR-ed into a zeroed buffer at their
-            // byte offsets (a lane's string shifted to the dword grid: one v_alignbyte and one ds_or per dword; bytes behind a run's
-            // end are zero, see the step) and the buffer goes out as aligned 16-byte vectors, 1 KiB per store instruction.  Unaligned
-            // 16-byte stores per lane (seg_store_run) cost a fifth of the kernel: the memory pipe splits each into dword pieces.
-            if (r == 0u && !__any(q[0] < qe0[0] || q[1] < qe0[1]) && !SD_DIRECT_ONLY) {
-                bool handled = true;
-                const uint32_t rb = reg_bit0 >> 3;                // LDS byte address of the wave's region (16-byte aligned)
-#pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    const uint64_t G0 = __shfl(base[j], 0);       // the stream's run: bytes [G0, G0 + T) of the output
-                    const uint32_t o = uint32_t(base[j] - G0);
-                    const uint32_t T = uint32_t(__shfl(o + want_c[j], 63));
-                    if (T > 64u * SD_ROUND || __any(k[j] != want_c[j])) { handled = false; break; }   // (wave-uniform; a stream that does not belong to the table)
-                    const uint32_t ga = uint32_t(reinterpret_cast<uintptr_t>(out) + G0) & 15u;
-                    const uint32_t nv = (ga + T + 15u) >> 4;      // 16-byte vectors of the output the run touches
-                    if (j == 0)                                    // (stream 1 finds the buffer cleared by stream 0's flush)
-                        for (uint32_t i = lane; i < SD_REGION / 16u; i += 64u) *lds_wptr<u32x4>(rb + 16u * i) = u32x4{0u, 0u, 0u, 0u};
-                    // the lane's run to LDS bytes [a, a + m): dword i of the shifted string holds bytes [4 i - sh, 4 i - sh + 4)
-                    const uint32_t a = rb + 16u + ga + o, sh = (a & 3u) ? (a & 3u) : 4u, adw = a - sh;
-                    const uint32_t lim = sh + want_c[j];          // bytes of the shifted string in use
-                    uint32_t R[4 * SD_GROUPS + 2];
-                    R[0] = 0u; R[4 * SD_GROUPS + 1] = 0u;
-#pragma unroll
-                    for (int g = 0; g < SD_GROUPS; ++g) { R[4 * g + 1] = Q[j][g].x; R[4 * g + 2] = Q[j][g].y; R[4 * g + 3] = Q[j][g].z; R[4 * g + 4] = Q[j][g].w; }
-#pragma unroll
-                    for (int i = 0; i <= 4 * SD_GROUPS; ++i) {
-                        if (i >= 8 && !__any(lim > 4u * uint32_t(i))) break;          // (wave-uniform) nobody's run reaches this far
-                        const uint32_t d = __builtin_amdgcn_alignbyte(R[i + 1], R[i], 4u - sh);   // (sh = 4: shift 0 = R[i])
-                        __hip_atomic_fetch_or(lds_wptr<uint32_t>(adw + 4u * uint32_t(i)), d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                    // out: the (at most two) vectors the run shares with its neighbours byte by byte — lanes 0..15 the bytes of the
-                    // first vector, lanes 16..31 those of the last: one LDS read and one store instruction —, whole vectors aligned
-                    uint8_t *gv = out + G0 - ga;
-                    const uint32_t endb = ga + T;
-                    {
-                        const uint32_t x = lane < 16u ? lane : 16u * (nv - 1u) + (lane - 16u);
-                        const bool part = lane < 16u ? (ga != 0u || endb < 16u) : (lane < 32u && nv > 1u && (endb & 15u) != 0u);
-                        if (part && x >= ga && x < endb) gv[x] = *lds_ptr<uint8_t>(rb + 16u + x);
-                    }
-                    for (uint32_t i = lane; i < nv; i += 64u) {
-                        const u32x4 v = *lds_ptr<u32x4>(rb + 16u + 16u * i);
-                        if (j + 1 < K) *lds_wptr<u32x4>(rb + 16u + 16u * i) = u32x4{0u, 0u, 0u, 0u};
-                        if (16u * i >= ga && 16u * i + 16u <= endb) *reinterpret_cast<uint4 *>(gv + 16u * i) = make_uint4(v.x, v.y, v.z, v.w);
-                    }
-                }
-                if (handled) continue;                            // (else: the direct stores below, which clip a run to its converged count)
             }
 #pragma unroll
             for (int j = 0; j < K; ++j) {
@@ -922,7 +869,7 @@ __global__ __launch_bounds__(T_THREADS) void segment_decode_kernel(IdxParams p, 
         for (int j = 0; j < K; ++j) {
             if (!active[j]) continue;
             const bool done = q[j] >= qe0[j];
-            const uint32_t E = ((ctx[j] >> (P + 1)) << 8) | (q[j] - qe0[j]);
+            const uint32_t E = (ctx[j] << 8) | (q[j] - qe0[j]);
             if (!(unres[j] & DEC16_LEAF) || !done || E != want_e[j] || k[j] != want_c[j] || (last[j] && (E & 255u) != 0u)) atomicExch(p.status, MHK_STATUS_CORRUPT);
         }
     }
@@ -931,9 +878,6 @@ __global__ __launch_bounds__(T_THREADS) void segment_decode_kernel(IdxParams p, 
 hipError_t launch_segment_decode(const IdxParams &p, uint8_t *d_out, uint64_t out_cap, hipStream_t st) {
     if (p.tP != 7 || !p.tprim || p.order == 2 || !p.e16 || !p.c16 || !p.tile_base) return hipErrorInvalidValue;
     void (*kern)(IdxParams, uint8_t *, uint64_t) = segment_decode_kernel<7>;
-#ifdef MH_EXP_PROBES
-    if (getenv("MH_SEG_DIRECT")) kern = segment_decode_kernel<7, true>;
-#endif
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
