@@ -958,7 +958,26 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
     if (v0 >= v1) return;                        // empty region (uniform for the workgroup)
     uint32_t *out32 = reinterpret_cast<uint32_t *>(p.out);
     const uint32_t S = 1u << p.chunk_shift;
-    const uint64_t rounds = (v1 - v0 + E_THREADS - 1) / E_THREADS;
+    // [r5] vectors per round, a choice of the region (workgroup-uniform).  A round of all 1024 lanes is 16 KiB of input; at 8 bits
+    // per symbol that is 131 072 bits, 768 more than half the image holds (R_HALF_CAP_BITS), so uniform bytes — BASELINE config 4
+    // — kept both barriers of every round.  A region whose mean round does not fit a half with 1024 lanes runs its rounds with
+    // the first 1008, 992 or 960 lanes (the largest count whose mean round fits with half a per cent to spare: 129 024 bits at 8
+    // bits per symbol); the other lanes of the last wave idle (zero-length entries, no index entries).  Multiples of 4: a fine
+    // index entry belongs to every fourth vector, which must stay every fourth lane.
+    uint32_t RS = E_THREADS;
+    if (!ESCK) {
+        const uint64_t nsym = (v1 * E_VEC < p.n ? v1 * E_VEC : p.n) - v0 * E_VEC;
+        const uint64_t bits = rp.region_bits[blockIdx.x];
+        const uint32_t cand[4] = {1024u, 1008u, 992u, 960u};
+        uint32_t pick = 0;
+#pragma unroll
+        for (int c = 3; c >= 0; --c)                              // bits / nsym * (cand * 16) * 1.005 <= cap - 32
+            if (bits * cand[c] * E_VEC * 201u <= uint64_t(R_HALF_CAP_BITS - 32u) * nsym * 200u) pick = cand[c];
+        if (pick) RS = pick;                                      // (none fits: more than ~8.4 bits per symbol; two barriers, all lanes)
+    }
+    const bool act = tid < RS;                                    // this lane takes a vector of every round
+    const bool wave_idles = uint32_t(wave) * 64u + 63u >= RS;     // (wave-uniform) some lane of this wave does not
+    const uint64_t rounds = (v1 - v0 + RS - 1) / RS;
     const uint64_t s0 = rp.region_start[blockIdx.x];
     uint64_t gbase = s0 >> 5, abs_round = s0;
     uint32_t cur = uint32_t(s0 & 31u);
@@ -968,10 +987,19 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
     // barrier: no thread ever reads a word that another thread's clear may touch in the same phase.
     uint32_t carry = 0;
     bool prev_half = false;                      // the previous round used a half of the image (see round())
+#ifndef MH_ENC_DEFER_FLUSH
+#define MH_ENC_DEFER_FLUSH 1
+#endif
+    constexpr bool DEFER = MH_ENC_DEFER_FLUSH != 0;
+    bool pend = false;                           // a half round's flush that has not been issued yet: its image, base, seam, full words
+    uint32_t *pend_img = nullptr;
+    uint64_t pend_gbase = 0;
+    bool pend_seam = false;
+    uint32_t pend_nfull = 0;
 
     auto fetch = [&](uint64_t r) -> LaneIn {
-        const uint64_t v = v0 + r * E_THREADS + tid;
-        LaneIn in = load_raw(p.data, p.n, v < v1 ? v * E_VEC : ~0ull >> 1, p.prev0);   // beyond the region: nothing
+        const uint64_t v = v0 + r * RS + tid;
+        LaneIn in = load_raw(p.data, p.n, (act && v < v1) ? v * E_VEC : ~0ull >> 1, p.prev0);   // beyond the region, an idle lane: nothing
         return in;
     };
     auto lookup16 = [&](const LaneIn &in, uint32_t pb, uint32_t (&e)[16]) {
@@ -984,7 +1012,7 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
     // clears them; four words per lane: one 16-byte LDS read, one 16-byte clear, one 16-byte store.  The group
     // that holds word nfull (the partial tail) is visited too: its reader returns that word.
     uint32_t *imgr = img;                        // the image of the round at hand: the whole one, or one of its halves
-    auto flush = [&](uint32_t nfull) -> uint32_t {
+    auto flush = [&](uint32_t *imgr, uint64_t gbase, bool seam_first, uint32_t nfull) -> uint32_t {   // (the round's own image, base and seam)
         uint32_t tail = 0;
         for (uint32_t j = tid * 4u; j <= nfull; j += E_THREADS * 4u) {
             const uint4 w = *reinterpret_cast<const uint4 *>(imgr + j);
@@ -1032,6 +1060,10 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
         uint32_t e[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) e[j] = (FULL || uint32_t(j) < in.nvalid) ? E[j] : 0u;   // the stream's ragged last vector, lanes past the region's end
+        if (FULL && wave_idles) {                                 // (wave-uniform: the last wave of a region with fewer than 1024 lanes per round)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) e[j] = act ? e[j] : 0u;
+        }
         P.L = 0;
         uint32_t emax = 0;
 #pragma unroll
@@ -1060,9 +1092,9 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
     };
     auto fetch_full = [&](uint64_t r) -> LaneIn {                // round r is whole: no bounds checks
         LaneIn in;
-        const uint64_t v = v0 + r * E_THREADS + tid;
+        const uint64_t v = v0 + r * RS + tid;                     // (an idle lane reads a vector of the next round: inside the stream, unused)
         in.x = reinterpret_cast<const uint4 *>(p.data)[v];
-        in.nvalid = E_VEC;
+        in.nvalid = act ? uint32_t(E_VEC) : 0u;                   // (the last rounds of a region run with bounds checks on vectors loaded here)
         in.head = p.prev0;
         if (lane == 0 && v) in.head = uint32_t(p.data[v * E_VEC - 1]);
         return in;
@@ -1107,13 +1139,16 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
         // (workgroup-uniform: cur and tot are) this round in a half of its own?  If the previous one was not, its flush of the
         // whole image may still be running: the barrier above was taken (prev_half false) and the halves are free again.
         const bool half = !ESC && cur + tot <= R_HALF_CAP_BITS;
+        // [r5] the previous round's flush may still be pending (below): it can wait behind this round's deposits only if they go
+        // to the other half; a whole-image round needs it done (and awaited by everybody) first
+        if (pend && !half) { carry = flush(pend_img, pend_gbase, pend_seam, pend_nfull); pend = false; }
         if (!half && r != 0 && prev_half) __syncthreads();       // a whole-image round behind a half round: wait for that flush
         imgr = half ? img + (r & 1u) * uint32_t(R_HALF_WORDS) : img;
         prev_half = half;
         if (carry) { atomicOr(&imgr[0], carry); carry = 0; }     // the previous round's partial word (the words it lands in are free: see above)
         const uint32_t exc = pre + P.inc - P.L;  // bits of the round in front of this lane
-        const uint64_t off = (v0 + r * E_THREADS + tid) * E_VEC;
-        const uint32_t nvalid = FULL ? uint32_t(E_VEC) : nvalid0;
+        const uint64_t off = (v0 + r * RS + tid) * E_VEC;
+        const uint32_t nvalid = FULL ? (act ? uint32_t(E_VEC) : 0u) : nvalid0;
         if (p.index && nvalid && ((uint32_t(off) & (S - 1u)) == 0u))
             p.index[off >> p.chunk_shift] = (uint64_t(pb0) << 56) | (abs_round + exc);
         if (p.fine && nvalid && (lane & (uint32_t(1u << T_SUB_SHIFT) / 16u - 1u)) == 0u)               // fine index (mh_kernels.h, TileParams): every fourth lane
@@ -1139,7 +1174,7 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
                 if (wave == m) region_escape_deposit(p.len8, p.code64, tab, img, x0, pb0, nvalid, cur + (exc - pre));
                 __syncthreads();
                 const uint32_t nfull = (cur + (upto - before)) >> 5;
-                const uint32_t t = flush(nfull);
+                const uint32_t t = flush(img, gbase, seam_first, nfull);
                 seam_first = seam_first && nfull == 0;
                 gbase += nfull;
                 cur = (cur + (upto - before)) & 31u;
@@ -1148,7 +1183,15 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
             }
         }
         ENC_STAMP(2);                            // exchange + deposits issued
-        // ---- while the LDS works the deposits off: the next rounds
+        // ---- [r5] while the LDS works the deposits off: FIRST the previous round's flush (its half is complete since that round's
+        // barrier, and nobody deposits into it before the next barrier), its partial last word OR-ed into this round's word 0
+        // (LDS atomics commute with the deposits) ...
+        if (pend) {
+            carry = flush(pend_img, pend_gbase, pend_seam, pend_nfull);
+            pend = false;
+            if (carry) { atomicOr(&imgr[0], carry); carry = 0; }
+        }
+        // ---- ... then the next rounds
         const LaneIn D4 = FULL ? fetch_full(r + 4) : fetch(r + 4);
         const uint32_t pb2 = head_byte(D2);
         lookup16(D2, pb2, Eb);
@@ -1159,7 +1202,12 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
             __syncthreads();
             ENC_STAMP(4);                        // barrier 2
             const uint32_t nfull = (cur + tot) >> 5;
-            carry = flush(nfull);
+            // [r5] a half round's flush waits until the NEXT round's deposits are on their way (MH_ENC_DEFER_FLUSH): the stamps of
+            // round 4 showed a fifth of a round spent at this barrier waiting for the LDS to drain ~160 atomic instructions and
+            // another fifth in the flush behind it; now the flush's reads queue behind the next round's atomics and its stores and
+            // the packing of the round after run while the LDS works
+            if (DEFER && half) { pend = true; pend_img = imgr; pend_gbase = gbase; pend_seam = seam_first; pend_nfull = nfull; }
+            else carry = flush(imgr, gbase, seam_first, nfull);
             // no barrier here: the next round touches the image only behind ITS first barrier, which every wave
             // reaches after its share of this flush
             seam_first = seam_first && nfull == 0;
@@ -1175,7 +1223,7 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
     };
     // leading rounds whose 16 KiB, and those of the four rounds behind them, are whole: the steady state
     const uint64_t whole = (p.n >> 4) < v1 ? (p.n >> 4) : v1;       // vectors with all 16 bytes inside the stream
-    const uint64_t rounds_full = whole > v0 ? (whole - v0) / E_THREADS : 0;
+    const uint64_t rounds_full = whole > v0 + (E_THREADS - RS) ? (whole - v0 - (E_THREADS - RS)) / RS : 0;   // (idle lanes read up to 64 vectors further)
     const uint64_t r_fast = rounds_full > 4 ? rounds_full - 4 : 0;
     uint64_t r = 0;
     uint32_t E2[16];
@@ -1190,6 +1238,7 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
 #pragma unroll
         for (int j = 0; j < 16; ++j) E1[j] = E2[j];
     }
+    if (pend) { carry = flush(pend_img, pend_gbase, pend_seam, pend_nfull); pend = false; }     // the last round's
     // the region's last partial dword: shared with the next region (or the stream's end), zeroed by the scan
     if (cur != 0 && gbase < rp.cap_words) {
         if (carry) atomicOr(&out32[gbase], __builtin_bswap32(carry));

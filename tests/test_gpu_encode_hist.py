@@ -159,3 +159,32 @@ def test_region_encoder_rounds_that_fit_half_the_image_next_to_rounds_that_do_no
     assert a[0] == ref_bits and a[1] == ref[1:]
     lens = np.asarray(oracle.Model.from_counts(counts, 1).codes()[0]).reshape(256, 256)
     assert lens[0x41, 0x41] <= 2 and np.median(lens[lens > 0]) >= 8    # the two kinds of round really differ
+
+
+@pytest.mark.parametrize("kind,chunk", [("uniform", 256), ("uniform", 8192), ("near8", 1024), ("mixed_regions", 1024), ("ragged_uniform", 512)])
+def test_region_encoder_rounds_of_fewer_than_1024_lanes(mhc, oracle, kind, chunk):
+    """[r5] A region whose mean 16 KiB round does not fit half the LDS image (8-bit codes: 131 072 bits against 130 304) runs its
+    rounds with the first 1008, 992 or 960 lanes, so that they alternate between the halves with one barrier each (BASELINE
+    config 4: uniform bytes).  Chunk index entries then fall on other lanes in every round and idle lanes must write none; regions
+    of the two kinds sit side by side in one stream (every workgroup chooses for its own region); the stream's ragged end goes
+    through the bounds-checked rounds.  The bytes are the oracle's and the length-pass encoder's; the fine index (every 64
+    symbols) is checked through the decoder in tests/test_gpu_tile.py's round trips and bench.py's."""
+    rng = np.random.default_rng(len(kind) + chunk)
+    n = (20 << 20) + 333
+    if kind == "uniform":
+        data = rng.integers(0, 256, n, dtype=np.uint8)                            # every code 8 bits: 1008 lanes per round
+    elif kind == "near8":                                                         # 8- and 9-bit codes, a few 7s: about 8.2 bits per symbol -> 992 / 960 lanes
+        w = np.concatenate([np.full(192, 1.0), np.full(64, 0.55)])
+        data = rng.choice(256, size=n, p=w / w.sum()).astype(np.uint8)
+    elif kind == "mixed_regions":                                                 # uniform bytes and text by turns, 3 MiB each: both geometries in one launch
+        data = rng.integers(0, 256, n, dtype=np.uint8)
+        t = text_like(n, 9)
+        for lo in range(0, n, 6 << 20):
+            data[lo:lo + (3 << 20)] = t[lo:lo + (3 << 20)]
+    else:
+        n = (5 << 20) + 16 * 1008 * 3 + 7                                          # ends three short rounds and seven bytes into a region
+        data = rng.integers(0, 256, n, dtype=np.uint8)
+    m, counts, a, b = run_both(mhc, data, chunk=chunk)
+    assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2])
+    ref, ref_bits = oracle.Model.from_counts(counts, 1).compress(data.tobytes())
+    assert a[0] == ref_bits and a[1] == ref[1:]
