@@ -929,6 +929,18 @@ __device__ __forceinline__ void region_escape_deposit(const uint8_t *len8, const
     }
 }
 
+// [r5] lanes per round of a region of `nsym` symbols priced at `bits`: 1024, or — where the mean round of 1024 vectors does not fit
+// half the image — the largest of 1008 / 992 / 960 whose mean round fits with half a per cent to spare; 1024 when none does
+// (more than ~8.4 bits per symbol: both barriers, all lanes)
+__device__ __forceinline__ uint32_t region_round_lanes(uint64_t nsym, uint64_t bits) {
+    const uint32_t cand[4] = {1024u, 1008u, 992u, 960u};
+    uint32_t pick = 0;
+#pragma unroll
+    for (int c = 3; c >= 0; --c)                                  // bits / nsym * (cand * 16) * 1.005 <= cap - 32
+        if (bits * cand[c] * E_VEC * 201u <= uint64_t(R_HALF_CAP_BITS - 32u) * nsym * 200u) pick = cand[c];
+    return pick ? pick : 1024u;
+}
+
 // ESCK: the kernel is launched twice; a workgroup takes its region in the launch that matches the region's escape flag
 // (one function with both round bodies spilled registers; a workgroup of the other kind leaves at once)
 #ifdef MH_ENC_STAMP
@@ -939,10 +951,20 @@ __device__ __forceinline__ void region_escape_deposit(const uint8_t *len8, const
 #else
 #define ENC_STAMP(i) do { } while (0)
 #endif
-template <bool ESCK>
+// WIDE [r5]: the launch for the regions whose rounds run with fewer than 1024 lanes (below); the other two instantiations keep
+// the round length a compile-time constant
+template <bool ESCK, bool WIDE = false>
 __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, RegionParams rp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if ((rp.region_esc[blockIdx.x] != 0) != ESCK) return;
+    {   // which launch takes this region (workgroup-uniform; before anything is staged)
+        const uint64_t v0 = uint64_t(blockIdx.x) * rp.region_vecs;
+        const uint64_t v1 = v0 + rp.region_vecs < rp.nvec_up ? v0 + rp.region_vecs : rp.nvec_up;
+        if (v0 < v1) {
+            const uint32_t rs = ESCK ? uint32_t(E_THREADS) : region_round_lanes((v1 * E_VEC < p.n ? v1 * E_VEC : p.n) - v0 * E_VEC, rp.region_bits[blockIdx.x]);
+            if ((rs != uint32_t(E_THREADS)) != WIDE) return;
+        } else if (WIDE) return;
+    }
     uint16_t *tab = reinterpret_cast<uint16_t *>(smem);
     uint32_t *img = reinterpret_cast<uint32_t *>(smem + 131072);
     uint32_t *sb = img + R_IMG_WORDS;
@@ -964,19 +986,10 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
     // the first 1008, 992 or 960 lanes (the largest count whose mean round fits with half a per cent to spare: 129 024 bits at 8
     // bits per symbol); the other lanes of the last wave idle (zero-length entries, no index entries).  Multiples of 4: a fine
     // index entry belongs to every fourth vector, which must stay every fourth lane.
-    uint32_t RS = E_THREADS;
-    if (!ESCK) {
-        const uint64_t nsym = (v1 * E_VEC < p.n ? v1 * E_VEC : p.n) - v0 * E_VEC;
-        const uint64_t bits = rp.region_bits[blockIdx.x];
-        const uint32_t cand[4] = {1024u, 1008u, 992u, 960u};
-        uint32_t pick = 0;
-#pragma unroll
-        for (int c = 3; c >= 0; --c)                              // bits / nsym * (cand * 16) * 1.005 <= cap - 32
-            if (bits * cand[c] * E_VEC * 201u <= uint64_t(R_HALF_CAP_BITS - 32u) * nsym * 200u) pick = cand[c];
-        if (pick) RS = pick;                                      // (none fits: more than ~8.4 bits per symbol; two barriers, all lanes)
-    }
-    const bool act = tid < RS;                                    // this lane takes a vector of every round
-    const bool wave_idles = uint32_t(wave) * 64u + 63u >= RS;     // (wave-uniform) some lane of this wave does not
+    // (region_round_lanes above; this launch was chosen by it.)  The launches with WIDE = false keep RS a constant.
+    const uint32_t RS = WIDE ? region_round_lanes((v1 * E_VEC < p.n ? v1 * E_VEC : p.n) - v0 * E_VEC, rp.region_bits[blockIdx.x]) : uint32_t(E_THREADS);
+    const bool act = !WIDE || tid < RS;                           // this lane takes a vector of every round
+    const bool wave_idles = WIDE && uint32_t(wave) * 64u + 63u >= RS;     // (wave-uniform) some lane of this wave does not
     const uint64_t rounds = (v1 - v0 + RS - 1) / RS;
     const uint64_t s0 = rp.region_start[blockIdx.x];
     uint64_t gbase = s0 >> 5, abs_round = s0;
@@ -987,15 +1000,6 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
     // barrier: no thread ever reads a word that another thread's clear may touch in the same phase.
     uint32_t carry = 0;
     bool prev_half = false;                      // the previous round used a half of the image (see round())
-#ifndef MH_ENC_DEFER_FLUSH
-#define MH_ENC_DEFER_FLUSH 1
-#endif
-    constexpr bool DEFER = MH_ENC_DEFER_FLUSH != 0;
-    bool pend = false;                           // a half round's flush that has not been issued yet: its image, base, seam, full words
-    uint32_t *pend_img = nullptr;
-    uint64_t pend_gbase = 0;
-    bool pend_seam = false;
-    uint32_t pend_nfull = 0;
 
     auto fetch = [&](uint64_t r) -> LaneIn {
         const uint64_t v = v0 + r * RS + tid;
@@ -1012,7 +1016,7 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
     // clears them; four words per lane: one 16-byte LDS read, one 16-byte clear, one 16-byte store.  The group
     // that holds word nfull (the partial tail) is visited too: its reader returns that word.
     uint32_t *imgr = img;                        // the image of the round at hand: the whole one, or one of its halves
-    auto flush = [&](uint32_t *imgr, uint64_t gbase, bool seam_first, uint32_t nfull) -> uint32_t {   // (the round's own image, base and seam)
+    auto flush = [&](uint32_t nfull) -> uint32_t {
         uint32_t tail = 0;
         for (uint32_t j = tid * 4u; j <= nfull; j += E_THREADS * 4u) {
             const uint4 w = *reinterpret_cast<const uint4 *>(imgr + j);
@@ -1139,9 +1143,6 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
         // (workgroup-uniform: cur and tot are) this round in a half of its own?  If the previous one was not, its flush of the
         // whole image may still be running: the barrier above was taken (prev_half false) and the halves are free again.
         const bool half = !ESC && cur + tot <= R_HALF_CAP_BITS;
-        // [r5] the previous round's flush may still be pending (below): it can wait behind this round's deposits only if they go
-        // to the other half; a whole-image round needs it done (and awaited by everybody) first
-        if (pend && !half) { carry = flush(pend_img, pend_gbase, pend_seam, pend_nfull); pend = false; }
         if (!half && r != 0 && prev_half) __syncthreads();       // a whole-image round behind a half round: wait for that flush
         imgr = half ? img + (r & 1u) * uint32_t(R_HALF_WORDS) : img;
         prev_half = half;
@@ -1174,7 +1175,7 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
                 if (wave == m) region_escape_deposit(p.len8, p.code64, tab, img, x0, pb0, nvalid, cur + (exc - pre));
                 __syncthreads();
                 const uint32_t nfull = (cur + (upto - before)) >> 5;
-                const uint32_t t = flush(img, gbase, seam_first, nfull);
+                const uint32_t t = flush(nfull);
                 seam_first = seam_first && nfull == 0;
                 gbase += nfull;
                 cur = (cur + (upto - before)) & 31u;
@@ -1183,15 +1184,10 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
             }
         }
         ENC_STAMP(2);                            // exchange + deposits issued
-        // ---- [r5] while the LDS works the deposits off: FIRST the previous round's flush (its half is complete since that round's
-        // barrier, and nobody deposits into it before the next barrier), its partial last word OR-ed into this round's word 0
-        // (LDS atomics commute with the deposits) ...
-        if (pend) {
-            carry = flush(pend_img, pend_gbase, pend_seam, pend_nfull);
-            pend = false;
-            if (carry) { atomicOr(&imgr[0], carry); carry = 0; }
-        }
-        // ---- ... then the next rounds
+        // ---- while the LDS works the deposits off: the next rounds
+        // ([r5] the previous round's flush was moved here as well — a half round's flush deferred until the next round's deposits
+        // are on their way, its reads queued behind them — and measured SLOWER, 9.44 against 8.83 ms per 16 GiB, 2.475 against 2.405
+        // per 4 GiB: profiles/r05/encoder/README.md, commit 7159b51; a wave's flush reads wait for its own ~10 atomics per lane)
         const LaneIn D4 = FULL ? fetch_full(r + 4) : fetch(r + 4);
         const uint32_t pb2 = head_byte(D2);
         lookup16(D2, pb2, Eb);
@@ -1202,12 +1198,7 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
             __syncthreads();
             ENC_STAMP(4);                        // barrier 2
             const uint32_t nfull = (cur + tot) >> 5;
-            // [r5] a half round's flush waits until the NEXT round's deposits are on their way (MH_ENC_DEFER_FLUSH): the stamps of
-            // round 4 showed a fifth of a round spent at this barrier waiting for the LDS to drain ~160 atomic instructions and
-            // another fifth in the flush behind it; now the flush's reads queue behind the next round's atomics and its stores and
-            // the packing of the round after run while the LDS works
-            if (DEFER && half) { pend = true; pend_img = imgr; pend_gbase = gbase; pend_seam = seam_first; pend_nfull = nfull; }
-            else carry = flush(imgr, gbase, seam_first, nfull);
+            carry = flush(nfull);
             // no barrier here: the next round touches the image only behind ITS first barrier, which every wave
             // reaches after its share of this flush
             seam_first = seam_first && nfull == 0;
@@ -1238,7 +1229,6 @@ __global__ __launch_bounds__(E_THREADS) void enc_region_kernel(EmitParams p, Reg
 #pragma unroll
         for (int j = 0; j < 16; ++j) E1[j] = E2[j];
     }
-    if (pend) { carry = flush(pend_img, pend_gbase, pend_seam, pend_nfull); pend = false; }     // the last round's
     // the region's last partial dword: shared with the next region (or the stream's end), zeroed by the scan
     if (cur != 0 && gbase < rp.cap_words) {
         if (carry) atomicOr(&out32[gbase], __builtin_bswap32(carry));
@@ -1524,6 +1514,7 @@ hipError_t launch_encode_regions(const EncodeArgs &a, const void *d_hist_ws, siz
     if (!d_hist_ws || hist_ws_bytes < g.total || g.grid > 1024) return hipErrorInvalidValue;
     e = once_per_device(&DeviceState::region_ready, [] {
         hipError_t r = allow_lds(reinterpret_cast<const void *>(enc_region_kernel<false>), REGION_LDS_BYTES);
+        if (r == hipSuccess) r = allow_lds(reinterpret_cast<const void *>(enc_region_kernel<false, true>), REGION_LDS_BYTES);
         if (r == hipSuccess) r = allow_lds(reinterpret_cast<const void *>(region_bits_kernel), 65536);
         return r != hipSuccess ? r : allow_lds(reinterpret_cast<const void *>(enc_region_kernel<true>), REGION_LDS_BYTES);
     });
@@ -1542,6 +1533,8 @@ hipError_t launch_encode_regions(const EncodeArgs &a, const void *d_hist_ws, siz
     RegionParams rp{region_start, region_bits, region_esc, g.region_vecs, g.nvec_up, (a.cap & ~uint64_t(3)) >> 2, status};
     (void)launch_set_word(reinterpret_cast<uint32_t *>(ws + 8), uint32_t(a.max_len > mh::ENC16_MAX_LEN ? ENC_PATH_REGIONS_ESCAPES : ENC_PATH_REGIONS), st);
     hipLaunchKernelGGL(enc_region_kernel<false>, dim3(g.grid), dim3(E_THREADS), REGION_LDS_BYTES, st, ep, rp);
+    if (a.max_len >= 8)                          // a region of ~8 bits per symbol needs codes that long: its rounds run with fewer lanes [r5]
+        hipLaunchKernelGGL((enc_region_kernel<false, true>), dim3(g.grid), dim3(E_THREADS), REGION_LDS_BYTES, st, ep, rp);
     if (a.max_len > mh::ENC16_MAX_LEN)           // the model has codes over 12 bits: the regions that contain any
         hipLaunchKernelGGL(enc_region_kernel<true>, dim3(g.grid), dim3(E_THREADS), REGION_LDS_BYTES, st, ep, rp);
     return hipGetLastError();
