@@ -448,6 +448,17 @@ int mh_dev_encode_path(const void *d_ws, void *stream);
 /* Diagnostic: which decoder the last mh_dev_decode* call on this workspace ran — 1 the tile decoder (fine index given, 8 MiB
  * or more, average code shorter than the tile tables' first level), 2 the chunk decoder.  Synchronises. */
 int mh_dev_decode_path(const void *d_ws, void *stream);
+/* Diagnostic: which instantiation of the chunk decoder that call launched (csrc/mh_decode.hip, dec_cfg) — chosen from the
+ * model's table layout and the stream's ratio, never from the environment:
+ *   0 LDS_WIDE          both table levels in LDS, no code over 8 bits, ratio over 0.6: two streams, 64-byte granules and bursts
+ *   1 LDS_SHORT         the same model on a better-compressed stream: four light streams
+ *   2 LDS_TWO_LEVEL     both levels in LDS, first level narrower than 8 bits;   3 LDS_TWO_LEVEL_P8   ... of 8 bits
+ *   4 L2_DIRECT         first level in LDS, uniform second-level tables of 2^H entries in L2, H read from the model;
+ *   5 / 6 / 7 / 8       ... with H = 2 / 3 / 4 / 8 as a compile-time constant (longest code 10 / 11 / 12 / 16 or more bits)
+ * -1: the chunk decoder did not run on this workspace (the tile decoder did).  The redo pass behind it (codes longer than
+ * both levels, ragged ends: one lane per chunk, tree walk) uses variant 9 REDO_LDS or 10 REDO_L2_DIRECT of the same layout.
+ * Synchronises. */
+int mh_dev_decode_variant(const void *d_ws, void *stream);
 /* Synchronises `stream` and returns the device-side status word of a workspace (MH_OK, MH_ERR_CORRUPT,
  * MH_ERR_TIMEOUT, MH_ERR_CAPACITY). */
 int mh_dev_status(const void *d_ws, void *stream);

@@ -39,7 +39,7 @@ EXPORTS = [
     "mh_decode_to", "mh_model_payload_bits", "mh_dev_encode_workspace", "mh_dev_encode", "mh_dev_payload_bits", "mh_dev_encode_at", "mh_dev_encode_ctx", "mh_dev_encode_hist", "mh_dev_decode_workspace", "mh_dev_decode", "mh_dev_decode_dn",
     "mh_dev_build_index_workspace", "mh_dev_build_index", "mh_dev_status",
     "mh_dev_model2_workspace", "mh_dev_model2_array", "mh_dev_model2_build_slice", "mh_dev_model2_finish",
-    "mh_dev_encode_fine", "mh_dev_encode_ctx_fine", "mh_dev_decode_fine", "mh_dev_build_index_fine", "mh_dev_decode_stream_states", "mh_dev_decode_stream_emit", "mh_dev_index_path", "mh_dev_encode_path", "mh_dev_decode_path",
+    "mh_dev_encode_fine", "mh_dev_encode_ctx_fine", "mh_dev_decode_fine", "mh_dev_build_index_fine", "mh_dev_decode_stream_states", "mh_dev_decode_stream_emit", "mh_dev_index_path", "mh_dev_encode_path", "mh_dev_decode_path", "mh_dev_decode_variant",
 ]
 
 
@@ -132,6 +132,7 @@ def lib():
         l.mh_dev_decode_stream_states.argtypes = [vp, vp, u64, u8, vp, vp, sz, vp]
         l.mh_dev_decode_stream_emit.argtypes = [vp, vp, u64, u8, vp, u64, vp, sz, vp]
         l.mh_dev_index_path.argtypes = [vp, vp]
+        l.mh_dev_decode_variant.argtypes = [vp, vp]
         l.mh_dev_encode_path.argtypes = [vp, vp]
         l.mh_dev_decode_path.argtypes = [vp, vp]
         _lib = l

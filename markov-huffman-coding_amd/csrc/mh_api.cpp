@@ -1477,6 +1477,14 @@ int mh_dev_decode_path(const void *d_ws, void *stream) {
     return int(v);
 }
 
+int mh_dev_decode_variant(const void *d_ws, void *stream) {
+    if (!d_ws) return MH_ERR_ARG;
+    uint32_t v = 0;
+    HIP_TRY(hipMemcpyAsync(&v, static_cast<const unsigned char *>(d_ws) + 44, sizeof v, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return int(v) - 1;                                           // (the launcher stores variant + 1: 0 = the chunk decoder did not run)
+}
+
 int mh_dev_index_path(const void *d_ws, void *stream) {
     if (!d_ws) return MH_ERR_ARG;
     uint32_t v = 0;

@@ -216,19 +216,45 @@ __device__ __forceinline__ void store_burst(const DecParams &p, uint64_t c0, con
     }
 }
 
-// SEC_LDS  both table levels in LDS (else the second level is gathered from L2)
-// SPR      symbols per window refill (2, or 4 when no code exceeds 8 bits)
-// DIRECT   L2 mode with uniform, directly addressed second-level tables
-// K        independent streams (chunks) per lane
-// GW       dwords per input granule (8 = 32 B, 16 = 64 B)
-// OUTB     16-byte stores per output burst (1 = 16 B, 4 = 64 B contiguous per stream)
-// Models whose tables live in LDS and whose codes are all <= 8 bits are bound by how the streams touch HBM
-// (measured: 32-byte granules re-fetch every 128-byte line four times, 16-byte stores double the write
-// traffic), so they run K = 2 with 64-byte granules and 64-byte store bursts; with a second level the
-// dependent lookups dominate and K = 4 with 32-byte granules wins (32-byte bursts with both levels in LDS,
-// 64-byte bursts on a two-slot FIFO with the second level in L2: see launch_decode).
-template <bool SEC_LDS, int SPR, bool DIRECT, int K, int GW, int OUTB, int PC, int HC, bool REDO = false, int NT = 512, int DEPTH = 2>
-__global__ __launch_bounds__(NT) void decode_kernel(DecParams p) {
+// ---- the chunk decoder's variants [r5]: every instantiation the launcher can select, by name (mh_kernels.h: DecVariant; the
+// one that ran is on record in the workspace, mh_dev_decode_variant; tests/test_gpu_decode_variants.py drives each of them
+// against the oracle).  Rounds 1-3 grew this kernel eleven template parameters and A/B macros; what survived the measurements:
+//   sec_lds  both table levels in LDS (else: uniform second-level tables of 2^H entries gathered from L2, "direct" layout)
+//   spr      symbols per window refill (2, or 4 when no code exceeds 8 bits)
+//   k        independent streams (chunks) per lane
+//   gw       dwords per input granule (8 = 32 B, 16 = 64 B)
+//   outb     16-byte stores per output burst
+//   pc / hc  first-level width / second-level height as compile-time constants (0: read from the parameters)
+//   redo     the redo pass: one lane per listed chunk, tree walk for codes longer than both levels
+//   depth    slots of the input granule FIFO
+// Models whose tables live in LDS and whose codes are all <= 8 bits are bound by how the streams touch HBM (32-byte granules
+// re-fetch every 128-byte line four times, 16-byte stores double the write traffic): they run two streams with 64-byte
+// granules and bursts when the payload is a large part of the traffic (uniform bytes: 1.6x), four light streams otherwise
+// (41 %-ratio text: the wide form is 8 % slower).  With a second level the dependent lookups dominate and four streams win
+// (Zipf code lengths, all tables in LDS: 5.5 ms light, 7.7 ms wide per 4 GiB).  The general L2 layout of rounds 1-2 (indexed
+// second-level tables gathered from L2) is gone: it was only chosen for more than 32 767 depth-8 inner nodes, and 256
+// contexts of at most 256 leaves have at most 256 x 127 of them (a context with 128 would hold 256 leaves below depth 8: a
+// Kraft sum of at most 1/2).
+struct DecCfg { bool sec_lds; int spr; int k, gw, outb, pc, hc; bool redo; int depth; };
+__host__ __device__ constexpr DecCfg dec_cfg(int v) {
+    return v == DV_LDS_WIDE       ? DecCfg{true, 4, 2, 16, 4, 8, 0, false, 2}
+         : v == DV_LDS_SHORT      ? DecCfg{true, 4, 4, 8, 2, 8, 0, false, 2}
+         : v == DV_LDS_TWO_LEVEL  ? DecCfg{true, 2, 4, 8, 2, 0, 0, false, 2}
+         : v == DV_LDS_TWO_LEVEL_P8 ? DecCfg{true, 2, 4, 8, 2, 8, 0, false, 2}
+         : v == DV_L2_DIRECT      ? DecCfg{false, 2, 4, 8, 4, 8, 0, false, 1}
+         : v == DV_L2_DIRECT_H2   ? DecCfg{false, 2, 4, 8, 4, 8, 2, false, 1}
+         : v == DV_L2_DIRECT_H3   ? DecCfg{false, 2, 4, 8, 4, 8, 3, false, 1}
+         : v == DV_L2_DIRECT_H4   ? DecCfg{false, 2, 4, 8, 4, 8, 4, false, 1}
+         : v == DV_L2_DIRECT_H8   ? DecCfg{false, 2, 4, 8, 4, 8, 8, false, 1}
+         : v == DV_REDO_LDS       ? DecCfg{true, 2, 1, 8, 1, 0, 0, true, 2}
+                                  : DecCfg{false, 2, 1, 8, 1, 0, 0, true, 2};      // DV_REDO_L2_DIRECT
+}
+constexpr int DEC_NT = 512;                                       // lanes per workgroup, every variant
+template <int V>
+__global__ __launch_bounds__(DEC_NT) void decode_kernel(DecParams p) {
+    constexpr DecCfg C = dec_cfg(V);
+    constexpr bool SEC_LDS = C.sec_lds, DIRECT = !C.sec_lds, REDO = C.redo;
+    constexpr int SPR = C.spr, K = C.k, GW = C.gw, OUTB = C.outb, PC = C.pc, HC = C.hc, NT = DEC_NT, DEPTH = C.depth;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (REDO && p.redo[0] == 0) return;                         // the usual case: nothing was handed over
     if (p.d_nbits) {                                            // payload length still on the device (mh_dev_decode_dn)
@@ -433,11 +459,10 @@ hipError_t launch_decode_redo(DecParams p, hipStream_t st) {
         hipLaunchKernelGGL(decode2_kernel, dim3(unsigned(want2 > cap2 ? cap2 : (want2 < 1 ? 1 : want2))), dim3(256), 0, st, p);
         return hipGetLastError();
     }
-    auto r_lds = decode_kernel<true, 2, false, 1, 8, 1, 0, 0, true>;
-    auto r_l2 = decode_kernel<false, 2, false, 1, 8, 1, 0, 0, true>;
-    auto r_l2d = decode_kernel<false, 2, true, 1, 8, 1, 0, 0, true>;
+    auto r_lds = decode_kernel<DV_REDO_LDS>;
+    auto r_l2d = decode_kernel<DV_REDO_L2_DIRECT>;
     hipError_t e = once_per_device(&DeviceState::redo_ready, [&] {
-        const void *all[] = {(const void *)r_lds, (const void *)r_l2, (const void *)r_l2d};
+        const void *all[] = {(const void *)r_lds, (const void *)r_l2d};
         for (const void *f : all) {
             hipError_t r = allow_lds(f, DEC_LDS_MAX);
             if (r != hipSuccess) return r;
@@ -445,12 +470,13 @@ hipError_t launch_decode_redo(DecParams p, hipStream_t st) {
         return hipSuccess;
     });
     if (e != hipSuccess) return e;
+    if (!p.sec_lds && !p.direct) return hipErrorInvalidValue;      // (the general L2 layout no longer exists: see dec_cfg)
     if (!p.sec_lds && p.P != 8) return hipErrorInvalidValue;
     const size_t lds = 1024 + (size_t(256) << p.P) * 2 + (p.sec_lds ? ((size_t(p.nsec) * 2 + 15) & ~size_t(15)) : 0);
     if (lds > size_t(DEC_LDS_MAX)) return hipErrorInvalidValue;
     const uint64_t rwant = (p.nchunks + DEC_THREADS - 1) / DEC_THREADS;
     const int rgrid = int(rwant > uint64_t(cu_count()) ? uint64_t(cu_count()) : rwant);
-    hipLaunchKernelGGL(p.sec_lds ? r_lds : p.direct ? r_l2d : r_l2, dim3(rgrid < 1 ? 1 : rgrid), dim3(DEC_THREADS), lds, st, p);
+    hipLaunchKernelGGL(p.sec_lds ? r_lds : r_l2d, dim3(rgrid < 1 ? 1 : rgrid), dim3(DEC_THREADS), lds, st, p);
     return hipGetLastError();
 }
 
@@ -465,73 +491,33 @@ hipError_t launch_decode(DecParams p, void *d_ws, hipStream_t st) {
         hipLaunchKernelGGL(decode2_kernel, dim3(unsigned(want2 > cap2 ? cap2 : want2)), dim3(256), 0, st, p);
         return hipGetLastError();
     }
-    // instantiations: <SEC_LDS, SPR, DIRECT, K, GW, OUTB, PC, HC[, REDO, NT, DEPTH]>
-    // tables in LDS -> wide (2 streams, 64-byte granules and store bursts) or light (4 streams, 32-byte
-    // granules and store bursts: 16-byte stores reach HBM as 32-byte writes, measured -14 %; 64-byte bursts
-    // measured the same as 32-byte ones here: 4 GiB text 4.24 vs 4.27 ms); L2 gathers -> 4 streams, 32-byte
-    // granules, 64-byte bursts.  The MH_LIGHT_* / MH_L2D_* macros exist for A/B builds (csrc/Makefile `exp`).
-#ifndef MH_LIGHT_OUTB
-#define MH_LIGHT_OUTB 2
-#endif
-#ifndef MH_LIGHT_DEPTH
-#define MH_LIGHT_DEPTH 2
-#endif
-    void (*k_lds2_light[2])(DecParams) = {decode_kernel<true, 2, false, 4, 8, MH_LIGHT_OUTB, 0, 0, false, 512, MH_LIGHT_DEPTH>,
-                                          decode_kernel<true, 2, false, 4, 8, MH_LIGHT_OUTB, 8, 0, false, 512, MH_LIGHT_DEPTH>};
-    auto k_lds4 = decode_kernel<true, 4, false, 2, 16, 4, 8, 0>;
-    auto k_lds4_light = decode_kernel<true, 4, false, 4, 8, MH_LIGHT_OUTB, 8, 0, false, 512, MH_LIGHT_DEPTH>;
-    auto k_l2 = decode_kernel<false, 2, false, 4, 8, MH_LIGHT_OUTB, 8, 0, false, 512, MH_LIGHT_DEPTH>;
-    // second-level height H as a template constant where it is common (max code length 10..12 and >= 16): the
-    // table index is then two instructions with immediate operands
-#ifndef MH_L2D_OUTB
-#define MH_L2D_OUTB 4
-#endif
-#ifndef MH_L2D_DEPTH
-#define MH_L2D_DEPTH 1
-#endif
-#ifndef MH_L2D_K
-#define MH_L2D_K 4
-#endif
-#ifndef MH_L2D_GW
-#define MH_L2D_GW 8
-#endif
-#ifndef MH_L2D_NT
-#define MH_L2D_NT 512
-#endif
-
-#define L2D(SPRV, HCV) decode_kernel<false, SPRV, true, MH_L2D_K, MH_L2D_GW, MH_L2D_OUTB, 8, HCV, false, MH_L2D_NT, MH_L2D_DEPTH>
-    void (*k_l2d[9])(DecParams) = {L2D(2, 0), L2D(2, 0), L2D(2, 2), L2D(2, 3), L2D(2, 4), L2D(2, 0), L2D(2, 0), L2D(2, 0), L2D(2, 8)};
-#undef L2D
+    // which variant (dec_cfg above says what each is and why)
+    if (!p.sec_lds && (p.P != 8 || !p.direct)) return hipErrorInvalidValue;       // the L2 layout is built with P = 8, uniform tables
+    size_t lds = 1024 + (size_t(256) << p.P) * 2 + (p.sec_lds ? ((size_t(p.nsec) * 2 + 15) & ~size_t(15)) : 0);
+    if (lds > size_t(DEC_LDS_MAX)) return hipErrorInvalidValue;
+    const bool short_codes = p.nsec == 0 && p.P == 8;              // no second level at all: every code <= 8 bits
+    const bool wide = p.sec_lds && short_codes && p.n > 0 && p.nbits * 10 > p.n * 8 * 6;      // ratio > 0.6
+    int v;
+    if (wide) v = DV_LDS_WIDE;
+    else if (p.sec_lds) v = short_codes ? DV_LDS_SHORT : p.P == 8 ? DV_LDS_TWO_LEVEL_P8 : DV_LDS_TWO_LEVEL;
+    else v = p.H == 2 ? DV_L2_DIRECT_H2 : p.H == 3 ? DV_L2_DIRECT_H3 : p.H == 4 ? DV_L2_DIRECT_H4 : p.H == 8 ? DV_L2_DIRECT_H8 : DV_L2_DIRECT;
+    void (*const kern[DV_REDO_LDS])(DecParams) = {decode_kernel<DV_LDS_WIDE>, decode_kernel<DV_LDS_SHORT>, decode_kernel<DV_LDS_TWO_LEVEL>,
+                                                  decode_kernel<DV_LDS_TWO_LEVEL_P8>, decode_kernel<DV_L2_DIRECT>, decode_kernel<DV_L2_DIRECT_H2>,
+                                                  decode_kernel<DV_L2_DIRECT_H3>, decode_kernel<DV_L2_DIRECT_H4>, decode_kernel<DV_L2_DIRECT_H8>};
+    static_assert(DV_LDS_WIDE == 0 && DV_L2_DIRECT_H8 == 8 && DV_REDO_LDS == 9, "the table above is indexed by DecVariant");
     e = once_per_device(&DeviceState::decode_ready, [&] {
-        const void *all[] = {(const void *)k_lds2_light[0], (const void *)k_lds2_light[1],
-                             (const void *)k_lds4, (const void *)k_lds4_light, (const void *)k_l2, (const void *)k_l2d[0], (const void *)k_l2d[2],
-                             (const void *)k_l2d[3], (const void *)k_l2d[4], (const void *)k_l2d[8]};
-        for (const void *f : all) {
-            hipError_t r = allow_lds(f, DEC_LDS_MAX);
+        for (int i = 0; i < DV_REDO_LDS; ++i) {
+            hipError_t r = allow_lds(reinterpret_cast<const void *>(kern[i]), DEC_LDS_MAX);
             if (r != hipSuccess) return r;
         }
         return hipSuccess;
     });
     if (e != hipSuccess) return e;
-    if (!p.sec_lds && p.P != 8) return hipErrorInvalidValue;       // the L2 layouts are built with P = 8
-    size_t lds = 1024 + (size_t(256) << p.P) * 2 + (p.sec_lds ? ((size_t(p.nsec) * 2 + 15) & ~size_t(15)) : 0);
-    if (lds > size_t(DEC_LDS_MAX)) return hipErrorInvalidValue;
-    // With the tables in LDS and NO second level (every code <= 8 bits) the kernel is bound by how the
-    // streams touch HBM once the payload is a large part of the traffic: uniform data runs 1.6x faster
-    // with the wide streams.  With a second level the dependent lookups dominate and four streams per
-    // lane win (measured with Zipf code lengths and all tables in LDS: 5.5 ms light, 7.7 ms wide per
-    // 4 GiB), as they do for low-ratio data (41 %-ratio text 8 % slower with the wide streams).
-    const bool short_codes = p.nsec == 0 && p.P == 8;
-    const bool wide = p.sec_lds && short_codes && p.n > 0 && p.nbits * 10 > p.n * 8 * 6;      // ratio > 0.6
-    const bool l2d = !p.sec_lds && p.direct;
-    const uint64_t per_block = l2d ? uint64_t(MH_L2D_NT) * MH_L2D_K : uint64_t(DEC_THREADS) * (wide ? 2 : 4);
-    uint64_t want = (p.nchunks + per_block - 1) / per_block;
-    int grid = int(want > uint64_t(cu_count()) ? uint64_t(cu_count()) : want);
-    const int p8 = p.P == 8;
-    if (wide) hipLaunchKernelGGL(k_lds4, dim3(grid), dim3(DEC_THREADS), lds, st, p);
-    else if (p.sec_lds) hipLaunchKernelGGL(short_codes ? k_lds4_light : k_lds2_light[p8], dim3(grid), dim3(DEC_THREADS), lds, st, p);
-    else if (p.direct) hipLaunchKernelGGL(k_l2d[p.H <= 8 ? p.H : 0], dim3(grid), dim3(MH_L2D_NT), lds, st, p);
-    else hipLaunchKernelGGL(k_l2, dim3(grid), dim3(DEC_THREADS), lds, st, p);
+    const uint64_t per_block = uint64_t(DEC_NT) * uint64_t(dec_cfg(v).k);
+    const uint64_t want = (p.nchunks + per_block - 1) / per_block;
+    const int grid = int(want > uint64_t(cu_count()) ? uint64_t(cu_count()) : want);
+    (void)launch_set_word(reinterpret_cast<uint32_t *>(static_cast<char *>(d_ws) + 44), uint32_t(v) + 1u, st);   // mh_dev_decode_variant
+    hipLaunchKernelGGL(kern[v], dim3(grid), dim3(DEC_NT), lds, st, p);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     // chunks with a code longer than both table levels: normally none, and the pass returns at once

@@ -202,6 +202,10 @@ hipError_t launch_stream_emit(IdxParams p, void *d_ws, uint8_t *d_out, uint64_t 
 // which encoder a launch_encode* call used (its workspace's status block, bytes 8..11)
 // which decoder ran (status block of the decode workspace, bytes 40..43; mh_dev_decode_path)
 enum { DEC_PATH_NONE = 0, DEC_PATH_TILE = 1, DEC_PATH_CHUNK = 2 };
+// the chunk decoder's variants (mh_decode.hip, dec_cfg): which one launch_decode chose is noted in the status block (bytes 44..47,
+// value + 1; mh_dev_decode_variant).  The redo pass runs behind every one of them with the variant of the same table layout.
+enum DecVariant { DV_LDS_WIDE = 0, DV_LDS_SHORT = 1, DV_LDS_TWO_LEVEL = 2, DV_LDS_TWO_LEVEL_P8 = 3, DV_L2_DIRECT = 4, DV_L2_DIRECT_H2 = 5,
+                  DV_L2_DIRECT_H3 = 6, DV_L2_DIRECT_H4 = 7, DV_L2_DIRECT_H8 = 8, DV_REDO_LDS = 9, DV_REDO_L2_DIRECT = 10 };
 hipError_t launch_set_word(uint32_t *d_word, uint32_t v, hipStream_t st);
 enum { ENC_PATH_NONE = 0, ENC_PATH_REGIONS = 1, ENC_PATH_LENGTH_PASS = 2, ENC_PATH_REGIONS_ESCAPES = 3, ENC_PATH_CHAIN = 4 };
 // how launch_build_index arrived at the index (status block bytes 8..11)

@@ -406,6 +406,8 @@ Model::Packed Model::pack() const {
         // uniform tables: one per depth-8 internal node (profile with hcap = 0 counts the nodes)
         size_t ntab[9], wtab[9];
         profile(0, ntab, wtab);
+        // (always: a context has at most 127 inner nodes at depth 8 — 128 would hold all 256 leaves below depth 8, a Kraft sum of
+        //  1/2 — so 256 contexts have at most 32 512; the general layout behind the else is kept for a table file that lies)
         if (ntab[8] <= 32767) uniform_h = std::min(std::max(pk.max_len - 8, 1), 8);
         else while (worst[8] > size_t(DEC_SEC_MAX_PER_CTX) && hcap > 1) { --hcap; profile(hcap, total, worst); }
     }
