@@ -91,7 +91,7 @@ def recipe(kind):
         c[:26] = fib_row()
     elif kind == "REDO_L2_DIRECT":               # 255 Zipf contexts + one Fibonacci context: second level in L2, codes of up to 25 bits
         c[:] = zipf_counts(1.1)
-        c[0] = fib_row()
+        c[0] = fib_row() * np.uint64(1000)        # (heavy enough that the planted pairs below do not reshape its tree)
     else:
         raise ValueError(kind)
     data = sample_rows(c, n if kind.startswith("L2_DIRECT") else (1 << 20) + 77, 7)     # (a chain that is not iid is drawn symbol by symbol)
