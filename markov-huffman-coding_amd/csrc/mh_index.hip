@@ -32,11 +32,12 @@ __device__ __forceinline__ void idx_fine_entry(const IdxParams &p, uint64_t g, u
 // A null table entry stops the walk (*bad): speculative starts may run into one legitimately.
 template <typename F>
 __device__ __forceinline__ uint64_t walk_segment(const IdxParams &p, const DecTables &tabs, const BitSrc &src, uint64_t start,
-                                                 uint64_t seg_end, uint32_t &count, bool &bad, F on_symbol) {
+                                                 uint64_t seg_end, uint32_t &count, bool &bad, F on_symbol, uint32_t *max_used = nullptr) {
     uint64_t pos = st_pos(p, start);
     uint32_t prev = st_ctx(p, start);
     count = 0;
     bad = false;
+    if (max_used) *max_used = 0;
     if (pos >= seg_end) return start;
     GranuleCursor bc;                                       // (dword reads cost a cache line each here: lanes are a segment apart)
     bc.init(src, pos);
@@ -45,6 +46,7 @@ __device__ __forceinline__ uint64_t walk_segment(const IdxParams &p, const DecTa
         uint32_t used = 0;
         uint32_t sym = decode_one(p.prim, p.sec_base, tabs, src, bc, prev, used, bad);
         if (bad) break;
+        if (max_used && used > *max_used) *max_used = used;     // (the longest code of the segment)
         prev = p.order == 2 ? (((prev << 8) | sym) & 0xFFFFu) : sym;
         pos += used;
         ++count;
@@ -157,13 +159,16 @@ __global__ __launch_bounds__(256) void index_tile_repair_kernel(IdxParams p, uin
     const uint64_t start = st_make(p, pe >> 8, i * IX_SEG_BITS + (pe & 255u));
     const BitSrc src{p.payload, p.payload_bytes >> 2, p.payload_bytes};
     const DecTables tabs{p.sec, p.tree, p.P, p.direct, p.H};
-    uint32_t count_sym;
+    uint32_t count_sym, longest;
     bool bad;
-    uint64_t end = walk_segment(p, tabs, src, start, seg_end, count_sym, bad, [](uint32_t, uint32_t, uint64_t) {});
+    uint64_t end = walk_segment(p, tabs, src, start, seg_end, count_sym, bad, [](uint32_t, uint32_t, uint64_t) {}, &longest);
     if (bad) end = st_make(p, st_ctx(p, end), seg_end);                // (the fill pass reports it if the state was the true one)
     const uint64_t over = st_pos(p, end) - seg_end;
     __hip_atomic_store(&p.e16[i], uint16_t((st_ctx(p, end) << 8) | uint32_t(over > 254 ? 254 : over)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    p.c16[i] = uint16_t(count_sym);
+    // [r5] bit 15 of the count: the segment holds a code the tile tables' two levels do not resolve (longer than tP + tH bits) —
+    // such a segment is always listed (the states pass cannot decode it) and the segment decoder leaves it to
+    // segment_walk_emit_kernel.  (A segment has at most IX_SEG_BITS symbols: the count itself needs nine bits.)
+    p.c16[i] = uint16_t(count_sym | (longest > p.tP + p.tH ? IX_C16_WALK : 0u));
     p.s16[i] = uint16_t(pe == IX_INVALID ? 0xFFFEu : pe);              // (an end state is never IX_INVALID: its overshoot is under 255)
 }
 
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(256) void index_tile_count_kernel(IdxParams p) {
     if (t >= p.ntile5) return;
     uint32_t sum = 0;
     const uint64_t s0 = t * IX_TILE_SEGS;
-    for (uint32_t j = lane; j < IX_TILE_SEGS; j += 64u) if (s0 + j < p.nseg5) sum += p.c16[s0 + j];
+    for (uint32_t j = lane; j < IX_TILE_SEGS; j += 64u) if (s0 + j < p.nseg5) sum += p.c16[s0 + j] & IX_C16_COUNT;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
     if (lane == 0) p.tile_cnt[t] = sum;
@@ -402,7 +407,6 @@ __global__ __launch_bounds__(64) void build_index_kernel(IdxParams p) {
 // then fix a single segment.  With the guesses on the lattice such streams synchronise at once.
 constexpr uint32_t IDX_SEG_BITS = 4096;
 constexpr uint32_t IDX_SEG_BITS_MIN = IDX_SEG_BITS - 64;       // smallest segment any gcd <= 64 gives (workspace sizing)
-constexpr uint32_t IDX_MAX_PASSES = 96;
 struct IdxWs { size_t off_changed, off_end, off_used, off_count, off_start, off_blk, total; uint64_t nseg, nblk;
                size_t off_e16, off_s16, off_c16, off_dirty, off_tcnt, off_tbase, off_tblk; uint64_t nseg5, ntile5, ntblk, dirty_cap; };
 static IdxWs idx_ws_layout(uint64_t nbits) {
@@ -448,8 +452,10 @@ static void note_index_path(unsigned char *ws, uint32_t path, hipStream_t st) {
 // Eligible: order 1, tile tables with P = 7, no code-length lattice (g == 1), a stream worth a launch of 256 workgroups.
 // Given up (*ok false, nothing else changed but the status block) when more than a quarter of the segments did not
 // synchronise within their warm-up, or the repairs do not die out.  Synchronises `st` between passes.
-static bool index_tiles_eligible(const IdxParams &p, const IdxWs &L, uint32_t g) {
-    return p.order != 2 && p.tprim && p.tP == 7 && p.max_len <= p.tP + p.tH && g == 1 && p.nbits >= (1ull << 20) && L.nseg5 < 0xFFFFFFFFull && !getenv("MH_INDEX_NO_TILES");
+// allow_long: codes longer than the tile tables resolve are the caller's business (the segment decoder hands their segments
+// to a walk; the index fill pass of the tiles cannot)
+static bool index_tiles_eligible(const IdxParams &p, const IdxWs &L, uint32_t g, bool allow_long = false) {
+    return p.order != 2 && p.tprim && p.tP == 7 && (allow_long || p.max_len <= p.tP + p.tH) && g == 1 && p.nbits >= (1ull << 20) && L.nseg5 < 0xFFFFFFFFull && !getenv("MH_INDEX_NO_TILES");
 }
 static hipError_t index_tile_states(const IdxParams &p, const IdxWs &L, unsigned char *ws, hipStream_t st, IdxParams &q, bool *ok_out) {
     hipError_t e = hipSuccess;
@@ -726,7 +732,7 @@ hipError_t launch_stream_states(IdxParams p, void *d_ws, hipStream_t st) {
     e = hipMemsetAsync(p.n_symbols, 0, 8, st);
     if (e != hipSuccess || p.nbits == 0) return e;
     const uint32_t g = p.len_gcd >= 1 && p.len_gcd <= 64 ? p.len_gcd : 1;
-    if (!index_tiles_eligible(p, L, g)) return hipSuccess;
+    if (!index_tiles_eligible(p, L, g, true)) return hipSuccess;
     IdxParams q;
     bool ok = false;
     e = index_tile_states(p, L, ws, st, q, &ok);
@@ -735,6 +741,42 @@ hipError_t launch_stream_states(IdxParams p, void *d_ws, hipStream_t st) {
     else e = hipMemsetAsync(ws, 0, L.off_end, st);
     return e;
 }
+// [r5] the segments the segment decoder left alone (bit 15 of their count: a code longer than the tile tables resolve), listed by
+// it in dirty_list (counter: the last word of `changed`): one thread each, general tables with the tree walk
+// (src/coding.cpp:129-149), bytes written one by one.  Rare by construction: such a code has a probability under 2^-15 in its
+// context.
+__global__ __launch_bounds__(256) void segment_walk_emit_kernel(IdxParams p, uint8_t *out, uint64_t out_cap) {
+    const uint32_t count = p.changed[IDX_MAX_PASSES - 1] < p.dirty_cap ? p.changed[IDX_MAX_PASSES - 1] : p.dirty_cap;
+    if (p.changed[IDX_MAX_PASSES - 1] > p.dirty_cap && blockIdx.x == 0 && threadIdx.x == 0) atomicExch(p.status, MHK_STATUS_CAPACITY);
+    const BitSrc src{p.payload, p.payload_bytes >> 2, p.payload_bytes};
+    const DecTables tabs{p.sec, p.tree, p.P, p.direct, p.H};
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < count; j += gridDim.x * blockDim.x) {
+        const uint64_t i = p.dirty_list[j];
+        const uint32_t pe = i ? uint32_t(p.e16[i - 1]) : (p.prev0 << 8);
+        const uint64_t seg_end = (i + 1) * IX_SEG_BITS < p.nbits ? (i + 1) * IX_SEG_BITS : p.nbits;
+        uint64_t pos = i * IX_SEG_BITS + (pe & 255u);
+        uint32_t prev = pe >> 8;
+        uint64_t base = p.tile_base[i / IX_TILE_SEGS];
+        for (uint64_t s = (i / IX_TILE_SEGS) * IX_TILE_SEGS; s < i; ++s) base += p.c16[s] & IX_C16_COUNT;
+        const uint32_t want = p.c16[i] & IX_C16_COUNT;
+        GranuleCursor bc;
+        bc.init(src, pos);
+        uint32_t k = 0;
+        bool bad = false;
+        while (pos < seg_end && k < want) {
+            uint32_t used = 0;
+            const uint32_t sym = decode_one(p.prim, p.sec_base, tabs, src, bc, prev, used, bad);
+            if (bad) break;
+            if (base + k < out_cap) out[base + k] = uint8_t(sym); else atomicExch(p.status, MHK_STATUS_CAPACITY);
+            prev = sym;
+            pos += used;
+            ++k;
+        }
+        const uint64_t over = pos - seg_end;
+        if (bad || pos < seg_end || k != want || uint32_t(p.e16[i]) != ((prev << 8) | uint32_t(over > 254 ? 254 : over))) atomicExch(p.status, MHK_STATUS_CORRUPT);
+    }
+}
+
 hipError_t launch_stream_emit(IdxParams p, void *d_ws, uint8_t *d_out, uint64_t out_cap, hipStream_t st) {
     unsigned char *ws = static_cast<unsigned char *>(d_ws);
     const IdxWs L = idx_ws_layout(p.nbits);
@@ -745,7 +787,15 @@ hipError_t launch_stream_emit(IdxParams p, void *d_ws, uint8_t *d_out, uint64_t 
     p.tile_cnt = reinterpret_cast<uint32_t *>(ws + L.off_tcnt);
     p.tile_base = reinterpret_cast<unsigned long long *>(ws + L.off_tbase);
     p.nseg5 = L.nseg5; p.ntile5 = L.ntile5;
-    return launch_segment_decode(p, d_out, out_cap, st);
+    p.dirty_list = reinterpret_cast<uint32_t *>(ws + L.off_dirty);
+    p.dirty_cap = uint32_t(L.dirty_cap < 0xFFFFFFFFull ? L.dirty_cap : 0xFFFFFFFFull);
+    const bool walks = p.max_len > p.tP + p.tH;                   // only such a model has segments for the walk
+    hipError_t e = walks ? hipMemsetAsync(p.changed + (IDX_MAX_PASSES - 1), 0, 4, st) : hipSuccess;
+    if (e != hipSuccess) return e;
+    e = launch_segment_decode(p, d_out, out_cap, st);
+    if (e != hipSuccess || !walks) return e;
+    hipLaunchKernelGGL(segment_walk_emit_kernel, dim3(64), dim3(256), 0, st, p, d_out, out_cap);
+    return hipGetLastError();
 }
 
 }  // namespace mhk

@@ -193,6 +193,10 @@ struct IdxParams {
 static_assert(MH_IX_SEG_DWORDS % 2 == 1 && MH_IX_SEG_DWORDS >= 5 && MH_IX_SEG_DWORDS <= 11, "an odd number of dwords; sixteen tiles must fit 96 KiB");
 constexpr uint32_t IX_SEG_BITS = 32u * MH_IX_SEG_DWORDS, IX_TILE_SEGS = 128, IX_TILE_BITS = IX_TILE_SEGS * IX_SEG_BITS, IX_WARM_BITS_MAX = 512;
 constexpr uint16_t IX_INVALID = 0xFFFF;
+// c16 (symbols that start in a segment): bits 0..14 the count, bit 15 = the segment holds a code longer than the tile tables'
+// two levels resolve (set by the repair kernel; the segment decoder leaves such a segment to a walk) [r5]
+constexpr uint32_t IX_C16_COUNT = 0x7FFFu, IX_C16_WALK = 0x8000u;
+constexpr uint32_t IDX_MAX_PASSES = 96;                  // pass counters in the index builder's workspace (`changed`)
 hipError_t launch_index_tile(const IdxParams &p, int mode, hipStream_t st);   // mode 0: states and counts, 1: the index entries
 // [r5] the segment decoder: the second pass over a stream without an index emits the bytes itself (e16 / c16 / tile_base set)
 hipError_t launch_segment_decode(const IdxParams &p, uint8_t *d_out, uint64_t out_cap, hipStream_t st);

@@ -535,7 +535,7 @@ __global__ __launch_bounds__(T_THREADS) void index_tile_kernel(IdxParams p) {
                 ctx[j] = pe >> 8;
                 q[j] = active[j] ? qb0[j] + (pe & 255u) : qb0[j];
                 want_e[j] = active[j] ? p.e16[seg[j]] : 0u;
-                want_c[j] = active[j] ? p.c16[seg[j]] : 0u;
+                want_c[j] = active[j] ? (p.c16[seg[j]] & IX_C16_COUNT) : 0u;
             }
         }
         if (MODE == 1) {                                          // symbol numbers: the tile's base + the counts of the segments in front
@@ -749,12 +749,13 @@ __global__ __launch_bounds__(T_THREADS) void segment_decode_kernel(IdxParams p, 
         // LDS operations of one wave execute in order: the reads below see the writes above
         uint64_t seg[K], base[K];
         uint32_t qe0[K], q[K], ctx[K], k[K], want_e[K], want_c[K], unres[K];
-        bool active[K], last[K];
+        bool active[K], last[K], skip[K];
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             seg[j] = t * IX_TILE_SEGS + uint32_t(j) * 64u + lane;
             const uint64_t b0 = seg[j] * IX_SEG_BITS;
             active[j] = b0 < p.nbits;
+            skip[j] = false;
             const uint64_t e0 = b0 + IX_SEG_BITS < p.nbits ? b0 + IX_SEG_BITS : p.nbits;
             last[j] = active[j] && e0 == p.nbits;
             const uint32_t qb0 = reg_bit0 + uint32_t(b0 - sb * 8u);
@@ -764,8 +765,16 @@ __global__ __launch_bounds__(T_THREADS) void segment_decode_kernel(IdxParams p, 
             ctx[j] = pe >> 8;
             q[j] = active[j] ? qb0 + (pe & 255u) : qb0;
             want_e[j] = active[j] ? p.e16[seg[j]] : 0u;
-            want_c[j] = active[j] ? p.c16[seg[j]] : 0u;
+            const uint32_t c = active[j] ? p.c16[seg[j]] : 0u;
+            want_c[j] = c & IX_C16_COUNT;
             k[j] = 0; unres[j] = DEC16_LEAF;
+            if (c & IX_C16_WALK) {                                // a code these tables do not resolve: the segment goes to the walk
+                const uint32_t slot = atomicAdd(&p.changed[IDX_MAX_PASSES - 1], 1u);      // (segment_walk_emit_kernel; its bytes keep their place in the prefix)
+                if (slot < p.dirty_cap) p.dirty_list[slot] = uint32_t(seg[j]);
+                active[j] = false;
+                q[j] = qe0[j];                                    // done at once; nothing of it is stored or checked here
+                skip[j] = true;
+            }
         }
         // output offsets: the tile's base + the counts of the segments in front
         bool fits = true;
@@ -857,7 +866,7 @@ __global__ __launch_bounds__(T_THREADS) void segment_decode_kernel(IdxParams p, 
             for (int j = 0; j < K; ++j) {
                 // bytes of this round that are the segment's: never past its converged count (a stream that does not belong
                 // to the table is reported below; it must not write into its neighbour's bytes)
-                const uint32_t have = k[j] < want_c[j] ? k[j] : want_c[j];
+                const uint32_t have = skip[j] ? 0u : (k[j] < want_c[j] ? k[j] : want_c[j]);
                 const uint32_t m = have > SD_ROUND * r ? (have - SD_ROUND * r < SD_ROUND ? have - SD_ROUND * r : SD_ROUND) : 0u;
 #ifdef MH_EXP_PROBES
                 if (p.iter & 1u) continue;                         // diagnostic library, MH_SEG_PROBE=1: no stores (output wrong): what the loop alone costs

@@ -199,3 +199,23 @@ def test_random_sources_through_both_passes(mhc, oracle, seed):
         assert (ns, st2) == (data.size, 0)
         assert np.array_equal(out[:data.size], data) and np.all(out[data.size:] == 0x5A)
     assert m.decompress(blob) == data.tobytes()
+
+
+@pytest.mark.parametrize("kind", ["REDO_LDS", "REDO_L2_DIRECT"])
+def test_codes_longer_than_the_tile_tables_resolve_go_to_the_walk(mhc, oracle, kind):
+    """Real files of some size have contexts with one-in-a-million successors: codes of 20 bits and more, which the tile tables
+    (first level 7 bits + second level of at most 8) do not resolve.  Their segments cannot be decoded by the states pass — they
+    are always listed, the repair kernel (general tables, tree walk) settles their state and marks them — and the segment
+    decoder leaves exactly those to a one-thread-per-segment walk; every other segment takes the fast way.  Models and data:
+    the chunk decoder's redo recipes (Fibonacci weights: codes of up to 25 bits, a few hundred of them planted in the data)."""
+    from test_gpu_decode_variants import recipe
+    counts, data = recipe(kind)
+    counts = counts.reshape(-1) + oracle.histogram_o1(data.tobytes()).astype(np.uint64)
+    om = oracle.Model.from_counts(counts, 1)
+    assert int(np.asarray(om.codes()[0]).max()) > 15
+    blob, nbits = om.compress(data.tobytes())
+    m = mhc.Model.from_table(om.table_bytes())
+    st1, path, ns, st2, out = stream_decode(mhc, m, blob[1:], nbits)
+    assert (st1, path, ns, st2) == (0, PATH_STATES, data.size, 0)
+    assert np.array_equal(out[:data.size], data) and np.all(out[data.size:] == 0x5A)
+    assert m.decompress(blob) == data.tobytes() and mhc.lib().mh_last_index_path() == PATH_STATES
