@@ -421,7 +421,7 @@ static IdxWs idx_ws_layout(uint64_t nbits) {
     w.off_start = up(w.off_count + size_t(w.nseg) * 4);
     w.off_blk = up(w.off_start + size_t(w.nseg) * 8);
     w.total = up(w.off_blk + size_t(w.nblk + 1) * 8);
-    // the fast path (index_tile_kernel): 6 bytes per 256-bit segment, a list of the segments to repair (a quarter of them at
+    // the fast path (index_tile_kernel): 6 bytes per IX_SEG_BITS-bit segment, a list of the segments to repair (a quarter of them at
     // most: beyond that the stream does not synchronise this way) and 12 bytes per tile, in the same space (one path runs at a time)
     w.nseg5 = (nbits + IX_SEG_BITS - 1) / IX_SEG_BITS;
     w.ntile5 = (w.nseg5 + IX_TILE_SEGS - 1) / IX_TILE_SEGS;

@@ -659,7 +659,7 @@ __global__ __launch_bounds__(T_THREADS) void index_tile_kernel(IdxParams p) {
 
 // ---- the segment decoder [r5] -----------------------------------------------------
 // A stream that came without any index used to be decoded THREE times: index_tile_kernel<0> (states), <1> (index entries),
-// then the tile decoder.  After the states pass and its repairs every 288-bit segment's entry state and symbol count are
+// then the tile decoder.  After the states pass and its repairs every segment's (IX_SEG_BITS bits) entry state and symbol count are
 // known, so a prefix sum gives the output offset of its first symbol and the second pass can emit the bytes itself: same
 // staging, same two streams per lane, same tables; a lane keeps the symbols of a round of 64 steps in registers (byte j of
 // the round = step j in every lane: static register indices) and writes its run to out[first symbol of the segment + 64

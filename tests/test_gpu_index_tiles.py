@@ -1,5 +1,5 @@
 """The index builder's fast path (mh_tile.hip index_tile_kernel): streams that come WITHOUT an index — what the
-reference writes, src/coding.cpp:35-59 — get chunk index and fine index from 64 adjacent 512-bit segments per wave.  Every case
+reference writes, src/coding.cpp:35-59 — get chunk index and fine index from 128 adjacent 352-bit segments per wave.  Every case
 compares with positions computed from the oracle's code lengths on the host; which way the index was built is asserted by
 path code (5 = tiles, 1 = the segment iteration it replaces), never by the clock."""
 import os

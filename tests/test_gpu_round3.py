@@ -204,7 +204,7 @@ def test_stream_without_an_index_decodes_through_the_tile_decoder(mhc, oracle):
     finally:
         del os.environ["MH_DECODE_PATH"]
         del os.environ["MH_DECODE_NO_STREAM"]
-    assert mhc.lib().mh_last_index_path() == 5              # the index builder's fast path (tiles of 288-bit segments)
+    assert mhc.lib().mh_last_index_path() == 5              # the index builder's fast path (tiles of 352-bit segments)
     assert out == data.tobytes()
     # device level: the fine index the builder wrote equals the one the encoder writes
     lib = mhc.lib()
