@@ -172,17 +172,58 @@ __global__ __launch_bounds__(256) void index_tile_repair_kernel(IdxParams p, uin
     p.s16[i] = uint16_t(pe == IX_INVALID ? 0xFFFEu : pe);              // (an end state is never IX_INVALID: its overshoot is under 255)
 }
 
-// symbols per tile of IX_TILE_SEGS segments (the input of the prefix sum): one wave per tile
-__global__ __launch_bounds__(256) void index_tile_count_kernel(IdxParams p) {
-    const uint64_t t = (uint64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t lane = threadIdx.x & 63u;
-    if (t >= p.ntile5) return;
-    uint32_t sum = 0;
-    const uint64_t s0 = t * IX_TILE_SEGS;
-    for (uint32_t j = lane; j < IX_TILE_SEGS; j += 64u) if (s0 + j < p.nseg5) sum += p.c16[s0 + j] & IX_C16_COUNT;
+// [r5] ... and from the second pass on only where something can have changed: a segment is out of order after a pass only if it
+// was repaired in that pass from a state that has changed meanwhile, or if its predecessor was (whose end state it must
+// follow).  So the next list is made from the previous one — one thread per entry checks the segment itself and its successor —
+// instead of reading all the segments' states again (1.1 GB per pass at 16 GiB: 0.39 ms each; a stream takes two or three
+// such passes, text six).  A segment can be listed twice (as itself and as its predecessor's successor): it is then repaired
+// twice to the same result.
+__global__ __launch_bounds__(256) void index_tile_dirty_next_kernel(IdxParams p, const uint32_t *prev_list, uint32_t prev_count) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    auto is_dirty = [&](uint64_t i) -> bool {
+        if (i >= p.nseg5) return false;
+        const uint32_t pe = i ? uint32_t(p.e16[i - 1]) : (p.prev0 << 8);
+        const uint32_t s = p.s16[i];
+        return s != pe || s == IX_INVALID;
+    };
+    uint64_t i = 0;
+    bool d0 = false, d1 = false;
+    if (j < prev_count) {
+        i = prev_list[j];
+        d0 = is_dirty(i);
+        d1 = is_dirty(i + 1);
+    }
+    const uint32_t mine = (d0 ? 1u : 0u) + (d1 ? 1u : 0u);
+    uint32_t inc = mine;                                          // one atomic per wave
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
-    if (lane == 0) p.tile_cnt[t] = sum;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if ((threadIdx.x & 63u) >= uint32_t(d)) inc += o; }
+    const uint32_t total = __shfl(inc, 63);
+    if (total == 0) return;
+    uint32_t at = 0;
+    if ((threadIdx.x & 63u) == 63u) at = atomicAdd(&p.changed[p.iter], total);
+    at = __shfl(at, 63) + inc - mine;
+    if (d0) { if (at < p.dirty_cap) p.dirty_list[at] = uint32_t(i); ++at; }
+    if (d1 && at < p.dirty_cap) p.dirty_list[at] = uint32_t(i + 1);
+}
+
+// symbols per tile of IX_TILE_SEGS segments (the input of the prefix sum): sixteen threads per tile, eight counts each
+__global__ __launch_bounds__(256) void index_tile_count_kernel(IdxParams p) {
+    static_assert(IX_TILE_SEGS == 128, "sixteen 16-byte vectors of counts per tile");
+    const uint32_t sub = threadIdx.x & 15u;
+    for (uint64_t t = (uint64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 4; t < ((p.ntile5 + 15u) & ~uint64_t(15)); t += (uint64_t(gridDim.x) * blockDim.x) >> 4) {
+        uint32_t sum = 0;
+        if (t < p.ntile5) {
+            const uint64_t s0 = t * IX_TILE_SEGS + sub * 8u;
+            const uint4 v = *reinterpret_cast<const uint4 *>(p.c16 + s0);      // (the array is 64-byte aligned and padded: mh_index.hip idx_ws_layout)
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (s0 + uint32_t(k) < p.nseg5) sum += (w[k >> 1] >> (16 * (k & 1))) & IX_C16_COUNT;
+        }
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+        if (sub == 0 && t < p.ntile5) p.tile_cnt[t] = sum;
+    }
 }
 
 // ---- streams the segment iteration cannot synchronise: fixed-length codes with context-dependent assignment
@@ -408,7 +449,7 @@ __global__ __launch_bounds__(64) void build_index_kernel(IdxParams p) {
 constexpr uint32_t IDX_SEG_BITS = 4096;
 constexpr uint32_t IDX_SEG_BITS_MIN = IDX_SEG_BITS - 64;       // smallest segment any gcd <= 64 gives (workspace sizing)
 struct IdxWs { size_t off_changed, off_end, off_used, off_count, off_start, off_blk, total; uint64_t nseg, nblk;
-               size_t off_e16, off_s16, off_c16, off_dirty, off_tcnt, off_tbase, off_tblk; uint64_t nseg5, ntile5, ntblk, dirty_cap; };
+               size_t off_e16, off_s16, off_c16, off_dirty, off_dirty2, off_tcnt, off_tbase, off_tblk; uint64_t nseg5, ntile5, ntblk, dirty_cap; };
 static IdxWs idx_ws_layout(uint64_t nbits) {
     IdxWs w;
     w.nseg = (nbits + IDX_SEG_BITS_MIN - 1) / IDX_SEG_BITS_MIN;  // capacity; the launch uses the model's segment length
@@ -430,8 +471,9 @@ static IdxWs idx_ws_layout(uint64_t nbits) {
     w.off_e16 = w.off_end;
     w.off_s16 = up(w.off_e16 + size_t(w.nseg5) * 2);
     w.off_c16 = up(w.off_s16 + size_t(w.nseg5) * 2);
-    w.off_dirty = up(w.off_c16 + size_t(w.nseg5) * 2);
-    w.off_tcnt = up(w.off_dirty + size_t(w.dirty_cap) * 4);
+    w.off_dirty = up(w.off_c16 + size_t(w.nseg5) * 2 + 64);       // (+ 64: the count kernel reads whole 16-byte vectors of counts)
+    w.off_dirty2 = up(w.off_dirty + size_t(w.dirty_cap) * 4);     // [r5] the lists of two consecutive passes
+    w.off_tcnt = up(w.off_dirty2 + size_t(w.dirty_cap) * 4);
     w.off_tbase = up(w.off_tcnt + size_t(w.ntile5) * 4);
     w.off_tblk = up(w.off_tbase + size_t(w.ntile5) * 8);
     const size_t total5 = up(w.off_tblk + size_t(w.ntblk + 1) * 8);
@@ -504,9 +546,14 @@ static hipError_t index_tile_states(const IdxParams &p, const IdxWs &L, unsigned
         if (e != hipSuccess) return e;
         unsigned int prev_dirty = ~0u;
         bool hopeless = false;
+        uint32_t *lists[2] = {reinterpret_cast<uint32_t *>(ws + L.off_dirty), reinterpret_cast<uint32_t *>(ws + L.off_dirty2)};
+        uint32_t which = 0;
         for (const uint32_t it_end = it + 24u; it < it_end && !ok && !hopeless; ++it) {
             q.iter = it;
-            hipLaunchKernelGGL(index_tile_dirty_kernel, dim3(dgrid), dim3(256), 0, st, q);
+            q.dirty_list = lists[which];
+            if (prev_dirty == ~0u) hipLaunchKernelGGL(index_tile_dirty_kernel, dim3(dgrid), dim3(256), 0, st, q);       // the first pass reads every segment's state
+            else hipLaunchKernelGGL(index_tile_dirty_next_kernel, dim3((prev_dirty + 255u) / 256u), dim3(256), 0, st, q, lists[which ^ 1u], prev_dirty);
+            which ^= 1u;
             unsigned int dirty = 1;
             e = hipMemcpyAsync(&dirty, q.changed + it, 4, hipMemcpyDeviceToHost, st);
             if (e != hipSuccess) return e;
@@ -523,7 +570,7 @@ static hipError_t index_tile_states(const IdxParams &p, const IdxWs &L, unsigned
     *ok_out = ok;
     if (ok) {
         unsigned long long *tblk = reinterpret_cast<unsigned long long *>(ws + L.off_tblk);
-        hipLaunchKernelGGL(index_tile_count_kernel, dim3(unsigned((q.ntile5 + 3) / 4)), dim3(256), 0, st, q);
+        { const uint64_t cw = (q.ntile5 + 15) / 16; hipLaunchKernelGGL(index_tile_count_kernel, dim3(unsigned(cw < 1 ? 1 : (cw > 8192 ? 8192 : cw))), dim3(256), 0, st, q); }
         (void)launch_scan_local(q.tile_cnt, q.ntile5, q.tile_base, tblk, st);
         (void)launch_scan_top(tblk, L.ntblk, nullptr, st);
         hipLaunchKernelGGL(index_scan_add_kernel, dim3(unsigned(L.ntblk)), dim3(SCAN_THREADS), 0, st, q.tile_base, tblk, q.ntile5, L.ntblk, q.n_symbols);
