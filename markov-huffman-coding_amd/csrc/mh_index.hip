@@ -551,7 +551,9 @@ static hipError_t index_tile_states(const IdxParams &p, const IdxWs &L, unsigned
         for (const uint32_t it_end = it + 24u; it < it_end && !ok && !hopeless; ++it) {
             q.iter = it;
             q.dirty_list = lists[which];
-            if (prev_dirty == ~0u) hipLaunchKernelGGL(index_tile_dirty_kernel, dim3(dgrid), dim3(256), 0, st, q);       // the first pass reads every segment's state
+            // the first pass reads every segment's state; so do the later ones while the list is long (runs of listed neighbours,
+            // as text has them, would be listed twice by the incremental form: 4 GiB of text 9.95 against 9.5 ms)
+            if (prev_dirty == ~0u || uint64_t(prev_dirty) * 64u > q.nseg5) hipLaunchKernelGGL(index_tile_dirty_kernel, dim3(dgrid), dim3(256), 0, st, q);
             else hipLaunchKernelGGL(index_tile_dirty_next_kernel, dim3((prev_dirty + 255u) / 256u), dim3(256), 0, st, q, lists[which ^ 1u], prev_dirty);
             which ^= 1u;
             unsigned int dirty = 1;
