@@ -591,7 +591,15 @@ hipError_t launch_build_index(IdxParams p, void *d_ws, hipStream_t st) {
     p.seg_count = reinterpret_cast<uint32_t *>(ws + L.off_count);
     p.seg_sym_start = reinterpret_cast<unsigned long long *>(ws + L.off_start);
     const uint32_t g = p.len_gcd >= 1 && p.len_gcd <= 64 ? p.len_gcd : 1;
-    p.seg_bits = IDX_SEG_BITS - IDX_SEG_BITS % g;
+    // [r5] On a code-length lattice (g > 1: fixed-length codes assigned by context — uniform bytes, base64 text) two decodes from
+    // different contexts merge only when they happen to produce the same symbol: 1/256 per step for random bytes, so a 512-symbol
+    // segment's end state still depends on its guess one time in seven and the iteration needs about ten passes.  Eight times
+    // the segment: the end state of 4096 symbols is independent of the guess but for one segment in 10^7.
+#ifndef MH_IDX_LATTICE_SEG_MULT
+#define MH_IDX_LATTICE_SEG_MULT 8
+#endif
+    const uint32_t seg_target = g > 1 ? IDX_SEG_BITS * MH_IDX_LATTICE_SEG_MULT : IDX_SEG_BITS;
+    p.seg_bits = seg_target - seg_target % g;
     p.nseg = (p.nbits + p.seg_bits - 1) / p.seg_bits;          // <= L.nseg
     hipError_t e = hipMemsetAsync(ws, 0, L.off_end, st);
     if (e != hipSuccess) return e;

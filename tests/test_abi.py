@@ -143,6 +143,17 @@ def test_compute_refuses_without_gpu(mhc):
     with pytest.raises(mhc.MhError) as e:
         m.decode(b"\x00", 8)
     assert e.value.status == mhc.MH_ERR_NO_DEVICE
+    # the device entry points of the two-pass stream decode (round 5): argument errors first, then no device — never a fallback
+    lib = mhc.lib()
+    buf = (ctypes.c_uint8 * 256)()
+    ns = ctypes.c_uint64()
+    p = ctypes.addressof(buf)
+    assert lib.mh_dev_decode_stream_states(None, p, 64, 0x20, ctypes.byref(ns), p, 256, None) == mhc.MH_ERR_ARG
+    assert lib.mh_dev_decode_stream_states(m.handle, p, 1 << 30, 0x20, ctypes.byref(ns), p, 256, None) == mhc.MH_ERR_CAPACITY   # workspace too small
+    ws = int(lib.mh_dev_build_index_workspace(64))
+    assert lib.mh_dev_decode_stream_states(m.handle, p, 64, 0x20, ctypes.byref(ns), p, ws, None) == mhc.MH_ERR_NO_DEVICE
+    assert lib.mh_dev_decode_stream_emit(m.handle, p, 64, 0x20, None, 16, p, ws, None) == mhc.MH_ERR_ARG
+    assert lib.mh_dev_decode_variant(None, None) == mhc.MH_ERR_ARG
 
 
 def test_cli_rejects_bad_chunk_sizes_before_touching_a_device(tmp_path):
