@@ -424,7 +424,8 @@ int mh_dev_build_index_fine(const mh_model *m, const uint8_t *d_payload, uint64_
  *   mh_dev_decode_stream_emit    pass 2: every segment is decoded once more from its true state and its bytes are written
  *       to d_out[offset of its first symbol ...); nothing is written at or beyond out_cap (MH_ERR_CAPACITY via mh_dev_status).
  *       End state and count of every segment must come out as converged and the stream must end exactly at nbits
- *       (src/coding.cpp:124,158): MH_ERR_CORRUPT otherwise.  No allocation, no synchronisation.
+ *       (src/coding.cpp:124,158): MH_ERR_CORRUPT otherwise.  No allocation; synchronises `stream` once, before its launch (it
+ *       reads the workspace's path word: MH_ERR_ARG when the workspace does not hold the states of this stream).
  * Workspace for both: mh_dev_build_index_workspace(nbits), the same buffer, untouched in between.
  */
 int mh_dev_decode_stream_states(const mh_model *m, const uint8_t *d_payload, uint64_t nbits, uint8_t prev0,

@@ -540,11 +540,7 @@ __global__ __launch_bounds__(1024) void hist2_reduce_kernel(const uint32_t *__re
 __global__ __launch_bounds__(1024) void hist2_total_kernel(const unsigned long long *__restrict__ counts, unsigned long long n, uint32_t *ctl) {
     __shared__ unsigned long long part[16];
     unsigned long long s = 0;
-    const ulonglong2 *c2 = reinterpret_cast<const ulonglong2 *>(counts);
-    for (size_t i = size_t(blockIdx.x) * 1024u + threadIdx.x; i < (size_t(1) << 23); i += size_t(gridDim.x) * 1024u) {
-        const ulonglong2 v = c2[i];
-        s += v.x + v.y;
-    }
+    for (size_t i = size_t(blockIdx.x) * 1024u + threadIdx.x; i < (size_t(1) << 24); i += size_t(gridDim.x) * 1024u) s += counts[i];   // (8-byte loads: the caller's array need not be 16-byte aligned)
 #pragma unroll
     for (int d = 32; d; d >>= 1) s += __shfl_down(s, d);
     if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = s;
