@@ -870,12 +870,6 @@ __global__ __launch_bounds__(T_THREADS) void segment_decode_kernel(IdxParams p, 
                 const uint32_t m = have > SD_ROUND * r ? (have - SD_ROUND * r < SD_ROUND ? have - SD_ROUND * r : SD_ROUND) : 0u;
 #ifdef MH_EXP_PROBES
                 if (p.iter & 1u) continue;                         // diagnostic library, MH_SEG_PROBE=1: no stores (output wrong): what the loop alone costs
-                if (p.iter & 6u) {                                 // MH_SEG_PROBE=2 / 4: every run stored from the 16- / 4-byte boundary below its start (output wrong): what does the alignment cost?
-                    uint8_t *d = out + base[j] + SD_ROUND * r;
-                    d = reinterpret_cast<uint8_t *>(reinterpret_cast<uintptr_t>(d) & ~uintptr_t((p.iter & 2u) ? 15 : 3));
-                    if (m) seg_store_run(d, Q[j], m);
-                    continue;
-                }
 #endif
                 if (m) seg_store_run(out + base[j] + SD_ROUND * r, Q[j], m);
             }
