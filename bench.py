@@ -287,9 +287,10 @@ def main():
     ap.add_argument("--size", type=int, default=None, help="bytes per GPU, weak scaling (default 16 GiB)")
     ap.add_argument("--total-size", type=int, default=None,
                     help="strong scaling: ONE stream of this many bytes split into N contiguous shards (e.g. 17179869184)")
-    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4],
+    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4, 5],
                     help="BASELINE.json configs[]: 3 (default) = 16 GiB Zipf(1.1) per GPU; 4 = uniform random, 8 GiB per GPU (64 GiB on 8); "
-                         "2 = 256 MiB of Lorem-Ipsum-style ASCII on one GPU (the reference's own benchmark size, README.md:174)")
+                         "2 = 256 MiB of Lorem-Ipsum-style ASCII on one GPU (the reference's own benchmark size, README.md:174); "
+                         "5 = order 2 on 16 GiB of that text, ONE stream split over the GPUs (extension: parity unpinned)")
     ap.add_argument("--kind", default=None, choices=["zipf", "uniform", "text"])
     ap.add_argument("--order", type=int, default=1, choices=[1, 2],
                     help="2 = order-2 contexts (BASELINE configs[4]; extension the reference does not have: parity unpinned; 1 GPU)")
@@ -334,9 +335,11 @@ def main():
     mhc.lib()                      # fails loudly if libmhc.so is missing: there is no fallback path
     import importlib
     sharded = importlib.import_module("mhc_amd.sharded")
-    kind = args.kind or {2: "text", 3: "zipf", 4: "uniform"}[args.config]
+    if args.config == 5:                                  # BASELINE configs[4]: order-2 contexts on 16 GiB of text (one stream, split N ways)
+        args.order = 2
+    kind = args.kind or {2: "text", 3: "zipf", 4: "uniform", 5: "text"}[args.config]
     # ---- what each rank holds: bytes [first, first + n) of ONE seeded stream
-    if args.total_size is None and args.size is None and world > 1 and args.config == 3 and args.order == 1:
+    if args.total_size is None and args.size is None and world > 1 and ((args.config == 3 and args.order == 1) or args.config == 5):
         # BASELINE.json's metric is ONE 16 GB stream at 1/2/4/8 GPUs: with no size given, N > 1 splits that stream
         # (strong scaling); --size keeps a fixed amount per GPU (weak scaling), --config 4 is 8 GiB per GPU by definition
         args.total_size = 16 << 30
@@ -346,7 +349,7 @@ def main():
         n = hi - first
     else:
         mode = "weak"
-        n = args.size if args.size is not None else {2: 256 << 20, 3: 16 << 30, 4: 8 << 30}[args.config]
+        n = args.size if args.size is not None else {2: 256 << 20, 3: 16 << 30, 4: 8 << 30, 5: 16 << 30}[args.config]
         first, total = rank * n, n * world
     global CHUNK
     if CHUNK == 0:
@@ -474,8 +477,9 @@ def main():
                         "chunk index every %d symbols%s" % (args.order, ("%d GiB" % (n >> 30)) if n >= 1 << 30 else ("%d MiB" % (n >> 20)),
                                                             kname, CHUNK, " [order 2: extension, parity unpinned]" if args.order == 2 else ""))
         else:
-            workload = ("order-1 Markov-Huffman round trip (histogram+tree+encode+decode), ONE %.3f GiB %s stream split into %d "
-                        "contiguous shards (strong scaling), chunk index every %d symbols" % (total / 2.0 ** 30, kname, world, CHUNK))
+            workload = ("order-%d Markov-Huffman round trip (histogram+tree+encode+decode), ONE %.3f GiB %s stream split into %d "
+                        "contiguous shards (strong scaling), chunk index every %d symbols%s" %
+                        (args.order, total / 2.0 ** 30, kname, world, CHUNK, " [order 2: extension, parity unpinned]" if args.order == 2 else ""))
         out = {
             "metric": "encode+decode GB/s on 16 GB byte stream, bit-exact round-trip",
             "value": round(gbps, 3), "unit": "GB/s", "n_gpus": world, "steps": K, "warmup": args.warmup,

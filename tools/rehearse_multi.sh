@@ -28,6 +28,7 @@ run weak_zipf_2g --size 2147483648
 run strong_zipf_4g --total-size 4294967296
 run config4_1g --config 4 --size 1073741824
 run order2_text_1g --order 2 --kind text --size 1073741824
+run config5_2x1g_strong --config 5 --total-size 2147483648      # [r5] BASELINE configs[4] as ONE stream split over the ranks
 
 run order2_text_1g_allreduce --order 2 --kind text --size 1073741824 --o2-exchange allreduce
 # ONE rank through the same N > 1 code path on the real backend (RCCL): process group, all-reduce, all-gather,
