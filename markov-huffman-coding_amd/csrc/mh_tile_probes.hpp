@@ -3,8 +3,10 @@
 // MH_EXP_PROBES and selects a form with MH_TILE_G.  Forms marked "output wrong" only measure what a step would cost.
 // Results: profiles/r05/decode_probes_4GiB.txt, DESIGN.md 3.3 [r5].
 //   1  no second level at all (output wrong): the floor of the loop
-//   2  the gather issued by lanes 0..15 only, 3 by lanes 0..31 (output wrong): does the texture addresser's time follow the
-//      ACTIVE lanes of an instruction, or the instruction?
+//   2  the gather issued by lanes 0..15 only (output wrong; with lanes 0..31, the first use of number 3: 4.51 ms, the same): does
+//      the texture addresser's time follow the ACTIVE lanes of an instruction, or the instruction?
+//   3  real (output right): the shipped gathers issued at raised wave priority (s_setprio 3 around them): does the order in which
+//      the CU's sixteen waves get their vector-memory instructions out matter?
 //   4  VERDICT r04 1(b), cost model (output wrong): the gather replaced by the two dependent LDS lookups an LDS-complete layout
 //      needs for a deep symbol (subtree shape -> rank, then the context's list of deep symbols), 59 KiB of the LDS set aside for
 //      those tables; 5 the same with the lanes that do not need them all reading one address (a broadcast, no bank conflict)
@@ -34,11 +36,11 @@ __device__ __forceinline__ void tile_second_probe(const uint32_t (&e)[K], const 
     if (G == 1) {
 #pragma unroll
         for (int k = 0; k < K; ++k) e2[k] = idx2[k] & 0u;
-    } else if (G == 2 || G == 3) {
+    } else if (G == 2) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             e2[k] = 0u;
-            if (lane < (G == 2 ? 16u : 32u)) e2[k] = probe_gather16(sec_rsrc, idx2[k]);
+            if (lane < 16u) e2[k] = probe_gather16(sec_rsrc, idx2[k]);
         }
     } else if (G == 4 || G == 5) {
         constexpr uint32_t BASE = (256u << P) * 2u;              // behind the first level: 4 KiB of "shapes", 55 KiB of "deep lists"
@@ -85,6 +87,26 @@ __device__ __forceinline__ void tile_second_probe(const uint32_t (&e)[K], const 
         if (nA && nB) g2 = probe_gather16(sec_rsrc, idx2[1]);
         e2[0] = nA ? g1 : 0u;
         e2[1] = nA ? g2 : g1;
+    } else if (G == 3) {
+        // MH_PRIO_MODE (compile time, make exp): 0 = priority 3 from before the gathers until their results are used (the first
+        // form measured: 40.8 ms against 4.45 — sixteen waves that all wait at top priority take turns); 1 = priority 3 for the
+        // ISSUE of the gathers only; 2 = priority 0 for the issue of the gathers, 2 for the rest of the step (the phases on the
+        // dependent chain: resolve, window, first level); 3 = the same with 1
+#ifndef MH_PRIO_MODE
+#define MH_PRIO_MODE 0
+#endif
+        uint32_t raw[K];
+        if (MH_PRIO_MODE == 0 || MH_PRIO_MODE == 1) __builtin_amdgcn_s_setprio(3);
+        else __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int k = 0; k < K; ++k) raw[k] = uint32_t(__builtin_amdgcn_raw_buffer_load_b16(sec_rsrc, int(idx2[k]), 0, 0));
+        if (MH_PRIO_MODE == 1) __builtin_amdgcn_s_setprio(0);
+        if (MH_PRIO_MODE == 2) __builtin_amdgcn_s_setprio(2);
+        if (MH_PRIO_MODE == 3) __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < K; ++k) e2[k] = raw[k] & 0xFFFFu;
+        if (MH_PRIO_MODE == 0) __builtin_amdgcn_s_setprio(0);
     } else {
 #pragma unroll
         for (int k = 0; k < K; ++k) e2[k] = probe_gather16(sec_rsrc, idx2[k]);
