@@ -1,142 +1,14 @@
-// mh_api.cpp — the C ABI of include/mh.h on top of the HIP kernels.  No CPU compute fallback: every
+// mh_api.cpp — the C ABI of include/mh.h on top of the HIP kernels: errors, device memory, staging, and the mh_dev_* compute
+// calls (device pointers + stream).  Models: mh_api_model.cpp; host-buffer calls: mh_api_host.cpp.  No CPU compute fallback: every
 // compute entry point needs a device and returns MH_ERR_NO_DEVICE without one.
-#include "../../include/mh.h"
+#include "mh_api_internal.hpp"
 
-#include <hip/hip_runtime.h>
-
-#include <chrono>
-#include <cstdio>
-#include <cstdlib>
-#include <algorithm>
-#include <atomic>
-#include <cstring>
-#include <mutex>
-#include <new>
-#include <thread>
-#include <vector>
-
-#include "mh_kernels.h"
-#include "mh_model.hpp"
-
-struct mh_model {
-    mh::Model host;              // host mirror of the trees (built lazily after a device build)
-    mh::Model::Packed packed;    // host-built images (empty after a device build)
-    int device = -1;
-    // what the entry points need without touching the mirror
-    int type = 1, max_len = 0, dec_bits = 8, dec_h = 0;   // type 2: order-2 contexts (extension, parity unpinned)
-    uint32_t nctx = 256;         // contexts the device tables are laid out for (65536 for type 2)
-    std::vector<uint8_t> table2; // type 2 loaded from a table file: the file itself (write_table returns it)
-    uint32_t len_gcd = 0;        // gcd of all code lengths (index builder: segment length is a multiple of it)
-    int min_len = 0;             // the shortest code of any context (0: no codes at all): a stream of nbits holds at most nbits / min_len symbols
-    bool dec_lds = true, dec_direct = false;
-    uint32_t nsec = 0;
-    // device build: node arrays stay on the device until somebody asks for the mirror
-    bool mirror_ready = true;
-    std::mutex mu;
-    void *d_build = nullptr;     // enc/dec images + node arrays + meta (device build)
-    bool build_cached = false;   // order 2: d_build goes back to the one-entry block cache when the model is freed
-    void *d_sec_own = nullptr;   // second-level tables (device build)
-    uint16_t *d_node_left = nullptr, *d_node_right = nullptr;
-    uint8_t *d_node_sym = nullptr;
-    uint32_t *d_meta = nullptr;
-    // device images (owned)
-    uint16_t *d_enc16 = nullptr;
-    uint8_t *d_len8 = nullptr;
-    uint8_t *d_len_slot = nullptr;
-    uint64_t *d_code64 = nullptr;
-    uint64_t *d_enc64 = nullptr;           // order 2: len << 56 | code (mhk::launch_enc64_pack), part of d_build
-    uint16_t *d_prim = nullptr;
-    uint16_t *d_sec = nullptr;
-    uint32_t *d_sec_base = nullptr;
-    uint32_t *d_tree = nullptr;
-    void *d_block = nullptr;     // the one allocation all of the above point into
-    // tile decoder tables (mh_tile.hip; LSB-first indexed; tile_p == 0: none)
-    int tile_p = 0, tile_h = 0;
-    uint32_t tile_nsec = 0;
-    uint16_t *d_tprim = nullptr, *d_tsec = nullptr;
-    void *d_tile_own = nullptr;  // their allocation when the model owns it
-    // order 2: tables of the live contexts, one slot each (dev_model_build2): the encoder's LDS image and the tile
-    // decoder's tables; o2_enc_ok / o2_dec_ok say whether they cover the model well enough to be used
-    void *d_o2hot = nullptr;     // one allocation: image | ctx2slot | slot_ctx | tprim | tsec
-    uint8_t *d_o2img = nullptr; uint32_t o2img_bytes = 0;
-    uint16_t *d_ctx2slot = nullptr;
-    uint32_t *d_tprim2 = nullptr, *d_tsec2 = nullptr;
-    uint32_t o2_nslots = 0, o2_p = 0, o2_h = 0, o2_nsec = 0;
-    bool o2_enc_ok = false, o2_dec_ok = false;
-};
-
-namespace {
+namespace mhapi {
 
 thread_local int g_last_hip = 0;
 thread_local int g_encode_retries = 0;    // segments of the calling thread's last mh_encode* that the one-pass order-2 encoder gave up on
 std::atomic<uint64_t> g_encode_retries_total{0};   // ... of all threads since the library was loaded
 thread_local int g_last_index_path = 0;   // how the calling thread's last index-free mh_decode* built its index (mh_last_index_path)
-
-int hip_fail(hipError_t e) {
-    g_last_hip = int(e);
-    return (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver) ? MH_ERR_NO_DEVICE : MH_ERR_HIP;
-}
-
-#define HIP_TRY(expr)                                   \
-    do {                                                \
-        hipError_t _e = (expr);                         \
-        if (_e != hipSuccess) return hip_fail(_e);      \
-    } while (0)
-
-bool have_device() {
-    int n = 0;
-    return hipGetDeviceCount(&n) == hipSuccess && n > 0;
-}
-
-bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-
-uint32_t gcd_u32(uint32_t a, uint32_t b) {
-    while (b) { const uint32_t t = a % b; a = b; b = t; }
-    return a;
-}
-
-// first-level width of the tile decoder's tables (mh_tile.hip): the LDS left beside 256 << P entries is what the
-// waves stage their input in, so P trades table hits against waves in flight.  MH_TILE_P overrides (5..8; 0: no
-// tile tables).
-int tile_p_choice() {                     // (read at every model build: tests vary it inside one process)
-    const char *e = getenv("MH_TILE_P");
-    const int p = e ? atoi(e) : 7;
-    return p == 0 ? 0 : (p < 5 ? 5 : (p > 8 ? 8 : p));
-}
-
-int chunk_shift_of(uint32_t chunk_symbols) {
-    if (chunk_symbols < MH_CHUNK_MIN || chunk_symbols > MH_CHUNK_MAX) return -1;
-    if (chunk_symbols & (chunk_symbols - 1)) return -1;
-    int s = 0;
-    while ((1u << s) != chunk_symbols) ++s;
-    return s;
-}
-
-int status_from_device(int s) {
-    switch (s) {
-        case mhk::MHK_STATUS_OK: return MH_OK;
-        case mhk::MHK_STATUS_TIMEOUT: return MH_ERR_TIMEOUT;
-        case mhk::MHK_STATUS_CAPACITY: return MH_ERR_CAPACITY;
-        default: return MH_ERR_CORRUPT;
-    }
-}
-
-// RAII device buffer for the host-buffer convenience calls
-// the shortest code of a device-built context from its meta record (mh_kernels.h, TB_META_STRIDE): mt[15] has bit l - 1 set
-// for every code length l in use, and is 0 for a one-symbol context, whose only code is one bit long (mt[2] = 1)
-static void note_min_len(mh_model *m, const uint32_t *mt) {
-    int l = 0;
-    if (mt[15]) l = __builtin_ctz(mt[15]) + 1;
-    else if (mt[2] >= 1) l = 1;
-    if (l && (m->min_len == 0 || l < m->min_len)) m->min_len = l;
-}
-
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
-    template <typename T> T *as() { return static_cast<T *>(p); }
-};
 
 // ---- pinned staging for the host-buffer calls ---------------------------------------
 // The callers' buffers are pageable (the CLI hands over mmapped files): a plain hipMemcpy from such memory
@@ -238,25 +110,6 @@ PinnedRing &ring_for_current_device() {
     return g_rings[ring_slot_for_device(dev)];
 }
 
-// MH_TIMING=1: the host-buffer calls account their time to three phases — upload (caller memory -> HBM, the page-cache
-// read of a mapped file included), device (kernels, waited for), download (HBM -> caller memory, the page faults of
-// a fresh file mapping included) — and print one stderr line per phase in the CLI's [mh-timing] format, so that
-// tools/cli_rate.py can tell the pipeline's rate from the file system's.  Each phase is waited for before the next
-// starts when timing is on (the calls overlap them otherwise).
-struct PhaseClock {
-    bool on = getenv("MH_TIMING") != nullptr;
-    double upload = 0, device = 0, download = 0;
-    size_t up_bytes = 0, down_bytes = 0;
-    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-    void report(const char *call, size_t n) const {
-        if (!on) return;
-        fprintf(stderr, "[mh-timing] %s.upload %zu bytes %.4f s %.2f GB/s\n", call, up_bytes, upload, upload > 0 ? up_bytes / upload / 1e9 : 0.0);
-        fprintf(stderr, "[mh-timing] %s.device %zu bytes %.4f s %.2f GB/s\n", call, n, device, device > 0 ? n / device / 1e9 : 0.0);
-        fprintf(stderr, "[mh-timing] %s.download %zu bytes %.4f s %.2f GB/s\n", call, down_bytes, download, download > 0 ? down_bytes / download / 1e9 : 0.0);
-        if (retries) fprintf(stderr, "[mh-timing] %s.retries %d (one-pass encoder timed out: segments encoded again with the two-pass pair)\n", call, retries);
-    }
-    int retries = 0;
-};
 thread_local PhaseClock *g_phase = nullptr;
 
 // small transfers keep the plain call (the ring pays from a few MiB on)
@@ -297,105 +150,24 @@ hipError_t stage_d2h(void *h_dst, const void *d_src, size_t n, hipStream_t st) {
     return e;
 }
 
-// Host tables are always built; the device images are uploaded when a device exists.  Without one the
-// model still answers table queries (mh_model_write_table, mh_model_get_code, ...) but every
-// compute call on it returns MH_ERR_NO_DEVICE.
-int upload_model(mh_model *m) {
-    m->packed = m->host.pack();
-    m->type = m->host.type;
-    m->max_len = m->packed.max_len;
-    m->dec_bits = m->packed.dec_bits; m->dec_h = m->packed.dec_h;
-    m->dec_lds = m->packed.dec_lds; m->dec_direct = m->packed.dec_direct;
-    m->nsec = uint32_t(m->packed.dec_sec.size());
-    // gcd of the code lengths, the 1-bit code of one-symbol contexts aside (src/huffman.cpp:154-162: such a
-    // context shifts the stream's phase once, it does not take the stream off the lattice of the others)
-    for (size_t i = 0; i < size_t(256) * 256; ++i) {
-        const int l = m->packed.len8[i];
-        if (l && (m->min_len == 0 || l < m->min_len)) m->min_len = l;
+// Host-buffer calls stage their data through HBM in segments, so their device footprint is bounded
+// whatever the input size (a 16 GiB file does not need 16 GiB + its worst-case payload on the card).
+// MH_SEGMENT_BYTES overrides the 256 MiB default (tests use small values to put seams everywhere).
+// The segment size is a multiple of the largest chunk size, so chunk boundaries fall on segment
+// boundaries.
+size_t segment_bytes() {
+    size_t s = size_t(256) << 20;
+    if (const char *e = getenv("MH_SEGMENT_BYTES")) {
+        const unsigned long long v = strtoull(e, nullptr, 10);
+        if (v) s = size_t(v);
     }
-    for (int c = 0; c < 256; ++c) {
-        int live = 0;
-        for (int sy = 0; sy < 256; ++sy) live += m->packed.len8[size_t(c) * 256 + sy] != 0;
-        if (live < 2) continue;
-        for (int sy = 0; sy < 256; ++sy) m->len_gcd = gcd_u32(m->len_gcd, m->packed.len8[size_t(c) * 256 + sy]);
-    }
-    if (!have_device()) return MH_OK;
-    if (m->max_len > mh::MAX_CODE_BITS) return MH_OK;   // compute calls report MH_ERR_CODE_TOO_LONG
-    HIP_TRY(hipGetDevice(&m->device));
-    const mh::Model::Packed &pk = m->packed;
-    // one device allocation and one upload for all images (each piece 256-byte aligned)
-    struct Piece { const void *src; size_t bytes; void **dst; };
-    const size_t sec_bytes = (pk.dec_sec.size() * 2 + 15) & ~size_t(15);     // kernels copy whole uint4s
-    const Piece pieces[] = {
-        {pk.enc16.data(), 65536 * 2, reinterpret_cast<void **>(&m->d_enc16)},
-        {pk.len8.data(), 65536, reinterpret_cast<void **>(&m->d_len8)},
-        {pk.len_slot.data(), 65536, reinterpret_cast<void **>(&m->d_len_slot)},
-        {pk.code64.data(), 65536 * 8, reinterpret_cast<void **>(&m->d_code64)},
-        {pk.tree.data(), size_t(256) * mh::TREE_STRIDE * 4, reinterpret_cast<void **>(&m->d_tree)},
-        {pk.dec_prim.data(), pk.dec_prim.size() * 2, reinterpret_cast<void **>(&m->d_prim)},
-        {pk.dec_sec.data(), pk.dec_sec.size() * 2, reinterpret_cast<void **>(&m->d_sec)},
-        {pk.sec_base.data(), 256 * 4, reinterpret_cast<void **>(&m->d_sec_base)},
-    };
-    size_t total = 0, off[8];
-    for (int i = 0; i < 8; ++i) { off[i] = total; total += ((i == 6 ? sec_bytes : pieces[i].bytes) + 255) & ~size_t(255); }
-    total += 256;
-    std::vector<unsigned char> staging(total, 0);
-    for (int i = 0; i < 8; ++i)
-        if (pieces[i].bytes) std::memcpy(staging.data() + off[i], pieces[i].src, pieces[i].bytes);
-    HIP_TRY(hipMalloc(&m->d_block, total));
-    HIP_TRY(hipMemcpy(m->d_block, staging.data(), total, hipMemcpyHostToDevice));
-    for (int i = 0; i < 8; ++i) *pieces[i].dst = static_cast<unsigned char *>(m->d_block) + off[i];
-    if (tile_p_choice()) {
-        const mh::Model::TilePacked tp = m->host.pack_tile(tile_p_choice());
-        if (tp.P) {
-            const size_t pb = (tp.prim.size() * 2 + 255) & ~size_t(255), sb = tp.sec.size() * 2 + 64;
-            HIP_TRY(hipMalloc(&m->d_tile_own, pb + sb));
-            HIP_TRY(hipMemset(m->d_tile_own, 0, pb + sb));
-            m->d_tprim = static_cast<uint16_t *>(m->d_tile_own);
-            m->d_tsec = reinterpret_cast<uint16_t *>(static_cast<unsigned char *>(m->d_tile_own) + pb);
-            HIP_TRY(hipMemcpy(m->d_tprim, tp.prim.data(), tp.prim.size() * 2, hipMemcpyHostToDevice));
-            if (!tp.sec.empty()) HIP_TRY(hipMemcpy(m->d_tsec, tp.sec.data(), tp.sec.size() * 2, hipMemcpyHostToDevice));
-            m->tile_p = tp.P; m->tile_h = tp.H; m->tile_nsec = uint32_t(tp.sec.size());
-        }
-    }
-    return MH_OK;
+    s &= ~size_t(MH_CHUNK_MAX - 1);
+    return s < MH_CHUNK_MAX ? size_t(MH_CHUNK_MAX) : s;
 }
 
-// After a device build the trees live in HBM only; table files and code/LUT queries need them on the
-// host.  Built once, on demand.
-int ensure_mirror(const mh_model *cm) {
-    mh_model *m = const_cast<mh_model *>(cm);
-    std::lock_guard<std::mutex> lock(m->mu);
-    if (m->mirror_ready) return MH_OK;
-    const size_t nn = size_t(256) * mhk::TB_NODE_STRIDE;
-    std::vector<uint16_t> left(nn), right(nn);
-    std::vector<uint8_t> sym(nn);
-    std::vector<uint32_t> meta(size_t(256) * mhk::TB_META_STRIDE);
-    HIP_TRY(hipMemcpy(left.data(), m->d_node_left, nn * 2, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(right.data(), m->d_node_right, nn * 2, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(sym.data(), m->d_node_sym, nn, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(meta.data(), m->d_meta, meta.size() * 4, hipMemcpyDeviceToHost));
-    m->host.type = 1;
-    m->host.ctx.assign(256, mh::ContextCoder{});
-    for (int c = 0; c < 256; ++c) {
-        const uint32_t *mt = &meta[size_t(c) * mhk::TB_META_STRIDE];
-        const int root = mt[1] == 0xFFFFFFFFu ? -1 : int(mt[1]);
-        m->host.ctx[c].adopt(int(mt[0]), root, &left[size_t(c) * mhk::TB_NODE_STRIDE], &right[size_t(c) * mhk::TB_NODE_STRIDE],
-                             &sym[size_t(c) * mhk::TB_NODE_STRIDE]);
-        m->host.ctx_weight[c] = (uint64_t(mt[14]) << 32) | mt[13];
-    }
-    m->mirror_ready = true;
-    return MH_OK;
-}
+}  // namespace mhapi
 
-int finish_model(mh_model *m, mh_model **out) {
-    int rc = upload_model(m);
-    if (rc != MH_OK) { mh_model_free(m); return rc; }
-    *out = m;
-    return MH_OK;
-}
-
-}  // namespace
+using namespace mhapi;
 
 extern "C" {
 
@@ -451,698 +223,6 @@ int mh_dev_download(void *h_dst, const void *d_src, size_t bytes) {
     if ((!h_dst || !d_src) && bytes) return MH_ERR_ARG;
     if (bytes) HIP_TRY(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
     return MH_OK;
-}
-
-/* ---------------------------------------------------------------- model */
-
-static int model2_from_host_counts(const uint64_t *counts, mh_model **out) {
-    if (!have_device()) return MH_ERR_NO_DEVICE;                 // the order-2 build has no host twin: it runs on the device
-    DevBuf d_counts;
-    HIP_TRY(d_counts.alloc((size_t(1) << 24) * 8));
-    HIP_TRY(hipMemcpy(d_counts.p, counts, (size_t(1) << 24) * 8, hipMemcpyHostToDevice));
-    return mh_dev_model_from_counts(d_counts.as<uint64_t>(), 2, nullptr, out);
-}
-
-int mh_model_from_counts(const uint64_t *counts, int order, mh_model **out) {
-    if (counts && out && order == 2) return model2_from_host_counts(counts, out);
-    if (!counts || !out || (order != 0 && order != 1)) return MH_ERR_ARG;
-    mh_model *m = new (std::nothrow) mh_model;
-    if (!m) return MH_ERR_NOMEM;
-    m->host.build_from_counts(counts, order);
-    return finish_model(m, out);
-}
-
-static int model_from_device_counts_via_host(const uint64_t *d_counts, int order, hipStream_t st, mh_model **out) {
-    size_t ncount = order ? 65536 : 256;
-    std::vector<uint64_t> counts(ncount);
-    HIP_TRY(hipMemcpyAsync(counts.data(), d_counts, ncount * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    return mh_model_from_counts(counts.data(), order, out);
-}
-
-// Fixed-size part of a device-built model: every image + the node arrays, each piece 256-byte aligned.
-namespace {
-// internal: dev_model_build met a model whose second-level tables need the general (non-uniform) L2 layout, which only
-// the host packer lays out (more than 32767 depth-8 inner nodes); never returned through the C ABI
-constexpr int BUILD_NEEDS_HOST = -1000;
-struct BuildLayout { size_t off[12], fixed; };
-BuildLayout build_layout() {
-    const size_t nn = size_t(256) * mhk::TB_NODE_STRIDE;
-    const size_t sizes[12] = {65536 * 2, 65536, 65536, 65536 * 8, size_t(256) * mh::TREE_STRIDE * 4, 65536 * 2, 256 * 4,
-                              nn * 2, nn * 2, nn, nn, size_t(256) * mhk::TB_META_STRIDE * 4};
-    BuildLayout L;
-    size_t total = 0;
-    for (int i = 0; i < 12; ++i) { L.off[i] = total; total += (sizes[i] + 255) & ~size_t(255); }
-    L.fixed = total;
-    return L;
-}
-// second-level tables: at most 32767 uniform tables of 256 entries in the L2 layout (far less in the LDS layout)
-constexpr size_t MODEL_WS_SEC_BYTES = size_t(32768) * 256 * 2 + 64;
-// the tile decoder's tables: a first level of at most 256 << 8 entries, at most 32768 second-level tables of 256
-constexpr size_t MODEL_WS_TILE_BYTES = size_t(65536) * 2 + 256 + size_t(32768) * 256 * 2 + 64 + 512;
-
-// d_ws == nullptr: the model allocates (and owns) its device memory.  Otherwise it lives in the caller's
-// workspace: no allocation, and the stream is synchronised exactly once (16 KiB of table sizes come back
-// so that the host can pick the decode-table layout).
-int dev_model_build(const uint64_t *d_counts, void *d_ws, size_t ws_bytes, hipStream_t st, mh_model **out) {
-    mh_model *m = new (std::nothrow) mh_model;
-    if (!m) return MH_ERR_NOMEM;
-    m->type = 1;
-    m->mirror_ready = false;
-    auto fail = [&](int rc) { mh_model_free(m); return rc; };
-#define HIP_TRY_M(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(hip_fail(_e)); } while (0)
-    HIP_TRY_M(hipGetDevice(&m->device));
-    const BuildLayout L = build_layout();
-    unsigned char *b;
-    if (d_ws) {
-        if (!aligned16(d_ws) || ws_bytes < L.fixed + 64) return fail(MH_ERR_CAPACITY);
-        b = static_cast<unsigned char *>(d_ws);
-    } else {
-        HIP_TRY_M(hipMalloc(&m->d_build, L.fixed));
-        b = static_cast<unsigned char *>(m->d_build);
-    }
-    const size_t *off = L.off;
-    m->d_enc16 = reinterpret_cast<uint16_t *>(b + off[0]);
-    m->d_len8 = b + off[1];
-    m->d_len_slot = b + off[2];
-    m->d_code64 = reinterpret_cast<uint64_t *>(b + off[3]);
-    m->d_tree = reinterpret_cast<uint32_t *>(b + off[4]);
-    m->d_prim = reinterpret_cast<uint16_t *>(b + off[5]);
-    m->d_sec_base = reinterpret_cast<uint32_t *>(b + off[6]);
-    m->d_node_left = reinterpret_cast<uint16_t *>(b + off[7]);
-    m->d_node_right = reinterpret_cast<uint16_t *>(b + off[8]);
-    m->d_node_sym = b + off[9];
-    uint8_t *d_node_height = b + off[10];
-    m->d_meta = reinterpret_cast<uint32_t *>(b + off[11]);
-
-    mhk::TreeBuildOut tb{m->d_len8, reinterpret_cast<unsigned long long *>(m->d_code64), m->d_enc16, m->d_len_slot,
-                         m->d_node_left, m->d_node_right, m->d_node_sym, d_node_height, m->d_meta, 8u};
-    HIP_TRY_M(mhk::launch_tree_build(reinterpret_cast<const unsigned long long *>(d_counts), 256, tb, st));
-    // (a pinned landing place, one per thread, kept for the life of the process — 16 KiB; freeing it from a destructor at exit
-    // would call into a runtime that may already be gone: a copy into pageable memory is staged by the runtime)
-    struct PinnedMeta { uint32_t *p = nullptr; };
-    static thread_local PinnedMeta pinned;
-    const size_t meta_words = size_t(256) * mhk::TB_META_STRIDE;
-    std::vector<uint32_t> meta_pageable;
-    if (!pinned.p && hipHostMalloc(reinterpret_cast<void **>(&pinned.p), meta_words * 4, hipHostMallocDefault) != hipSuccess) {
-        (void)hipGetLastError();
-        pinned.p = nullptr;
-    }
-    if (!pinned.p) meta_pageable.resize(meta_words);
-    uint32_t *meta = pinned.p ? pinned.p : meta_pageable.data();
-    HIP_TRY_M(hipMemcpyAsync(meta, m->d_meta, meta_words * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY_M(hipStreamSynchronize(st));                      // 16 KiB of sizes: the one sync of this call
-
-    // same layout rule as mh::Model::pack()
-    size_t tot[9] = {0}, worst[9] = {0}, ntab8 = 0;
-    uint64_t weight[256];
-    for (int c = 0; c < 256; ++c) {
-        const uint32_t *mt = &meta[size_t(c) * mhk::TB_META_STRIDE];
-        m->max_len = std::max(m->max_len, int(mt[2]));
-        note_min_len(m, mt);
-        // mt[15]: bit l-1 = a code of l bits exists (bit 31: 32 or more); one-symbol contexts aside, as in upload_model()
-        for (uint32_t l = 1; l <= 32; ++l)
-            if (mt[15] & (1u << (l - 1))) m->len_gcd = gcd_u32(m->len_gcd, l == 32 ? 1u : l);
-        ntab8 += mt[3];
-        for (int P = 0; P < 9; ++P) { tot[P] += mt[4 + P]; worst[P] = std::max(worst[P], size_t(mt[4 + P])); }
-        weight[c] = (uint64_t(mt[14]) << 32) | mt[13];
-    }
-    if (m->max_len > mh::MAX_CODE_BITS) { *out = m; return MH_OK; }   // compute calls report MH_ERR_CODE_TOO_LONG
-    int P = 0;
-    for (int q = 8; q >= 4 && !P; --q)
-        if (worst[q] <= size_t(mh::DEC_SEC_MAX_PER_CTX) && (size_t(256) << q) + tot[q] <= size_t(mh::DEC_LDS_ENTRIES)) P = q;
-    m->dec_lds = P != 0;
-    if (!m->dec_lds) {
-        if (ntab8 > 32767) return fail(BUILD_NEEDS_HOST);         // general L2 layout: rare; the caller lets the host do it
-        P = 8;
-        m->dec_direct = true;
-        m->dec_h = std::min(std::max(m->max_len - 8, 1), 8);
-    }
-    m->dec_bits = P;
-    int order_idx[256];
-    for (int i = 0; i < 256; ++i) order_idx[i] = i;
-    std::stable_sort(order_idx, order_idx + 256, [&](int a, int b2) { return weight[a] > weight[b2]; });
-    mhk::TreePackArgs pa{};
-    size_t nsec = 0;
-    for (int i = 0; i < 256; ++i) {
-        const int c = order_idx[i];
-        const uint32_t *mt = &meta[size_t(c) * mhk::TB_META_STRIDE];
-        pa.sec_base_val[c] = uint32_t(nsec);                     // travels in the kernel arguments: no pageable copy to wait for
-        nsec += m->dec_direct ? (size_t(mt[3]) << m->dec_h) : size_t(mt[4 + P]);
-    }
-    m->nsec = uint32_t(nsec);
-    const size_t sec_bytes = ((nsec * 2 + 15) & ~size_t(15)) + 16;
-    if (d_ws) {
-        if (ws_bytes < L.fixed + sec_bytes) return fail(MH_ERR_CAPACITY);
-        m->d_sec = reinterpret_cast<uint16_t *>(b + L.fixed);
-    } else {
-        HIP_TRY_M(hipMalloc(&m->d_sec_own, sec_bytes));
-        m->d_sec = static_cast<uint16_t *>(m->d_sec_own);
-    }
-    HIP_TRY_M(hipMemsetAsync(m->d_sec, 0, sec_bytes, st));
-    pa.node_left = m->d_node_left; pa.node_right = m->d_node_right; pa.node_sym = m->d_node_sym; pa.node_height = d_node_height;
-    pa.ctx_meta = m->d_meta; pa.sec_base = m->d_sec_base;
-    pa.P = uint32_t(P); pa.direct = m->dec_direct ? 1u : 0u; pa.H = uint32_t(m->dec_h); pa.hcap = 8u;
-    pa.prim = m->d_prim; pa.sec = m->d_sec; pa.tree = m->d_tree;
-    bool packed = false;                                      // (the tile tables' packing below takes this one along: one launch)
-    // ---- the tile decoder's tables: the same trees packed once more, LSB-first, with a first level of tile_p bits
-    if (const int tP = tile_p_choice()) {
-        const int tH = std::min(std::max(m->max_len - tP, 1), 8);
-        size_t ntab = size_t(256) << tP;
-        mhk::TreePackArgs pt{};
-        if (tP == 8) {
-            ntab = 0;
-            for (int c = 0; c < 256; ++c) { pt.sec_base_val[c] = uint32_t(ntab << tH); ntab += meta[size_t(c) * mhk::TB_META_STRIDE + 3]; }
-        } else {
-            for (int c = 0; c < 256; ++c) pt.sec_base_val[c] = uint32_t(size_t(c) << (tP + tH));
-        }
-        if (ntab <= 32767 || tP < 8) {
-            const size_t pb = ((size_t(256) << tP) * 2 + 255) & ~size_t(255), sb = (ntab << tH) * 2 + 64;
-            unsigned char *tb;
-            if (d_ws) {
-                const size_t at = (L.fixed + sec_bytes + 255) & ~size_t(255);
-                if (ws_bytes < at + pb + sb) return fail(MH_ERR_CAPACITY);
-                tb = b + at;
-            } else {
-                HIP_TRY_M(hipMalloc(&m->d_tile_own, pb + sb));
-                tb = static_cast<unsigned char *>(m->d_tile_own);
-            }
-            m->d_tprim = reinterpret_cast<uint16_t *>(tb);
-            m->d_tsec = reinterpret_cast<uint16_t *>(tb + pb);
-            HIP_TRY_M(hipMemsetAsync(m->d_tsec, 0, sb, st));
-            pt.node_left = m->d_node_left; pt.node_right = m->d_node_right; pt.node_sym = m->d_node_sym; pt.node_height = d_node_height;
-            pt.ctx_meta = m->d_meta; pt.sec_base = nullptr; pt.sec_base_in = nullptr;
-            pt.P = uint32_t(tP); pt.direct = 1u; pt.H = uint32_t(tH); pt.hcap = 8u;
-            pt.prim = m->d_tprim; pt.sec = m->d_tsec; pt.tree = nullptr; pt.lsb = 1u;
-            HIP_TRY_M(mhk::launch_tree_pack2(pa, pt, 256, st));
-            packed = true;
-            m->tile_p = tP; m->tile_h = tH; m->tile_nsec = uint32_t(ntab << tH);
-        }
-    }
-    if (!packed) HIP_TRY_M(mhk::launch_tree_pack(pa, 256, st));
-#undef HIP_TRY_M
-    *out = m;
-    return MH_OK;
-}
-}  // namespace
-
-// ---- order 2 (extension; parity unpinned: the spec is the generalised oracle, oracle/mh_oracle.h) ----------
-namespace {
-constexpr uint32_t O2_CTX = 65536;
-constexpr uint32_t O2_HCAP = 4;          // second-level tables of at most 16 entries: <= 4096 entries per context
-const unsigned char O2_MAGIC[4] = {'M', 'H', '2', 1};
-
-bool is_o2_table(const uint8_t *b, size_t n) {
-    if (n < 37 || b[0] != 0x80) return false;
-    for (int i = 1; i < 33; ++i) if (b[i]) return false;
-    return std::memcmp(b + 33, O2_MAGIC, 4) == 0;
-}
-
-struct Build2Layout { size_t off[12], total; };
-Build2Layout build2_layout() {
-    const size_t nn = size_t(O2_CTX) * mhk::TB_NODE_STRIDE, ne = size_t(O2_CTX) * 256;
-    const size_t sizes[12] = {ne, ne * 8, ne * 4, ne * 2, size_t(O2_CTX) * 4, nn * 2, nn * 2, nn, nn, size_t(O2_CTX) * mhk::TB_META_STRIDE * 4, 256, ne * 8};
-    Build2Layout L;
-    size_t total = 0;
-    for (int i = 0; i < 12; ++i) { L.off[i] = total; total += (sizes[i] + 255) & ~size_t(255); }
-    L.total = total;
-    return L;
-}
-
-void place2(mh_model *m, unsigned char *b, const Build2Layout &L, uint8_t **node_height) {
-    m->d_len8 = b + L.off[0];
-    m->d_code64 = reinterpret_cast<uint64_t *>(b + L.off[1]);
-    m->d_tree = reinterpret_cast<uint32_t *>(b + L.off[2]);
-    m->d_prim = reinterpret_cast<uint16_t *>(b + L.off[3]);
-    m->d_sec_base = reinterpret_cast<uint32_t *>(b + L.off[4]);
-    m->d_node_left = reinterpret_cast<uint16_t *>(b + L.off[5]);
-    m->d_node_right = reinterpret_cast<uint16_t *>(b + L.off[6]);
-    m->d_node_sym = b + L.off[7];
-    *node_height = b + L.off[8];
-    m->d_meta = reinterpret_cast<uint32_t *>(b + L.off[9]);
-    m->d_enc64 = reinterpret_cast<uint64_t *>(b + L.off[11]);
-}
-
-// The live contexts' tables: slots for the heaviest live contexts whose two bytes are both among the 63 most frequent
-// byte values (ids 0..62; everything else is id 63 = escape).  Encoder image and tile-decoder tables are filled on the
-// device (o2_hot_pack_kernel); the host only ranks (it holds every context's weight after the build's one sync).
-//   o2_enc_ok: the slots carry all but 1e-5 of the input (an escape costs a whole wave sub-step the slow path)
-//   o2_dec_ok: EVERY live context has a slot (the decoder follows slot -> slot and has no other path)
-constexpr uint32_t O2_SLOTS_MAX = 440;   // (440 + 1) rows of 128 B + 8448 B of maps = 64896 B <= the length pass's 64 KiB of LDS
-constexpr uint32_t O2_TILE_P = 6;
-int o2_hot_setup(mh_model *m, const std::vector<uint64_t> &weight, const std::vector<uint8_t> &live, const uint8_t *, hipStream_t st) {
-    if (getenv("MH_O2_NO_HOT")) return MH_OK;
-    uint64_t bw[256] = {0};
-    long double total = 0;
-    uint32_t nlive = 0;
-    for (uint32_t c = 0; c < O2_CTX; ++c) {
-        if (!live[c]) continue;
-        ++nlive;
-        const uint64_t w = weight[c] ? weight[c] : 1;              // (a model from a table file has no weights)
-        bw[c >> 8] += w; bw[c & 255u] += w;
-        total += w;
-    }
-    if (nlive == 0) return MH_OK;
-    int order[256];
-    for (int i = 0; i < 256; ++i) order[i] = i;
-    std::stable_sort(order, order + 256, [&](int a, int b) { return bw[a] > bw[b]; });
-    uint8_t symid[256];
-    std::memset(symid, 63, sizeof symid);
-    mhk::O2HotArgs a{};
-    for (int i = 0; i < 63; ++i)
-        if (bw[order[i]]) { symid[order[i]] = uint8_t(i); a.id_sym[i] = uint8_t(order[i]); a.id_used[i] = 1; }
-    std::vector<uint32_t> cand;
-    for (uint32_t c = 0; c < O2_CTX; ++c)
-        if (live[c] && symid[c >> 8] < 63 && symid[c & 255u] < 63) cand.push_back(c);
-    std::stable_sort(cand.begin(), cand.end(), [&](uint32_t x, uint32_t y) { return weight[x] > weight[y]; });
-    const uint32_t nslots = uint32_t(std::min<size_t>(cand.size(), O2_SLOTS_MAX));
-    if (nslots == 0) return MH_OK;
-    long double covered = 0;
-    std::vector<uint16_t> slot_ctx(nslots), ctx2slot(O2_CTX, 0xFFFF);
-    std::vector<uint8_t> slot_id1(nslots);
-    std::vector<unsigned char> head(8448, 0);                      // symid | ctxmap
-    std::memcpy(head.data(), symid, 256);
-    uint16_t *ctxmap = reinterpret_cast<uint16_t *>(head.data() + 256);
-    for (int i = 0; i < 64 * 64; ++i) ctxmap[i] = uint16_t(nslots);    // the all-escape row
-    for (uint32_t s = 0; s < nslots; ++s) {
-        const uint32_t c = cand[s];
-        slot_ctx[s] = uint16_t(c);
-        slot_id1[s] = symid[c & 255u];
-        ctx2slot[c] = uint16_t(s);
-        ctxmap[(uint32_t(symid[c >> 8]) << 6) | (symid[c & 255u] ^ symid[c >> 8])] = uint16_t(s);   // column XOR-ed with the row's id (bank spreading)
-        covered += weight[c] ? weight[c] : 1;
-    }
-    const bool all_hot = nslots == nlive;
-    const uint32_t P = O2_TILE_P, H = uint32_t(std::min(std::max(m->max_len - int(P), 1), 8));
-    const bool tiles = all_hot && m->d_node_left != nullptr;
-    const size_t img = 8448 + size_t(nslots + 1) * 128;
-    auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
-    const size_t off_map = up(img), off_sc = off_map + up(size_t(O2_CTX) * 2), off_s1 = off_sc + up(size_t(nslots) * 2), off_tp = off_s1 + up(nslots);
-    const size_t off_ts = off_tp + (tiles ? up((size_t(nslots) << P) * 4) : 0);
-    const size_t nsec = tiles ? ((size_t(nslots) << P) << H) : 0;
-    const size_t tot = off_ts + up(nsec * 4 + 64);
-    HIP_TRY(hipMalloc(&m->d_o2hot, tot));
-    unsigned char *b = static_cast<unsigned char *>(m->d_o2hot);
-    HIP_TRY(hipMemsetAsync(b + off_ts, 0, up(nsec * 4 + 64), st));
-    HIP_TRY(hipMemcpyAsync(b, head.data(), head.size(), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(b + off_map, ctx2slot.data(), size_t(O2_CTX) * 2, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(b + off_sc, slot_ctx.data(), size_t(nslots) * 2, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(b + off_s1, slot_id1.data(), size_t(nslots), hipMemcpyHostToDevice, st));
-    a.slot_ctx = reinterpret_cast<const uint16_t *>(b + off_sc); a.nslots = nslots;
-    a.slot_id1 = b + off_s1;
-    a.len8 = m->d_len8; a.code64 = reinterpret_cast<const unsigned long long *>(m->d_code64);
-    a.hot = reinterpret_cast<uint16_t *>(b + 8448);
-    a.ctx2slot = reinterpret_cast<const uint16_t *>(b + off_map);
-    a.P = P; a.H = H;
-    if (tiles) {
-        a.node_left = m->d_node_left; a.node_right = m->d_node_right; a.node_sym = m->d_node_sym; a.ctx_meta = m->d_meta;
-        a.tprim = reinterpret_cast<uint32_t *>(b + off_tp); a.tsec = reinterpret_cast<uint32_t *>(b + off_ts);
-    }
-    HIP_TRY(mhk::launch_o2_hot_pack(a, st));
-    HIP_TRY(hipStreamSynchronize(st));                            // the staging vectors above are on this frame (the caller syncs next anyway: the wait is paid once)
-    m->d_o2img = b; m->o2img_bytes = uint32_t(img);
-    m->d_ctx2slot = reinterpret_cast<uint16_t *>(b + off_map);
-    m->o2_nslots = nslots; m->o2_p = P; m->o2_h = H; m->o2_nsec = uint32_t(nsec);
-    m->d_tprim2 = tiles ? a.tprim : nullptr; m->d_tsec2 = tiles ? a.tsec : nullptr;
-    m->o2_enc_ok = covered >= total * (1.0L - 1e-5L);
-    m->o2_dec_ok = tiles;
-    return MH_OK;
-}
-
-// Order-2 model build in two steps, so that G ranks can share it (reduce-scatter of the 1 << 24 counts,
-// every rank builds the trees of its 65536 / G contexts, all-gather of the per-context arrays):
-//   build2_slice   trees, code lengths, codewords and node arrays of contexts [c0, c1) from their counts, written to
-//                  their place in the (caller's or the model's own) workspace — every array is laid out by context, so
-//                  a rank's share of each is ONE contiguous range that a collective can gather in place
-//   build2_finish  with all 65536 contexts in place: the packed encoder entries, the decode tables, the live contexts'
-//                  LDS tables; one sync for the 4 MiB of per-context sizes
-int build2_slice(const uint64_t *d_counts_slice, uint32_t c0, uint32_t c1, unsigned char *b, hipStream_t st) {
-    if (c0 >= c1 || c1 > O2_CTX) return MH_ERR_ARG;
-    const Build2Layout L = build2_layout();
-    mhk::TreeBuildOut tb{b + L.off[0] + size_t(c0) * 256, reinterpret_cast<unsigned long long *>(b + L.off[1]) + size_t(c0) * 256, nullptr, nullptr,
-                         reinterpret_cast<uint16_t *>(b + L.off[5]) + size_t(c0) * mhk::TB_NODE_STRIDE,
-                         reinterpret_cast<uint16_t *>(b + L.off[6]) + size_t(c0) * mhk::TB_NODE_STRIDE,
-                         b + L.off[7] + size_t(c0) * mhk::TB_NODE_STRIDE, b + L.off[8] + size_t(c0) * mhk::TB_NODE_STRIDE,
-                         reinterpret_cast<uint32_t *>(b + L.off[9]) + size_t(c0) * mhk::TB_META_STRIDE, O2_HCAP};
-    HIP_TRY(mhk::launch_tree_build(reinterpret_cast<const unsigned long long *>(d_counts_slice), int(c1 - c0), tb, st));
-    return MH_OK;
-}
-
-int build2_finish(unsigned char *b, bool owned, hipStream_t st, mh_model **out) {
-    mh_model *m = new (std::nothrow) mh_model;
-    if (!m) return MH_ERR_NOMEM;
-    m->type = 2; m->nctx = O2_CTX; m->mirror_ready = false;
-    m->dec_bits = 8; m->dec_lds = false; m->dec_direct = false; m->dec_h = 0;
-    if (owned) { m->d_build = b; m->build_cached = true; }
-    auto fail = [&](int rc) { mh_model_free(m); return rc; };
-#define HIP_TRY_M(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(hip_fail(_e)); } while (0)
-    HIP_TRY_M(hipGetDevice(&m->device));
-    const Build2Layout L = build2_layout();
-    uint8_t *d_node_height = nullptr;
-    place2(m, b, L, &d_node_height);
-    HIP_TRY_M(mhk::launch_enc64_pack(m->d_len8, m->d_code64, m->d_enc64, uint64_t(O2_CTX) * 256, st));
-    std::vector<uint32_t> meta(size_t(O2_CTX) * mhk::TB_META_STRIDE);
-    HIP_TRY_M(hipMemcpyAsync(meta.data(), m->d_meta, meta.size() * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY_M(hipStreamSynchronize(st));
-    std::vector<uint32_t> sec_base(O2_CTX);
-    size_t nsec = 0;
-    uint32_t lenmask = 0;                                         // union of the contexts' code-length sets (gcd of a union = gcd of its members)
-    for (uint32_t c = 0; c < O2_CTX; ++c) {
-        const uint32_t *mt = &meta[size_t(c) * mhk::TB_META_STRIDE];
-        m->max_len = std::max(m->max_len, int(mt[2]));
-        note_min_len(m, mt);
-        lenmask |= mt[15];
-        sec_base[c] = uint32_t(nsec);
-        nsec += mt[4 + 8];                                        // tables under the depth-8 nodes, heights capped at O2_HCAP
-    }
-    for (uint32_t l = 1; l <= 32; ++l)
-        if (lenmask & (1u << (l - 1))) m->len_gcd = gcd_u32(m->len_gcd, l == 32 ? 1u : l);
-    if (nsec > 0xFFFFFFFFull - 4096) return fail(MH_ERR_CAPACITY);
-    m->nsec = uint32_t(nsec);
-    if (m->max_len > mh::MAX_CODE_BITS) { *out = m; return MH_OK; }
-    const size_t sec_bytes = ((nsec * 2 + 15) & ~size_t(15)) + 16;
-    HIP_TRY_M(hipMalloc(&m->d_sec_own, sec_bytes));
-    m->d_sec = static_cast<uint16_t *>(m->d_sec_own);
-    HIP_TRY_M(hipMemsetAsync(m->d_sec_own, 0, sec_bytes, st));
-    HIP_TRY_M(hipMemcpyAsync(m->d_sec_base, sec_base.data(), size_t(O2_CTX) * 4, hipMemcpyHostToDevice, st));
-    mhk::TreePackArgs pa{};
-    pa.node_left = m->d_node_left; pa.node_right = m->d_node_right; pa.node_sym = m->d_node_sym; pa.node_height = d_node_height;
-    pa.ctx_meta = m->d_meta; pa.sec_base = m->d_sec_base; pa.sec_base_in = m->d_sec_base;
-    pa.P = 8; pa.direct = 0; pa.H = 0; pa.hcap = O2_HCAP;
-    pa.prim = m->d_prim; pa.sec = m->d_sec; pa.tree = m->d_tree;
-    HIP_TRY_M(mhk::launch_tree_pack(pa, int(O2_CTX), st));
-    // ---- the live contexts' own tables (text-like sources: a few hundred contexts over a few dozen byte values)
-    {
-        std::vector<uint64_t> weight(O2_CTX);
-        std::vector<uint8_t> live(O2_CTX);
-        for (uint32_t c = 0; c < O2_CTX; ++c) {
-            const uint32_t *mt = &meta[size_t(c) * mhk::TB_META_STRIDE];
-            weight[c] = (uint64_t(mt[14]) << 32) | mt[13];
-            live[c] = mt[1] != 0xFFFFFFFFu;
-        }
-        const int rc2 = o2_hot_setup(m, weight, live, d_node_height, st);
-        if (rc2 != MH_OK) return fail(rc2);
-    }
-    HIP_TRY_M(hipStreamSynchronize(st));                         // sec_base lives in pageable host memory
-#undef HIP_TRY_M
-    *out = m;
-    return MH_OK;
-}
-
-// counts (1 << 24, device) -> 65536 trees, codes and decode tables, all on the device
-// The ~600 MiB build block of an order-2 model is kept when a model is freed and handed to the next build on the same
-// device (a codec that rebuilds its model per stream — bench.py — otherwise pays a hipMalloc / hipFree of that size per step).
-struct Build2Cache { std::mutex mu; void *p = nullptr; int device = -1; } g_build2_cache;
-void *build2_block_take() {
-    std::lock_guard<std::mutex> lock(g_build2_cache.mu);
-    int dev = -1;
-    if (g_build2_cache.p && hipGetDevice(&dev) == hipSuccess && dev == g_build2_cache.device) {
-        void *p = g_build2_cache.p;
-        g_build2_cache.p = nullptr;
-        (void)hipDeviceSynchronize();             // what hipFree would have waited for: nothing still reads the freed model's tables
-        return p;
-    }
-    return nullptr;
-}
-void build2_block_give(void *p, int device) {
-    std::lock_guard<std::mutex> lock(g_build2_cache.mu);
-    if (g_build2_cache.p) (void)hipFree(g_build2_cache.p);
-    g_build2_cache.p = p; g_build2_cache.device = device;
-}
-
-int dev_model_build2(const uint64_t *d_counts, hipStream_t st, mh_model **out) {
-    void *b = build2_block_take();
-    if (!b) HIP_TRY(hipMalloc(&b, build2_layout().total));
-    const int rc = build2_slice(d_counts, 0, O2_CTX, static_cast<unsigned char *>(b), st);
-    if (rc != MH_OK) { (void)hipFree(b); return rc; }
-    return build2_finish(static_cast<unsigned char *>(b), true, st, out);     // (the model frees `b`, also when it fails)
-}
-
-// order-2 table file -> host-derived images (ContextCoder per non-empty context) -> device
-int model2_from_table(const uint8_t *bytes, size_t n, mh_model **out) {
-    mh_model *m = new (std::nothrow) mh_model;
-    if (!m) return MH_ERR_NOMEM;
-    m->type = 2; m->nctx = O2_CTX; m->mirror_ready = true;
-    m->dec_bits = 8; m->dec_lds = false; m->dec_direct = false; m->dec_h = 0;
-    m->table2.assign(bytes, bytes + n);
-    const size_t ne = size_t(O2_CTX) * 256;
-    std::vector<uint8_t> len8(ne, 0);
-    std::vector<uint64_t> code64(ne, 0);
-    std::vector<uint16_t> prim(ne, mh::DEC16_NULL), sec;
-    std::vector<uint32_t> tree(ne, 0), sec_base(O2_CTX, 0);
-    mh::BitReader in(bytes + 37, n - 37);
-    mh::ContextCoder cc;
-    std::vector<uint8_t> live2(O2_CTX, 0);
-    for (uint32_t c = 0; c < O2_CTX; ++c) {
-        sec_base[c] = uint32_t(sec.size());
-        if (in.bit()) {
-            live2[c] = 1;
-            if (!cc.load(in)) { delete m; return MH_ERR_BADTABLE; }
-            int live = 0;
-            for (int sy = 0; sy < 256; ++sy) {
-                const mh::Code &cd = cc.code(sy);
-                len8[size_t(c) * 256 + sy] = uint8_t(std::min(cd.len, 255));
-                code64[size_t(c) * 256 + sy] = cd.len <= 64 ? cd.right_aligned() : 0;
-                live += cd.len != 0;
-                if (cd.len && (m->min_len == 0 || cd.len < m->min_len)) m->min_len = cd.len;
-            }
-            m->max_len = std::max(m->max_len, cc.max_len());
-            if (live >= 2) for (int sy = 0; sy < 256; ++sy) m->len_gcd = gcd_u32(m->len_gcd, len8[size_t(c) * 256 + sy]);
-            cc.pack_decode(8, int(O2_HCAP), 0, &prim[size_t(c) << 8], sec, sec_base[c], &tree[size_t(c) * 256]);
-        }
-        if (in.failed()) { delete m; return MH_ERR_BADTABLE; }
-    }
-    m->nsec = uint32_t(sec.size());
-    if (!have_device() || m->max_len > mh::MAX_CODE_BITS) { *out = m; return MH_OK; }
-    auto fail = [&](int rc) { mh_model_free(m); return rc; };
-#define HIP_TRY_M(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(hip_fail(_e)); } while (0)
-    HIP_TRY_M(hipGetDevice(&m->device));
-    const Build2Layout L = build2_layout();
-    HIP_TRY_M(hipMalloc(&m->d_build, L.total));
-    uint8_t *d_node_height = nullptr;
-    place2(m, static_cast<unsigned char *>(m->d_build), L, &d_node_height);
-    m->d_node_left = m->d_node_right = nullptr; m->d_node_sym = nullptr; m->d_meta = nullptr;   // no trees on the device
-    const size_t sec_bytes = ((sec.size() * 2 + 15) & ~size_t(15)) + 16;
-    HIP_TRY_M(hipMalloc(&m->d_sec_own, sec_bytes));
-    m->d_sec = static_cast<uint16_t *>(m->d_sec_own);
-    HIP_TRY_M(hipMemset(m->d_sec_own, 0, sec_bytes));
-    HIP_TRY_M(hipMemcpy(m->d_len8, len8.data(), ne, hipMemcpyHostToDevice));
-    HIP_TRY_M(hipMemcpy(m->d_code64, code64.data(), ne * 8, hipMemcpyHostToDevice));
-    HIP_TRY_M(mhk::launch_enc64_pack(m->d_len8, m->d_code64, m->d_enc64, uint64_t(ne), nullptr));
-    HIP_TRY_M(hipStreamSynchronize(nullptr));
-    HIP_TRY_M(hipMemcpy(m->d_tree, tree.data(), ne * 4, hipMemcpyHostToDevice));
-    HIP_TRY_M(hipMemcpy(m->d_prim, prim.data(), ne * 2, hipMemcpyHostToDevice));
-    HIP_TRY_M(hipMemcpy(m->d_sec_base, sec_base.data(), size_t(O2_CTX) * 4, hipMemcpyHostToDevice));
-    if (!sec.empty()) HIP_TRY_M(hipMemcpy(m->d_sec, sec.data(), sec.size() * 2, hipMemcpyHostToDevice));
-    {   // the encoder's LDS image of the live contexts (no weights in a table file: every live context counts the same)
-        const int rc2 = o2_hot_setup(m, std::vector<uint64_t>(O2_CTX, 0), live2, nullptr, nullptr);
-        if (rc2 != MH_OK) return fail(rc2);
-    }
-#undef HIP_TRY_M
-    *out = m;
-    return MH_OK;
-}
-
-// table file of a device-built order-2 model, written from the node arrays
-int model2_write_table(const mh_model *m, std::vector<uint8_t> &out) {
-    if (!m->table2.empty()) { out = m->table2; return MH_OK; }
-    if (!m->d_node_left) return MH_ERR_NO_DEVICE;
-    const size_t nn = size_t(O2_CTX) * mhk::TB_NODE_STRIDE;
-    std::vector<uint16_t> left(nn), right(nn);
-    std::vector<uint8_t> sym(nn);
-    std::vector<uint32_t> meta(size_t(O2_CTX) * mhk::TB_META_STRIDE);
-    HIP_TRY(hipMemcpy(left.data(), m->d_node_left, nn * 2, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(right.data(), m->d_node_right, nn * 2, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(sym.data(), m->d_node_sym, nn, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(meta.data(), m->d_meta, meta.size() * 4, hipMemcpyDeviceToHost));
-    mh::BitWriter w;
-    w.bit(1);
-    for (int i = 0; i < 256 + 7; ++i) w.bit(0);                   // the empty order-1 table, zero padded
-    for (int i = 0; i < 4; ++i) w.byte(O2_MAGIC[i]);
-    std::vector<uint32_t> stack;
-    for (uint32_t c = 0; c < O2_CTX; ++c) {
-        const uint32_t root = meta[size_t(c) * mhk::TB_META_STRIDE + 1];
-        const uint16_t *l = &left[size_t(c) * mhk::TB_NODE_STRIDE], *r = &right[size_t(c) * mhk::TB_NODE_STRIDE];
-        const uint8_t *sy = &sym[size_t(c) * mhk::TB_NODE_STRIDE];
-        w.bit(root != 0xFFFFFFFFu);
-        if (root == 0xFFFFFFFFu) continue;
-        stack.assign(1, root);                                    // pre-order: inner -> 0, leaf -> 1 + symbol (src/huffman.cpp:174-188)
-        while (!stack.empty()) {
-            const uint32_t i = stack.back();
-            stack.pop_back();
-            if (l[i] == 0xFFFF) { w.bit(1); w.byte(sy[i]); }
-            else { w.bit(0); stack.push_back(r[i]); stack.push_back(l[i]); }
-        }
-    }
-    out = w.bytes();
-    return MH_OK;
-}
-}  // namespace
-
-size_t mh_dev_model_workspace(int order) { return order == 1 ? build_layout().fixed + MODEL_WS_SEC_BYTES + MODEL_WS_TILE_BYTES : 0; }
-
-int mh_dev_model_from_counts_ws(const uint64_t *d_counts, int order, void *d_ws, size_t ws_bytes, void *stream, mh_model **out) {
-    if (!d_counts || !out || order != 1 || !d_ws) return MH_ERR_ARG;
-    if (!have_device()) return MH_ERR_NO_DEVICE;
-    const int rc = dev_model_build(d_counts, d_ws, ws_bytes, static_cast<hipStream_t>(stream), out);
-    // the rare model the device packer does not lay out: built on the host instead (that model owns its memory)
-    if (rc == BUILD_NEEDS_HOST) return model_from_device_counts_via_host(d_counts, order, static_cast<hipStream_t>(stream), out);
-    return rc;
-}
-
-size_t mh_dev_model2_workspace(void) { return build2_layout().total; }
-
-int mh_dev_model2_array(int which, size_t *offset, size_t *bytes_per_context) {
-    // the per-context arrays a slice build fills: 0 code lengths, 1 codewords, 2..5 tree nodes (left, right, symbol,
-    // height), 6 per-context sizes
-    static const int idx[7] = {0, 1, 5, 6, 7, 8, 9};
-    static const size_t per[7] = {256, 256 * 8, size_t(mhk::TB_NODE_STRIDE) * 2, size_t(mhk::TB_NODE_STRIDE) * 2, size_t(mhk::TB_NODE_STRIDE),
-                                  size_t(mhk::TB_NODE_STRIDE), size_t(mhk::TB_META_STRIDE) * 4};
-    if (which < 0 || which >= 7 || !offset || !bytes_per_context) return MH_ERR_ARG;
-    *offset = build2_layout().off[idx[which]];
-    *bytes_per_context = per[which];
-    return MH_OK;
-}
-
-int mh_dev_model2_build_slice(const uint64_t *d_counts_slice, uint32_t ctx_first, uint32_t ctx_end, void *d_ws, size_t ws_bytes, void *stream) {
-    if (!d_counts_slice || !d_ws || !aligned16(d_ws) || ws_bytes < build2_layout().total) return MH_ERR_ARG;
-    if (!have_device()) return MH_ERR_NO_DEVICE;
-    return build2_slice(d_counts_slice, ctx_first, ctx_end, static_cast<unsigned char *>(d_ws), static_cast<hipStream_t>(stream));
-}
-
-int mh_dev_model2_finish(void *d_ws, size_t ws_bytes, void *stream, mh_model **out) {
-    if (!d_ws || !out || !aligned16(d_ws) || ws_bytes < build2_layout().total) return MH_ERR_ARG;
-    if (!have_device()) return MH_ERR_NO_DEVICE;
-    return build2_finish(static_cast<unsigned char *>(d_ws), false, static_cast<hipStream_t>(stream), out);
-}
-
-int mh_dev_model_from_counts(const uint64_t *d_counts, int order, void *stream, mh_model **out) {
-    if (!d_counts || !out || order < 0 || order > 2) return MH_ERR_ARG;
-    if (!have_device()) return MH_ERR_NO_DEVICE;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    if (order == 2) return dev_model_build2(d_counts, st, out);
-    if (order == 0) return model_from_device_counts_via_host(d_counts, order, st, out);   // one tree: not worth a kernel
-    int rc = dev_model_build(d_counts, nullptr, 0, st, out);
-    if (rc == BUILD_NEEDS_HOST) return model_from_device_counts_via_host(d_counts, order, st, out);
-    return rc;
-}
-
-int mh_model_from_table_bits(const uint8_t *bytes, size_t n, mh_model **out) {
-    if ((!bytes && n) || !out) return MH_ERR_ARG;
-    if (is_o2_table(bytes, n)) return model2_from_table(bytes, n, out);
-    mh_model *m = new (std::nothrow) mh_model;
-    if (!m) return MH_ERR_NOMEM;
-    if (!m->host.load_table(bytes, n)) { delete m; return MH_ERR_BADTABLE; }
-    return finish_model(m, out);
-}
-
-int mh_model_write_table(const mh_model *m, uint8_t *out, size_t cap, size_t *nbytes) {
-    if (!m || !nbytes) return MH_ERR_ARG;
-    std::vector<uint8_t> t;
-    if (m->type == 2) { int rc = model2_write_table(m, t); if (rc != MH_OK) return rc; }
-    else {
-        int rc = ensure_mirror(m); if (rc != MH_OK) return rc;
-        t = m->host.save_table();
-    }
-    *nbytes = t.size();
-    if (!out) return MH_OK;
-    if (cap < t.size()) return MH_ERR_CAPACITY;
-    if (!t.empty()) std::memcpy(out, t.data(), t.size());
-    return MH_OK;
-}
-
-int mh_model_type(const mh_model *m) { return m ? m->type : MH_ERR_ARG; }
-
-int mh_model_max_code_len(const mh_model *m) { return m ? m->max_len : MH_ERR_ARG; }
-int mh_model_min_code_len(const mh_model *m) { return m ? m->min_len : MH_ERR_ARG; }
-
-int mh_model_get_code(const mh_model *m, int prev, int sym, int *len, uint64_t *code) {
-    if (!m || !len || !code) return MH_ERR_ARG;
-    if (m->type == 2) {                                          // prev = the 16-bit context; read straight from the device tables
-        if (!m->d_len8) return MH_ERR_NO_DEVICE;
-        const size_t i = (size_t(prev & 0xFFFF) << 8) | size_t(sym & 255);
-        uint8_t l = 0;
-        HIP_TRY(hipMemcpy(&l, m->d_len8 + i, 1, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(code, m->d_code64 + i, 8, hipMemcpyDeviceToHost));
-        *len = l;
-        return MH_OK;
-    }
-    { int rc = ensure_mirror(m); if (rc != MH_OK) return rc; }
-    const mh::Code &c = m->host.context(prev).code(sym);
-    *len = c.len;
-    *code = c.len <= 64 ? c.right_aligned() : 0;
-    return MH_OK;
-}
-
-int mh_model_get_lut(const mh_model *m, int prev, int w, int *present, int *is_internal, int *value, int *depth) {
-    if (!m || !present || !is_internal || !value || !depth || m->type == 2) return MH_ERR_ARG;
-    { int rc = ensure_mirror(m); if (rc != MH_OK) return rc; }
-    const mh::ContextCoder &c = m->host.context(prev);
-    int n = c.lut(w);
-    *present = n >= 0;
-    *is_internal = *value = *depth = 0;
-    if (n >= 0) {
-        *is_internal = !c.node(n).leaf;
-        *value = c.node(n).sym;
-        *depth = c.node(n).depth;
-    }
-    return MH_OK;
-}
-
-int mh_model_decode_layout(const mh_model *m, int *primary_bits, int *secondary_entries, int *in_lds) {
-    if (!m || !primary_bits || !secondary_entries || !in_lds) return MH_ERR_ARG;
-    *primary_bits = m->dec_bits;
-    *secondary_entries = int(m->nsec);
-    *in_lds = m->dec_lds ? 1 : 0;
-    return MH_OK;
-}
-
-int mh_model_tile_layout(const mh_model *m, int *primary_bits, int *secondary_bits, int *secondary_entries) {
-    if (!m || !primary_bits || !secondary_bits || !secondary_entries) return MH_ERR_ARG;
-    const bool o2 = m->type == 2;
-    *primary_bits = o2 ? (m->o2_dec_ok ? int(m->o2_p) : 0) : m->tile_p;
-    *secondary_bits = o2 ? int(m->o2_h) : m->tile_h;
-    *secondary_entries = o2 ? int(m->o2_nsec) : int(m->tile_nsec);
-    return MH_OK;
-}
-
-int mh_model_image(const mh_model *m, int which, void *out, size_t cap, size_t *bytes) {
-    if (!m || !bytes) return MH_ERR_ARG;
-    if (!m->d_len8) return MH_ERR_NO_DEVICE;
-    const void *src = nullptr;
-    size_t n = 0;
-    const size_t nc = m->nctx;                                   // 256, or 65536 for an order-2 model (which has no enc16 / len_slot)
-    switch (which) {
-        case 0: src = m->d_enc16; n = m->d_enc16 ? 65536 * 2 : 0; break;
-        case 1: src = m->d_len8; n = nc * 256; break;
-        case 2: src = m->d_len_slot; n = m->d_len_slot ? 65536 : 0; break;
-        case 3: src = m->d_code64; n = nc * 256 * 8; break;
-        case 4: src = m->d_prim; n = (nc << m->dec_bits) * 2; break;
-        case 5: src = m->d_sec; n = size_t(m->nsec) * 2; break;
-        case 6: src = m->d_sec_base; n = nc * 4; break;
-        case 7: src = m->d_tree; n = nc * mh::TREE_STRIDE * 4; break;
-        case 8: src = m->d_tprim; n = m->tile_p ? (size_t(256) << m->tile_p) * 2 : 0; break;
-        case 9: src = m->d_tsec; n = size_t(m->tile_nsec) * 2; break;
-        default: return MH_ERR_ARG;
-    }
-    *bytes = n;
-    if (!out) return MH_OK;
-    if (cap < n) return MH_ERR_CAPACITY;
-    if (n) HIP_TRY(hipMemcpy(out, src, n, hipMemcpyDeviceToHost));
-    return MH_OK;
-}
-
-void mh_model_free(mh_model *m) {
-    if (!m) return;
-    if (m->d_block) (void)hipFree(m->d_block);
-    if (m->d_build) {
-        if (m->type == 2 && m->build_cached) build2_block_give(m->d_build, m->device);   // (waits for nothing: the caller has finished with the model)
-        else (void)hipFree(m->d_build);
-    }
-    if (m->d_sec_own) (void)hipFree(m->d_sec_own);
-    if (m->d_tile_own) (void)hipFree(m->d_tile_own);
-    if (m->d_o2hot) (void)hipFree(m->d_o2hot);
-    delete m;
 }
 
 /* ------------------------------------------------------------ device calls */
@@ -1208,7 +288,9 @@ static int dev_encode_hist(const mh_model *m, const uint8_t *d_data, size_t n, u
 // (byte before previous) << 8 | previous byte
 // set around a retry: the one-pass order-2 encoder gave up waiting (its workgroups were not all resident: a device shared
 // with a long-running kernel of somebody else), the host-side callers that synchronise anyway run the two-pass pair instead
-static thread_local bool t_no_chain = false;
+}  // extern "C" (two items the host-buffer calls share: mh_api_internal.hpp)
+namespace mhapi { thread_local bool t_no_chain = false; }
+extern "C" {
 
 static int dev_encode_ctx(const mh_model *m, const uint8_t *d_data, size_t n, uint32_t ctx0, const uint64_t *d_start_bit,
                           uint8_t *d_payload, size_t cap, uint64_t *d_nbits, uint64_t *d_index, uint32_t chunk_symbols,
@@ -1288,7 +370,6 @@ int mh_dev_encode_fine(const mh_model *m, const uint8_t *d_data, size_t n, uint8
                            d_ws, ws_bytes, stream, d_fine);
 }
 
-static uint32_t ctx_of_prev0(const mh_model *m, uint8_t prev0) { return m && m->type == 2 ? (uint32_t(prev0) << 8 | prev0) : prev0; }
 
 int mh_dev_encode_ctx(const mh_model *m, const uint8_t *d_data, size_t n, uint32_t ctx0, const uint64_t *d_start_bit,
                       uint8_t *d_payload, size_t cap, uint64_t *d_nbits, uint64_t *d_index, uint32_t chunk_symbols,
@@ -1505,423 +586,5 @@ int mh_dev_status(const void *d_ws, void *stream) {
 
 /* ------------------------------------------------------- host-buffer calls */
 
-// Host-buffer calls stage their data through HBM in segments, so their device footprint is bounded
-// whatever the input size (a 16 GiB file does not need 16 GiB + its worst-case payload on the card).
-// MH_SEGMENT_BYTES overrides the 256 MiB default (tests use small values to put seams everywhere).
-// The segment size is a multiple of the largest chunk size, so chunk boundaries fall on segment
-// boundaries.
-static size_t segment_bytes() {
-    size_t s = size_t(256) << 20;
-    if (const char *e = getenv("MH_SEGMENT_BYTES")) {
-        const unsigned long long v = strtoull(e, nullptr, 10);
-        if (v) s = size_t(v);
-    }
-    s &= ~size_t(MH_CHUNK_MAX - 1);
-    return s < MH_CHUNK_MAX ? size_t(MH_CHUNK_MAX) : s;
-}
-
-// ---- input residency (mh_set_input_residency): the histogram pass leaves its upload in HBM and the next
-// mh_encode of the same host buffer reads it there, so a compress moves the file over PCIe once.
-namespace {
-struct ResidentInput {
-    std::mutex mu;
-    bool enabled = false;
-    const void *host = nullptr;
-    size_t n = 0;
-    uint64_t sig = 0;
-    void *dev = nullptr;
-    int device = -1;
-    void drop() { if (dev) (void)hipFree(dev); dev = nullptr; host = nullptr; n = 0; }
-} g_resident;
-
-// size + three sampled 4 KiB blocks: guards against a DIFFERENT buffer at a recycled address, not against a
-// caller who edits the buffer in between (the option's contract forbids that)
-uint64_t sample_signature(const uint8_t *p, size_t n) {
-    uint64_t h = 1469598103934665603ull ^ n;
-    auto mix = [&](size_t off) {
-        const size_t len = std::min<size_t>(4096, n - off);
-        for (size_t i = 0; i < len; ++i) { h ^= p[off + i]; h *= 1099511628211ull; }
-    };
-    if (n) { mix(0); mix(n / 2); mix(n - std::min<size_t>(n, 4096)); }
-    return h;
-}
-}  // namespace
-
-int mh_set_input_residency(int on) {
-    std::lock_guard<std::mutex> lock(g_resident.mu);
-    g_resident.enabled = on != 0;
-    if (!on) g_resident.drop();
-    return MH_OK;
-}
-
-static int histogram_host(const uint8_t *data, size_t n, uint8_t prev0, uint64_t *counts, int order) {
-    if ((!data && n) || !counts) return MH_ERR_ARG;
-    if (!have_device()) return MH_ERR_NO_DEVICE;
-    const size_t nc = order == 2 ? (size_t(1) << 24) : order ? 65536 : 256;
-    const size_t seg = segment_bytes();
-    PhaseClock clock;
-    struct Scope { PhaseClock *c; size_t n; Scope(PhaseClock *cc, size_t nn) : c(cc), n(nn) { g_phase = c; } ~Scope() { c->report("histogram", n); g_phase = nullptr; } } scope(&clock, n);
-    DevBuf d_data, d_counts, d_hws;
-    // with residency on, the whole input stays on the card (when it leaves half of the free memory alone)
-    uint8_t *d_all = nullptr;
-    {
-        std::lock_guard<std::mutex> lock(g_resident.mu);
-        g_resident.drop();
-        size_t free_b = 0, total_b = 0;
-        if (g_resident.enabled && n >= seg && hipMemGetInfo(&free_b, &total_b) == hipSuccess && n + (size_t(1) << 30) < free_b / 2) {
-            void *p = nullptr;
-            if (hipMalloc(&p, n + 64) == hipSuccess) {
-                d_all = static_cast<uint8_t *>(p);
-                g_resident.dev = p; g_resident.host = data; g_resident.n = n; g_resident.sig = sample_signature(data, n);
-                (void)hipGetDevice(&g_resident.device);
-            }
-        }
-    }
-    if (!d_all) HIP_TRY(d_data.alloc(n < seg ? n : seg));
-    HIP_TRY(d_counts.alloc(nc * 8));
-    const size_t hws = order == 1 && n >= (size_t(1) << 20) ? mh_dev_histogram_workspace(n)   // pays from about a megabyte on
-                       : order == 2 ? mh_dev_histogram_o2_workspace(n < seg ? n : seg) : 0;  // (order 2: room for the partition path)
-    size_t hws_have = hws;
-    if (hws) {
-        const hipError_t he = d_hws.alloc(hws);
-        if (he != hipSuccess) {
-            // order 2's partition workspace is optional (about 2 bytes per segment byte): without it launch_hist_o2 keeps
-            // everything in the tag cache — slower on flat sources, same counts.  Order 1's is small: an error.
-            if (order != 2) HIP_TRY(he);
-            (void)hipGetLastError();
-            hws_have = 0;
-        }
-    }
-    std::vector<uint64_t> part(nc);
-    for (size_t i = 0; i < nc; ++i) counts[i] = 0;
-    for (size_t off = 0; off < n || off == 0; off += seg) {
-        const size_t len = n - off < seg ? n - off : seg;
-        uint8_t *d_seg = d_all ? d_all + off : d_data.as<uint8_t>();   // segment sizes are multiples of 8 KiB: aligned
-        if (len) HIP_TRY(stage_h2d(d_seg, data + off, len, nullptr));
-        const uint8_t p0 = off ? data[off - 1] : prev0;            // context carried across the seam (src/main.cpp:32,36)
-        const uint16_t c0 = off ? uint16_t(data[off - 2] << 8 | data[off - 1]) : uint16_t(prev0 << 8 | prev0);   // segments are >= 8 KiB
-        int rc = order == 2 ? mh_dev_histogram_o2_ws(d_seg, len, c0, d_counts.as<uint64_t>(), hws_have ? d_hws.p : nullptr, hws_have, nullptr)
-                 : order ? mh_dev_histogram_o1(d_seg, len, p0, d_counts.as<uint64_t>(), hws ? d_hws.p : nullptr, hws, nullptr)
-                         : mh_dev_histogram_o0(d_seg, len, d_counts.as<uint64_t>(), nullptr, 0, nullptr);
-        if (rc != MH_OK) return rc;
-        HIP_TRY(hipMemcpy(part.data(), d_counts.p, nc * 8, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < nc; ++i) counts[i] += part[i];
-        if (n == 0) break;
-    }
-    return MH_OK;
-}
-
-int mh_histogram_o1(const uint8_t *data, size_t n, uint8_t prev0, uint64_t *counts) {
-    return histogram_host(data, n, prev0, counts, 1);
-}
-
-int mh_histogram_o0(const uint8_t *data, size_t n, uint64_t *counts) { return histogram_host(data, n, 0, counts, 0); }
-
-int mh_histogram_o2(const uint8_t *data, size_t n, uint64_t *counts) { return histogram_host(data, n, MH_PREV0, counts, 2); }
-
-size_t mh_encode_bound(const mh_model *m, size_t n) {
-    size_t maxlen = m ? size_t(m->max_len) : 64;
-    if (maxlen < 1) maxlen = 1;
-    return (n * maxlen + 7) / 8 + 16;
-}
-
-uint8_t mh_stream_header(const mh_model *m, uint64_t nbits) {
-    int type = m ? m->type : 1;
-    int bi = int(nbits & 7u);
-    if (type == 2) return uint8_t(0x40 | ((8 - bi) % 8));         // order-2 extension: its own magic nibble (the reference rejects it)
-    return uint8_t(0x30 | ((~type & 1) << 3) | ((8 - bi) % 8));   // src/coding.cpp:88
-}
-
-int mh_stream_parse_header(const mh_model *m, uint8_t header, uint64_t file_bytes, uint64_t *nbits) {
-    if (!m || !nbits || file_bytes < 1) return MH_ERR_ARG;
-    if (m->type == 2) {
-        if ((header & 0xF8) != 0x40) return (header & 0xF0) == 0x30 ? MH_ERR_TYPE : MH_ERR_CORRUPT;
-    } else {
-        if ((header & 0xF0) != 0x30) return (header & 0xF8) == 0x40 ? MH_ERR_TYPE : MH_ERR_CORRUPT;   // src/coding.cpp:103-106
-        if (((~(header & (1 << 3)) >> 3) & 1) != m->type) return MH_ERR_TYPE;  // src/coding.cpp:107-110
-    }
-    uint64_t total = (file_bytes - 1) * 8;
-    uint64_t rem = header & 7u;                                                 // src/coding.cpp:111-115
-    if (rem > total) return MH_ERR_CORRUPT;
-    *nbits = total - rem;
-    return MH_OK;
-}
-
-int mh_encode(const mh_model *m, const uint8_t *data, size_t n, uint8_t prev0, uint8_t *out_payload, size_t cap,
-              uint64_t *nbits, uint64_t *index, uint32_t chunk_symbols) {
-    if (!m || (!data && n) || !nbits || (!out_payload && cap)) return MH_ERR_ARG;
-    if (index && chunk_shift_of(chunk_symbols) < 0) return MH_ERR_ARG;
-    if (!have_device()) return MH_ERR_NO_DEVICE;
-    if (m->max_len > mh::MAX_CODE_BITS) return MH_ERR_CODE_TOO_LONG;
-    g_encode_retries = 0;
-    hipStream_t st = nullptr;
-    PhaseClock clock;
-    struct Scope { PhaseClock *c; size_t n; Scope(PhaseClock *cc, size_t nn) : c(cc), n(nn) { g_phase = c; } ~Scope() { c->report("encode", n); g_phase = nullptr; } } scope(&clock, n);
-    // Segment by segment: each one is encoded pre-shifted to the bit where the previous one ended
-    // (mh_dev_encode_at), so its bytes drop into the output with one OR-merged seam byte.
-    const size_t seg = segment_bytes();
-    const size_t slen = n < seg ? n : seg;
-    const size_t dcap = mh_encode_bound(m, slen) + 16;
-    const size_t sidx = index ? size_t(mh_index_entries(slen, chunk_symbols)) : 0;
-    const size_t wsb = mh_dev_encode_workspace(slen);
-    DevBuf d_data, d_out, d_nbits, d_start, d_index, d_ws;
-    // the histogram pass may have left this very buffer on the card (mh_set_input_residency): consumed here
-    struct Held { void *p = nullptr; ~Held() { if (p) (void)hipFree(p); } } resident;
-    {
-        std::lock_guard<std::mutex> lock(g_resident.mu);
-        int dev = -1;
-        if (g_resident.dev && g_resident.host == data && g_resident.n == n && hipGetDevice(&dev) == hipSuccess &&
-            dev == g_resident.device && g_resident.sig == sample_signature(data, n)) {
-            resident.p = g_resident.dev;
-            g_resident.dev = nullptr;
-        }
-        g_resident.drop();
-    }
-    const uint8_t *d_all = static_cast<const uint8_t *>(resident.p);
-    if (!d_all) HIP_TRY(d_data.alloc(slen));
-    HIP_TRY(d_out.alloc(dcap));
-    HIP_TRY(d_nbits.alloc(8));
-    HIP_TRY(d_start.alloc(8));
-    HIP_TRY(d_index.alloc(sidx * 8));
-    HIP_TRY(d_ws.alloc(wsb));
-    std::vector<uint64_t> seg_index(sidx);
-    uint64_t start = 0;                                          // global bit position of the next segment
-    for (size_t off = 0; off < n; off += seg) {
-        const size_t len = n - off < seg ? n - off : seg;
-        const uint8_t *d_seg = d_all ? d_all + off : d_data.as<uint8_t>();
-        if (!d_all) HIP_TRY(stage_h2d(d_data.p, data + off, len, st));
-        HIP_TRY(hipMemcpy(d_start.p, &start, 8, hipMemcpyHostToDevice));
-        const uint32_t c0 = m->type == 2 ? (off ? uint32_t(data[off - 2]) << 8 | data[off - 1] : ctx_of_prev0(m, prev0))
-                                         : (off ? data[off - 1] : prev0);      // segments are >= 8 KiB, so off >= 2 when not 0
-        int rc = dev_encode_ctx(m, d_seg, len, c0, d_start.as<uint64_t>(), d_out.as<uint8_t>(), dcap,
-                                d_nbits.as<uint64_t>(), index ? d_index.as<uint64_t>() : nullptr, chunk_symbols, d_ws.p, wsb, st, nullptr);
-        if (rc != MH_OK) return rc;
-        rc = mh_dev_status(d_ws.p, st);
-        if (rc == MH_ERR_TIMEOUT && !t_no_chain) {               // (see t_no_chain)
-            ++g_encode_retries;                                  // never silent: mh_last_encode_retries(), MH_TIMING line
-            clock.retries = g_encode_retries;
-            g_encode_retries_total.fetch_add(1, std::memory_order_relaxed);
-            t_no_chain = true;
-            rc = dev_encode_ctx(m, d_seg, len, c0, d_start.as<uint64_t>(), d_out.as<uint8_t>(), dcap,
-                                d_nbits.as<uint64_t>(), index ? d_index.as<uint64_t>() : nullptr, chunk_symbols, d_ws.p, wsb, st, nullptr);
-            t_no_chain = false;
-            if (rc == MH_OK) rc = mh_dev_status(d_ws.p, st);
-        }
-        if (rc != MH_OK) return rc;
-        uint64_t end = 0;                                        // end position inside the segment's buffer
-        HIP_TRY(hipMemcpy(&end, d_nbits.p, 8, hipMemcpyDeviceToHost));
-        const uint64_t lead = start & 7u;
-        const size_t obyte = size_t(start >> 3);                 // output byte the segment's buffer starts at
-        const size_t nbytes = size_t((end + 7) / 8);
-        if (obyte + nbytes > cap) return MH_ERR_CAPACITY;
-        if (nbytes) {
-            size_t skip = 0;
-            if (lead) {                                          // seam byte shared with the previous segment
-                uint8_t first = 0;
-                HIP_TRY(hipMemcpy(&first, d_out.p, 1, hipMemcpyDeviceToHost));
-                out_payload[obyte] |= first;
-                skip = 1;
-            }
-            if (nbytes > skip)
-                HIP_TRY(stage_d2h(out_payload + obyte + skip, d_out.as<uint8_t>() + skip, nbytes - skip, st));
-        }
-        if (index) {
-            const size_t ne = size_t(mh_index_entries(len, chunk_symbols));
-            HIP_TRY(hipMemcpy(seg_index.data(), d_index.p, ne * 8, hipMemcpyDeviceToHost));
-            uint64_t *dst = index + off / chunk_symbols;         // seg is a multiple of every chunk size
-            for (size_t i = 0; i < ne; ++i) dst[i] = seg_index[i] + uint64_t(obyte) * 8;   // buffer position -> stream position
-        }
-        start += end - lead;
-    }
-    *nbits = start;
-    return MH_OK;
-}
-
-int mh_decode_to(const mh_model *m, const uint8_t *payload, uint64_t nbits, uint8_t prev0, mh_output_fn get_out, void *ctx,
-                 size_t *nbytes, const uint64_t *index, uint32_t chunk_symbols, uint64_t n_symbols) {
-    if (!m || (!payload && nbits) || !nbytes || !get_out) return MH_ERR_ARG;
-    if (!have_device()) return MH_ERR_NO_DEVICE;
-    uint8_t *out = nullptr;
-    if (!index) chunk_symbols = MH_CHUNK_DEFAULT;
-    if (chunk_shift_of(chunk_symbols) < 0) return MH_ERR_ARG;
-    hipStream_t st = nullptr;
-    PhaseClock clock;
-    struct Scope { PhaseClock *c; size_t *n; Scope(PhaseClock *cc, size_t *nn) : c(cc), n(nn) { g_phase = c; } ~Scope() { c->report("decode", *n); g_phase = nullptr; } } scope(&clock, nbytes);
-    size_t pbytes = size_t((nbits + 7) / 8);
-    if (index) {
-        // With an index the stream is decoded segment by segment: a run of whole chunks needs only the
-        // payload bytes between its first and its following index entry.
-        *nbytes = size_t(n_symbols);
-        out = get_out(ctx, size_t(n_symbols));
-        if (!out && n_symbols) return MH_ERR_CAPACITY;
-        const uint64_t MASK = m->type == 2 ? MH_INDEX2_BIT_MASK : MH_INDEX_BIT_MASK;
-        const size_t seg = segment_bytes();
-        const uint64_t nchunks = mh_index_entries(n_symbols, chunk_symbols);
-        const size_t slen = n_symbols < seg ? size_t(n_symbols) : seg;
-        const size_t sidx = size_t(mh_index_entries(slen, chunk_symbols));
-        const size_t dws = mh_dev_decode_workspace(0, slen, chunk_symbols);
-        DevBuf d_pl, d_idx, d_dws, d_o;
-        size_t pl_cap = 0;
-        HIP_TRY(d_idx.alloc(sidx * 8));
-        HIP_TRY(d_dws.alloc(dws));
-        HIP_TRY(d_o.alloc(slen));
-        std::vector<uint64_t> seg_index(sidx);
-        for (uint64_t off = 0; off < n_symbols; off += seg) {
-            const size_t len = n_symbols - off < seg ? size_t(n_symbols - off) : seg;
-            const uint64_t c0 = off / chunk_symbols;
-            const size_t ne = size_t(mh_index_entries(len, chunk_symbols));
-            const uint64_t pos0 = index[c0] & MASK;
-            const uint64_t pos1 = c0 + ne < nchunks ? (index[c0 + ne] & MASK) : nbits;
-            if (pos0 > pos1 || pos1 > nbits) return MH_ERR_CORRUPT;
-            const uint64_t hb0 = (pos0 >> 3) & ~uint64_t(15);    // the device wants the payload 16-byte aligned
-            const uint64_t hb1 = (pos1 + 7) >> 3;
-            const size_t need = size_t(hb1 - hb0);
-            if (need > pl_cap) {
-                if (d_pl.p) { (void)hipFree(d_pl.p); d_pl.p = nullptr; }
-                pl_cap = need + (need >> 2) + 64;
-                HIP_TRY(d_pl.alloc(pl_cap));
-            }
-            if (need) HIP_TRY(stage_h2d(d_pl.p, payload + hb0, need, st));
-            for (size_t i = 0; i < ne; ++i) {
-                const uint64_t e = index[c0 + i];
-                if ((e & MASK) < pos0) return MH_ERR_CORRUPT;
-                seg_index[i] = (e & ~MASK) | ((e & MASK) - hb0 * 8);
-            }
-            HIP_TRY(hipMemcpy(d_idx.p, seg_index.data(), ne * 8, hipMemcpyHostToDevice));
-            int rc = mh_dev_decode(m, d_pl.as<uint8_t>(), pos1 - hb0 * 8, d_o.as<uint8_t>(), len, d_idx.as<uint64_t>(), chunk_symbols,
-                                   d_dws.p, dws, st);
-            if (rc != MH_OK) return rc;
-            rc = mh_dev_status(d_dws.p, st);
-            if (rc != MH_OK) return rc;
-            HIP_TRY(stage_d2h(out + off, d_o.p, len, st));
-        }
-        return MH_OK;
-    }
-    // No index (what the reference writes): the whole payload goes to the card, the index is rebuilt
-    // there, and the output comes back segment by segment.
-    DevBuf d_payload, d_index, d_ws, d_nsym, d_out;
-    HIP_TRY(d_payload.alloc(pbytes));
-    if (pbytes) HIP_TRY(stage_h2d(d_payload.p, payload, pbytes, st));
-    HIP_TRY(d_nsym.alloc(8));
-    // [r5] two passes over the payload and no index at all (mh_dev_decode_stream_states / _emit): the segments' states, then the
-    // bytes.  Streams and models that do not take that path — and cards without room for the whole output at once — build
-    // both indices and decode from them, as before.
-    if (m->type != 2 && !getenv("MH_DECODE_NO_STREAM")) {
-        DevBuf d_iws, d_all;
-        const size_t iws = mh_dev_build_index_workspace(nbits);
-        HIP_TRY(d_iws.alloc(iws));
-        int rc = mh_dev_decode_stream_states(m, d_payload.as<uint8_t>(), nbits, prev0, d_nsym.as<uint64_t>(), d_iws.p, iws, st);
-        if (rc != MH_OK) return rc;
-        rc = mh_dev_status(d_iws.p, st);
-        if (rc != MH_OK) return rc;
-        if (mh_dev_index_path(d_iws.p, st) == mhk::IDX_PATH_STATES) {
-            HIP_TRY(hipMemcpy(&n_symbols, d_nsym.p, 8, hipMemcpyDeviceToHost));
-            if (d_all.alloc(size_t(n_symbols)) == hipSuccess) {
-                *nbytes = size_t(n_symbols);
-                out = get_out(ctx, size_t(n_symbols));           // the size is known only now
-                if (!out && n_symbols) return MH_ERR_CAPACITY;
-                rc = mh_dev_decode_stream_emit(m, d_payload.as<uint8_t>(), nbits, prev0, d_all.as<uint8_t>(), n_symbols, d_iws.p, iws, st);
-                if (rc != MH_OK) return rc;
-                rc = mh_dev_status(d_iws.p, st);
-                if (rc != MH_OK) return rc;
-                g_last_index_path = mhk::IDX_PATH_STATES;
-                const size_t seg = segment_bytes();
-                for (uint64_t off = 0; off < n_symbols; off += seg) {
-                    const size_t len = n_symbols - off < seg ? size_t(n_symbols - off) : seg;
-                    HIP_TRY(stage_d2h(out + off, d_all.as<uint8_t>() + off, len, st));
-                }
-                return MH_OK;
-            }
-            (void)hipGetLastError();                             // no room for the whole output: the indexed way, segment by segment
-        }
-    }
-    // every code is at least one bit: the stream holds at most nbits symbols
-    const uint64_t idx_cap = nbits / chunk_symbols + 2;
-    HIP_TRY(d_index.alloc(size_t(idx_cap) * 8));
-    // the fill pass of the index builder also writes the fine index (one uint32 per 64 symbols): the stream then
-    // decodes with the tile decoder although it came without any index
-    DevBuf d_fine;
-    // (nbits / 64 entries = half the payload's size again: a bound for 1-bit codes.  The fine index only buys speed, so a
-    // card that cannot spare it decodes with the chunk decoder instead of failing — ADVICE r03)
-    // (a code has at least min_len bits: nbits / min_len symbols at most — ADVICE r03 / VERDICT r04)
-    uint64_t fine_cap = m->type == 2 ? 0 : nbits / uint64_t(m->min_len > 0 ? m->min_len : 1) / MH_FINE_SYMBOLS + 2;
-    if (fine_cap && d_fine.alloc(size_t(fine_cap) * 4) != hipSuccess) {
-        (void)hipGetLastError();
-        fine_cap = 0;
-    }
-    {
-        DevBuf d_iws;
-        const size_t iws = mh_dev_build_index_workspace(nbits);
-        HIP_TRY(d_iws.alloc(iws));
-        int rc = mh_dev_build_index_fine(m, d_payload.as<uint8_t>(), nbits, prev0, d_index.as<uint64_t>(), idx_cap, chunk_symbols,
-                                         fine_cap ? d_fine.as<uint32_t>() : nullptr, fine_cap, d_nsym.as<uint64_t>(), d_iws.p, iws, st);
-        if (rc != MH_OK) return rc;
-        rc = mh_dev_status(d_iws.p, st);
-        if (rc != MH_OK) return rc;
-        g_last_index_path = mh_dev_index_path(d_iws.p, st);
-    }
-    HIP_TRY(hipMemcpy(&n_symbols, d_nsym.p, 8, hipMemcpyDeviceToHost));
-    *nbytes = size_t(n_symbols);
-    out = get_out(ctx, size_t(n_symbols));                       // the size is known only now
-    if (!out && n_symbols) return MH_ERR_CAPACITY;
-    const size_t seg = segment_bytes();
-    const size_t slen = n_symbols < seg ? size_t(n_symbols) : seg;
-    const uint64_t nchunks = mh_index_entries(n_symbols, chunk_symbols);
-    HIP_TRY(d_out.alloc(slen));
-    const size_t dws = mh_dev_decode_workspace(nbits, slen, chunk_symbols);
-    HIP_TRY(d_ws.alloc(dws));
-    for (uint64_t off = 0; off < n_symbols; off += seg) {
-        const size_t len = n_symbols - off < seg ? size_t(n_symbols - off) : seg;
-        const uint64_t c0 = off / chunk_symbols;
-        const uint64_t ne = mh_index_entries(len, chunk_symbols);
-        uint64_t end_bits = nbits;                               // a segment ends where the next one's first chunk starts
-        if (c0 + ne < nchunks) {
-            HIP_TRY(hipMemcpy(&end_bits, d_index.as<uint64_t>() + c0 + ne, 8, hipMemcpyDeviceToHost));
-            end_bits &= m->type == 2 ? MH_INDEX2_BIT_MASK : MH_INDEX_BIT_MASK;
-        }
-        int rc = mh_dev_decode_fine(m, d_payload.as<uint8_t>(), end_bits, nullptr, d_out.as<uint8_t>(), len, d_index.as<uint64_t>() + c0,
-                                    chunk_symbols, fine_cap ? d_fine.as<uint32_t>() + off / MH_FINE_SYMBOLS : nullptr, d_ws.p, dws, st);
-        if (rc != MH_OK) return rc;
-        rc = mh_dev_status(d_ws.p, st);
-        if (rc != MH_OK) return rc;
-        HIP_TRY(stage_d2h(out + off, d_out.p, len, st));
-    }
-    return MH_OK;
-}
-
-namespace {
-struct FixedOut { uint8_t *p; size_t cap; };
-uint8_t *fixed_out(void *ctx, size_t n) {
-    FixedOut *f = static_cast<FixedOut *>(ctx);
-    return n <= f->cap ? f->p : nullptr;
-}
-}  // namespace
-
-int mh_decode(const mh_model *m, const uint8_t *payload, uint64_t nbits, uint8_t prev0, uint8_t *out, size_t cap,
-              size_t *nbytes, const uint64_t *index, uint32_t chunk_symbols, uint64_t n_symbols) {
-    if (!out && cap) return MH_ERR_ARG;
-    FixedOut f{out, out ? cap : 0};
-    return mh_decode_to(m, payload, nbits, prev0, fixed_out, &f, nbytes, index, chunk_symbols, n_symbols);
-}
-
-int mh_model_payload_bits(const mh_model *m, const uint64_t *counts, uint64_t *nbits) {
-    if (!m || !counts || !nbits) return MH_ERR_ARG;
-    if (m->type == 2) {                                          // counts: 1 << 24 entries; the lengths come from the device table
-        if (!m->d_len8) return MH_ERR_NO_DEVICE;
-        std::vector<uint8_t> len8(size_t(1) << 24);
-        HIP_TRY(hipMemcpy(len8.data(), m->d_len8, len8.size(), hipMemcpyDeviceToHost));
-        uint64_t total = 0;
-        for (size_t i = 0; i < len8.size(); ++i) total += counts[i] * len8[i];
-        *nbits = total;
-        return MH_OK;
-    }
-    { int rc = ensure_mirror(m); if (rc != MH_OK) return rc; }
-    const int nctx = m->type ? 256 : 1;
-    uint64_t total = 0;
-    for (int c = 0; c < nctx; ++c)
-        for (int sym = 0; sym < 256; ++sym) total += counts[c * 256 + sym] * uint64_t(m->host.context(c).code(sym).len);
-    *nbits = total;
-    return MH_OK;
-}
 
 }  // extern "C"

@@ -1,6 +1,6 @@
 """CPU sanitizer configuration (SURVEY.md 5 "race detection / sanitizers").  The reference strips its 29 asserts with -DNDEBUG
 (Makefile:20-21; e.g. src/coding.cpp:72,127-128) and its table loader recurses over untrusted bits with no bounds checks
-(src/huffman.cpp:166-172).  Here the HOST code — mh_model.cpp, mh_api.cpp, host/coding.cpp, host/main.cpp — is built with
+(src/huffman.cpp:166-172).  Here the HOST code — mh_model.cpp, mh_api*.cpp, host/coding.cpp, host/main.cpp — is built with
 AddressSanitizer + UndefinedBehaviorSanitizer (`make -C markov-huffman-coding_amd/csrc asan`, CPU build only: kernels are
 not instrumented) and driven three ways, none of which needs a GPU:
   * the table-file mutation fuzz (csrc/sanitize/fuzz_table.cpp): 10 000 truncations / bit flips / splices of the golden
